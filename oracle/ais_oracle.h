@@ -1,0 +1,119 @@
+/*
+ * ais_oracle.h -- CPU restatement (plain C) of the gr-ais demod hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke test
+ * in __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The
+ * product (gr-ais_amd/) never includes, links or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference (bistromath/gr-ais) ships
+ * no tests, golden vectors or fixtures (lib/qa_ais.cc:30-36 is an empty
+ * suite) and cannot be built here (GNU Radio >=3.8, VOLK, Boost, FFTW absent;
+ * CMakeLists.txt:71).  This file restates the reference's control flow line
+ * by line (citations on every function) plus the four third-party kernels it
+ * calls (GNU Radio 3.8 fft_filter_ccc, VOLK mag^2 / dot product,
+ * fast_atan2f, mmse_fir_interpolator_cc) from their published algorithms.
+ * The only known answers it is pinned against are the control-flow
+ * observations recorded in SURVEY.md section 4.1 (tests/test_oracle_kat.py).
+ */
+#ifndef AIS_ORACLE_H
+#define AIS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } orc_cf;
+
+enum { ORC_KEY_CORR_START = 0, ORC_KEY_PHASE_EST = 1, ORC_KEY_TIME_EST = 2, ORC_KEY_CORR_EST = 3 };
+
+typedef struct {
+    uint64_t offset; /* absolute item offset */
+    double value;    /* pmt::from_double payload */
+    int32_t key;     /* ORC_KEY_* */
+    int32_t port;    /* output port the tag was added on */
+} orc_tag;
+
+/* ---- third-party kernels restated ---- */
+float orc_fast_atan2f(float y, float x);
+orc_cf orc_mmse_interpolate(const orc_cf *in, float mu, int *err);
+float orc_branchless_clip(float x, float clip);
+void orc_det_sincos(float phase, float *s, float *c);
+void orc_fft(orc_cf *buf, int n, int inverse); /* in place, unnormalised */
+
+/* ---- corr_est_cc (lib/corr_est_cc_impl.cc) ---- */
+typedef struct orc_corr orc_corr;
+orc_corr *orc_corr_create(const orc_cf *symbols, int nsym, float sps, unsigned mark_delay, float threshold);
+void orc_corr_destroy(orc_corr *h);
+int orc_corr_history(const orc_corr *h);        /* history() = N+1 */
+int orc_corr_output_multiple(const orc_corr *h); /* nsamples of the FFT filter */
+int orc_corr_fftsize(const orc_corr *h);
+float orc_corr_threshold(const orc_corr *h);    /* d_thresh */
+unsigned orc_corr_mark_delay(const orc_corr *h);
+void orc_corr_taps(const orc_corr *h, orc_cf *out); /* d_symbols as stored */
+void orc_corr_set_symbols(orc_corr *h, const orc_cf *symbols, int nsym);
+/* one work() call: `in` has history()-1 old items then noutput new ones */
+int orc_corr_work(orc_corr *h, int noutput_items, const orc_cf *in, orc_cf *out, orc_cf *corr_out /* or NULL */,
+                  uint64_t nitems_written, orc_tag *tags, int max_tags, int *ntags);
+
+/* ---- freqest (lib/freqest_impl.cc) and its wiring (python/gmsk_sync.py) ---- */
+typedef struct { float binsize; int offset; int fftlen; } orc_freqest;
+void orc_freqest_init(orc_freqest *f, float sample_rate, int data_rate, int fftlen);
+int orc_freqest_work(const orc_freqest *f, int noutput_items, const orc_cf *in, float *out);
+
+typedef struct orc_freqsync orc_freqsync;
+orc_freqsync *orc_freqsync_create(double samplerate, double bits_per_sec, int fftlen);
+void orc_freqsync_destroy(orc_freqsync *h);
+/* feeds n new samples; processes every complete fftlen-vector in ONE freqest
+ * work call; returns number of output samples (multiple of fftlen);
+ * fhat_out (may be NULL) receives one estimate per vector. */
+int orc_freqsync_process(orc_freqsync *h, const orc_cf *in, int n, orc_cf *out, float *fhat_out);
+
+/* ---- analog.feedforward_agc_cc (3rd party, python/ais_demod.py:35) ---- */
+/* `in` has nsamples-1 history items then noutput new ones */
+void orc_feedforward_agc(int nsamples, float reference, int noutput_items, const orc_cf *in, orc_cf *out);
+
+/* ---- msk_timing_recovery_cc (lib/msk_timing_recovery_cc_impl.cc) ---- */
+typedef struct orc_msk orc_msk;
+orc_msk *orc_msk_create(float sps, float gain, float limit, int osps, int *err);
+void orc_msk_destroy(orc_msk *h);
+int orc_msk_set_gain(orc_msk *h, float gain);
+float orc_msk_get_gain(const orc_msk *h);
+void orc_msk_set_limit(orc_msk *h, float limit);
+float orc_msk_get_limit(const orc_msk *h);
+void orc_msk_set_sps(orc_msk *h, float sps);
+float orc_msk_get_sps(const orc_msk *h);
+int orc_msk_forecast(const orc_msk *h, int noutput_items);
+/* one general_work() call.  tags: every tag currently in the scheduler's tag
+ * store for this stream (any key, any offset, sorted by offset); the function
+ * applies get_tags_in_range itself.  Returns produced; *consumed = iidx. */
+int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const orc_cf *in, orc_cf *out,
+                         float *out_err /* or NULL */, float *out_mu /* or NULL */, const orc_tag *tags,
+                         int ntags, uint64_t nitems_read, int *consumed, int *status);
+void orc_msk_get_state(const orc_msk *h, float *state8, int *div);
+
+/* ---- NRZI bit tail (python/ais_demod.py:48-52 + lib/invert_impl.cc) ---- */
+typedef struct { orc_cf prev_sym; unsigned char prev_bit; } orc_bittail;
+void orc_bittail_init(orc_bittail *t);
+void orc_bittail_process(orc_bittail *t, const orc_cf *syms, int n, unsigned char *bits);
+
+/* ---- template generation (python/ais_demod.py:36-38) ---- */
+/* gmsk_mod(sps, bt) driven by modulate_vector_bc(data, taps=[1]): returns
+ * nbytes*8*sps samples */
+int orc_gmsk_modulate_vector(int sps, double bt, const unsigned char *data, int nbytes, orc_cf *out);
+
+/* ---- the chain of python/ais_demod.py:56 for one channel ---- */
+typedef struct orc_demod orc_demod;
+/* stages bitmask: 1 = freq_sync, 2 = agc, (corr_est and msk always on) */
+orc_demod *orc_demod_create(float sps, float bits_per_sec, float gain, float limit, int fftlen, const orc_cf *symbols,
+                            int nsym, int stages);
+void orc_demod_destroy(orc_demod *h);
+/* one chain step of n new input samples; returns number of bits produced */
+int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, int max_bits, orc_cf *syms_or_null,
+                   orc_tag *tags_out, int max_tags, int *ntags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
