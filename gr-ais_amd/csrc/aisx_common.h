@@ -1,0 +1,175 @@
+// aisx_common.h -- shared scalar/complex helpers for the HIP kernels.
+//
+// Kernel BODIES are written as templates over an execution context `Ctx`
+// (thread id, LDS base, barrier, wave ballot/shuffle, global atomics).  The
+// product instantiates them with DevCtx (aisx_devctx.h, real gfx950 wave64
+// builtins); tests/emul instantiates the same bodies with a thread-per-lane
+// CPU model so the index arithmetic can be checked against the oracle without a
+// GPU.  Everything is compiled with -ffp-contract=off and uses explicit fmaf()
+// where a fused multiply-add is wanted, so both instantiations round alike.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AISX_DI __device__ __forceinline__
+#define AISX_HD __host__ __device__ __forceinline__
+#else
+#define AISX_DI inline
+#define AISX_HD inline
+#endif
+
+namespace aisx {
+
+struct cf {
+    float re, im;
+};
+
+AISX_HD cf mk(float re, float im)
+{
+    cf r;
+    r.re = re;
+    r.im = im;
+    return r;
+}
+AISX_HD cf operator+(cf a, cf b) { return mk(a.re + b.re, a.im + b.im); }
+AISX_HD cf operator-(cf a, cf b) { return mk(a.re - b.re, a.im - b.im); }
+AISX_HD cf cconj(cf a) { return mk(a.re, -a.im); }
+
+// std::complex<float> product as libstdc++ evaluates it: (ac - bd, ad + bc),
+// every operation rounded to float, no fusing.  Used on the bit-exact paths
+// (timing recovery, NCO mix, AGC).
+AISX_HD cf cmul_exact(cf a, cf b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+
+// Fused complex product for the FFT correlator (tolerance path): 2 mul + 2 fma.
+AISX_HD cf cmul_fma(cf a, cf b)
+{
+    return mk(fmaf(-a.im, b.im, a.re * b.re), fmaf(a.im, b.re, a.re * b.im));
+}
+AISX_HD cf cmul_conj_fma(cf a, cf b) // a * conj(b)
+{
+    return mk(fmaf(a.im, b.im, a.re * b.re), fmaf(a.im, b.re, -(a.re * b.im)));
+}
+
+// volk_32fc_magnitude_squared_32f (generic kernel): re*re + im*im, unfused.
+AISX_HD float mag2(cf a) { return a.re * a.re + a.im * a.im; }
+
+// float division, correctly rounded on both sides
+AISX_HD float fdiv_rn(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
+
+// gr::branchless_clip (gnuradio/math.h)
+AISX_HD float branchless_clip(float x, float clip)
+{
+    float x1 = fabsf(x + clip);
+    float x2 = fabsf(x - clip);
+    x1 -= x2;
+    return 0.5f * x1;
+}
+
+// gr::fast_atan2f (gnuradio-runtime fast_atan2f.cc); `tab` = 257-entry table
+AISX_HD float fast_atan2f_tab(float y, float x, const float* tab)
+{
+    const float TAN_MAP_RES = 0.003921569f;
+    float y_abs = fabsf(y), x_abs = fabsf(x), z, base_angle, angle;
+    if (!((y_abs > 0.0f) || (x_abs > 0.0f)))
+        return 0.0f;
+    if (y_abs < x_abs)
+        z = fdiv_rn(y_abs, x_abs);
+    else
+        z = fdiv_rn(x_abs, y_abs);
+    if (z < TAN_MAP_RES) {
+        base_angle = z;
+    } else {
+        float alpha = z * 255.0f;
+        int index = ((int)alpha) & 0xff;
+        alpha -= (float)index;
+        base_angle = tab[index];
+        base_angle += (tab[index + 1] - tab[index]) * alpha;
+    }
+    if (x_abs > y_abs) {
+        if (x >= 0.0f) {
+            angle = (y >= 0.0f) ? base_angle : -base_angle;
+        } else {
+            angle = 3.14159265358979323846f;
+            if (y >= 0.0f)
+                angle -= base_angle;
+            else
+                angle = base_angle - angle;
+        }
+    } else {
+        if (y >= 0.0f) {
+            angle = 1.57079632679489661923f;
+            if (x >= 0.0f)
+                angle -= base_angle;
+            else
+                angle += base_angle;
+        } else {
+            angle = -1.57079632679489661923f;
+            if (x >= 0.0f)
+                angle += base_angle;
+            else
+                angle -= base_angle;
+        }
+    }
+    return angle;
+}
+
+// Deterministic sin/cos for the NCO: plain IEEE double + and * only, so the
+// device result is bit-identical to the oracle's orc_det_sincos.
+AISX_HD void det_sincos(float phase, float* s, float* c)
+{
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    double x = (double)phase;
+    double kd = rint(x * TWO_OVER_PI);
+    int k = (int)kd;
+    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    double r2 = r * r;
+    double ps = -2.5052108385441718775e-08;
+    ps = ps * r2 + 2.7557319223985890653e-06;
+    ps = ps * r2 + -1.9841269841269841270e-04;
+    ps = ps * r2 + 8.3333333333333332177e-03;
+    ps = ps * r2 + -1.6666666666666665741e-01;
+    double sn = r + r * (r2 * ps);
+    double pc = 2.0876756987868098979e-09;
+    pc = pc * r2 + -2.7557319223985888276e-07;
+    pc = pc * r2 + 2.4801587301587301566e-05;
+    pc = pc * r2 + -1.3888888888888889419e-03;
+    pc = pc * r2 + 4.1666666666666664354e-02;
+    pc = pc * r2 + -0.5;
+    double cs = 1.0 + r2 * pc;
+    double so, co;
+    switch (k & 3) {
+    case 0: so = sn; co = cs; break;
+    case 1: so = cs; co = -sn; break;
+    case 2: so = -sn; co = -cs; break;
+    default: so = -cs; co = sn; break;
+    }
+    *s = (float)so;
+    *c = (float)co;
+}
+
+// std::abs(std::complex<float>) as glibc's hypotf evaluates it
+AISX_HD float cabs_f(cf a) { return (float)sqrt((double)a.re * (double)a.re + (double)a.im * (double)a.im); }
+
+// ------------------------------------------------------------------
+// Tag record shared by the C-ABI (must match aisx_tag in include/aisx.h)
+// ------------------------------------------------------------------
+struct tag_rec {
+    uint64_t offset;
+    double value;
+    int32_t key;
+    int32_t chan;
+};
+enum { KEY_CORR_START = 0, KEY_PHASE_EST = 1, KEY_TIME_EST = 2, KEY_CORR_EST = 3 };
+
+} // namespace aisx

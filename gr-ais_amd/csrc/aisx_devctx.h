@@ -1,0 +1,33 @@
+// aisx_devctx.h -- the gfx950 execution context the kernel bodies run under in
+// the product: wave64 ballot/shuffle builtins, LDS, workgroup barrier, global
+// atomics.  (tests/emul has the CPU model of the same interface.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace aisx {
+
+struct DevCtx {
+    char* lds_;
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+    __device__ __forceinline__ int bx() const { return blockIdx.x; }
+    __device__ __forceinline__ int by() const { return blockIdx.y; }
+    __device__ __forceinline__ char* lds() const { return lds_; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
+    __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) const
+    {
+        return __shfl(v, src, 64);
+    }
+    __device__ __forceinline__ float shfl_f32(float v, int src) const { return __shfl(v, src, 64); }
+    __device__ __forceinline__ int shfl_i32(int v, int src) const { return __shfl(v, src, 64); }
+    __device__ __forceinline__ float shfl_up_f32(float v, int d) const { return __shfl_up(v, d, 64); }
+    __device__ __forceinline__ float shfl_down_f32(float v, int d) const { return __shfl_down(v, d, 64); }
+    __device__ __forceinline__ float shfl_xor_f32(float v, int m) const { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ int shfl_xor_i32(int v, int m) const { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ double shfl_xor_f64(double v, int m) const { return __shfl_xor(v, m, 64); }
+    __device__ __forceinline__ int ctz64(unsigned long long v) const { return __ffsll((long long)v) - 1; }
+    __device__ __forceinline__ void atomic_or64(unsigned long long* p, unsigned long long v) const { atomicOr(p, v); }
+};
+
+} // namespace aisx

@@ -1,0 +1,763 @@
+// aisx_lib.hip -- C ABI (include/aisx.h) for corr_est_cc and msk_timing_recovery_cc
+// plus the __global__ wrappers that run the kernel bodies on gfx950.
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "aisx_devctx.h"
+#include "aisx_host.h"
+#include "aisx_plan.h"
+#include "aisx_tables.h"
+#include "k_corr.h"
+#include "k_msk.h"
+
+using namespace aisx;
+
+namespace aisx {
+char* err_buf()
+{
+    static thread_local char buf[512] = "";
+    return buf;
+}
+} // namespace aisx
+
+extern "C" int aisx_version(void) { return AISX_VERSION; }
+extern "C" const char* aisx_last_error(void) { return err_buf(); }
+extern "C" int aisx_device_count(int* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count)
+        *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? AISX_OK : AISX_ERR_NO_DEVICE;
+}
+extern "C" int aisx_set_device(int device)
+{
+    AISX_HIPCHK(hipSetDevice(device));
+    return AISX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CF_T) void k_corr_inith(CorrInitParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr_inith_body(cx, p);
+}
+
+__global__ __launch_bounds__(CF_T) void k_corr_main(CorrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr_main_body(cx, p);
+}
+
+__global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
+{
+    DevCtx cx{ nullptr };
+    corr_resolve_body(cx, p);
+}
+
+__global__ __launch_bounds__(64) void k_msk(MskParams p)
+{
+    DevCtx cx{ nullptr };
+    msk_body(cx, p);
+}
+
+// ---------------------------------------------------------------------------
+// corr_est_cc
+// ---------------------------------------------------------------------------
+struct aisx_corr {
+    int nchan = 0, N = 0, max_items = 0, tag_cap = 0, L = 0, isps = 0, out_multiple = 0;
+    float sps = 0, thresh = 0;
+    unsigned mark_delay = 0;
+    std::vector<cf> symbols; // d_symbols
+    cf *d_taps = nullptr, *d_tapspad = nullptr, *d_Hpos = nullptr, *d_wtab = nullptr;
+    cf* d_hist[2] = { nullptr, nullptr };
+    int hist_cur = 0;
+    unsigned long long* d_abits = nullptr;
+    long abits_stride = 0;
+    cf* d_scratch = nullptr;
+    long scratch_stride = 0;
+    tag_rec* d_tags = nullptr;
+    int* d_tag_count = nullptr;
+    float* d_atan = nullptr;
+    uint64_t written = 0;
+    int last_emit_port1 = 0;
+    // GNU Radio path staging
+    cf *d_st_in = nullptr, *d_st_out = nullptr, *d_st_corr = nullptr;
+    int st_cap = 0;
+};
+
+static int corr_upload_taps(aisx_corr* h)
+{
+    // taps/F, zero padded, then the forward transform in the kernel's own position order
+    std::vector<cf> pad = corr_padded_taps(h->symbols);
+    AISX_HIPCHK(hipMemcpy(h->d_tapspad, pad.data(), sizeof(cf) * CF_F, hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemcpy(h->d_taps, h->symbols.data(), sizeof(cf) * h->N, hipMemcpyHostToDevice));
+    CorrInitParams ip{ h->d_tapspad, h->d_wtab, h->d_Hpos };
+    hipLaunchKernelGGL(k_corr_inith, dim3(1), dim3(CF_T), CF_LDS_BYTES, 0, ip);
+    AISX_HIPCHK(hipGetLastError());
+    AISX_HIPCHK(hipDeviceSynchronize());
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int nsym, float sps, unsigned mark_delay,
+                                float threshold, int nchan, int max_items, int max_tags_per_chan)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (!symbols || nsym < 1 || nchan < 1 || max_items < 1 || max_tags_per_chan < 4) {
+        set_err("aisx_corr_create: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if (nsym > CF_F / 2) {
+        set_err("aisx_corr_create: template of %d samples exceeds the %d supported by the F=%d kernel", nsym,
+                CF_F / 2, CF_F);
+        return AISX_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_corr* h = new aisx_corr();
+    h->nchan = nchan;
+    h->N = nsym;
+    h->max_items = max_items;
+    h->tag_cap = max_tags_per_chan;
+    h->sps = sps;
+    h->L = CF_F - nsym;
+    // constructor maths of lib/corr_est_cc_impl.cc:58-85 (aisx_plan.h)
+    CorrSetup cs = corr_setup((const cf*)symbols, nsym, sps, mark_delay, threshold);
+    h->symbols = cs.symbols;
+    h->mark_delay = cs.mark_delay;
+    h->thresh = cs.thresh;
+    h->isps = cs.isps;
+    h->out_multiple = cs.out_multiple;
+    std::vector<cf> w = corr_wtab();
+    h->abits_stride = (max_items + 63) / 64 + 1;
+    h->scratch_stride = max_items;
+#define CK(e)               \
+    do {                    \
+        rc = (e);           \
+        if (rc != AISX_OK) { \
+            aisx_corr_destroy(h); \
+            return rc;      \
+        }                   \
+    } while (0)
+    CK(dev_alloc(&h->d_taps, nsym));
+    CK(dev_alloc(&h->d_tapspad, CF_F));
+    CK(dev_alloc(&h->d_Hpos, CF_F));
+    CK(dev_alloc(&h->d_wtab, CF_F));
+    CK(dev_alloc(&h->d_hist[0], (size_t)nchan * nsym));
+    CK(dev_alloc(&h->d_hist[1], (size_t)nchan * nsym));
+    CK(dev_alloc(&h->d_abits, (size_t)nchan * h->abits_stride));
+    CK(dev_alloc(&h->d_scratch, (size_t)nchan * h->scratch_stride, false));
+    CK(dev_alloc(&h->d_tags, (size_t)nchan * h->tag_cap));
+    CK(dev_alloc(&h->d_tag_count, nchan));
+    CK(dev_alloc(&h->d_atan, 257));
+    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * CF_F, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("aisx_corr_create: table upload failed");
+        aisx_corr_destroy(h);
+        return AISX_ERR_HIP;
+    }
+    CK(corr_upload_taps(h));
+#undef CK
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_destroy(aisx_corr* h)
+{
+    if (!h)
+        return AISX_OK;
+    dev_free(h->d_taps);
+    dev_free(h->d_tapspad);
+    dev_free(h->d_Hpos);
+    dev_free(h->d_wtab);
+    dev_free(h->d_hist[0]);
+    dev_free(h->d_hist[1]);
+    dev_free(h->d_abits);
+    dev_free(h->d_scratch);
+    dev_free(h->d_tags);
+    dev_free(h->d_tag_count);
+    dev_free(h->d_atan);
+    dev_free(h->d_st_in);
+    dev_free(h->d_st_out);
+    dev_free(h->d_st_corr);
+    delete h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_symbols(const aisx_corr* h, aisx_cf32* out, int cap)
+{
+    if (!h || !out || cap < h->N)
+        return AISX_ERR_INVALID;
+    memcpy(out, h->symbols.data(), sizeof(cf) * h->N);
+    return h->N;
+}
+
+extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int nsym)
+{
+    if (!h || !symbols)
+        return AISX_ERR_INVALID;
+    if (nsym != h->N) {
+        set_err("aisx_corr_set_symbols: length %d != %d (re-create the block to change the template length)", nsym,
+                h->N);
+        return AISX_ERR_INVALID;
+    }
+    // lib/corr_est_cc_impl.cc:132-162: stored as given, threshold untouched
+    memcpy(h->symbols.data(), symbols, sizeof(cf) * nsym);
+    h->mark_delay = h->mark_delay >= (unsigned)nsym ? (unsigned)nsym - 1 : h->mark_delay;
+    return corr_upload_taps(h);
+}
+
+extern "C" int aisx_corr_history(const aisx_corr* h) { return h ? h->N + 1 : AISX_ERR_INVALID; }
+extern "C" int aisx_corr_output_multiple(const aisx_corr* h) { return h ? h->out_multiple : AISX_ERR_INVALID; }
+extern "C" int aisx_corr_max_noutput_items(const aisx_corr*) { return 24 * 1024; }
+extern "C" float aisx_corr_threshold(const aisx_corr* h) { return h ? h->thresh : 0.f; }
+extern "C" unsigned aisx_corr_mark_delay(const aisx_corr* h) { return h ? h->mark_delay : 0u; }
+extern "C" uint64_t aisx_corr_nitems_written(const aisx_corr* h) { return h ? h->written : 0; }
+
+extern "C" int aisx_corr_reset(aisx_corr* h)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipMemset(h->d_hist[0], 0, sizeof(cf) * (size_t)h->nchan * h->N));
+    AISX_HIPCHK(hipMemset(h->d_hist[1], 0, sizeof(cf) * (size_t)h->nchan * h->N));
+    h->hist_cur = 0;
+    h->written = 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out,
+                                 long out_stride, aisx_cf32* d_corr, long corr_stride, int n, void* stream)
+{
+    if (!h || !d_in || !d_out || n < 1 || n > h->max_items || in_stride < n || out_stride < n ||
+        (d_corr && corr_stride < n)) {
+        set_err("aisx_corr_process: bad argument (n=%d, max_items=%d)", n, h ? h->max_items : -1);
+        return AISX_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int nseg, tps;
+    corr_grid(h->nchan, n, h->L, &nseg, &tps);
+
+    AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
+    CorrParams p;
+    p.in = (const cf*)d_in;
+    p.in_stride = in_stride;
+    p.out = (cf*)d_out;
+    p.out_stride = out_stride;
+    p.corr = d_corr ? (cf*)d_corr : h->d_scratch;
+    p.corr_stride = d_corr ? corr_stride : h->scratch_stride;
+    p.dense_corr = d_corr ? 1 : 0;
+    p.hist_in = h->d_hist[h->hist_cur];
+    p.hist_out = h->d_hist[h->hist_cur ^ 1];
+    p.Hpos = h->d_Hpos;
+    p.wtab = h->d_wtab;
+    p.abits = h->d_abits;
+    p.abits_stride = h->abits_stride;
+    p.n = n;
+    p.N = h->N;
+    p.L = h->L;
+    p.nseg = nseg;
+    p.tiles_per_seg = tps;
+    p.thresh = h->thresh;
+    hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
+    AISX_HIPCHK(hipGetLastError());
+
+    ResolveParams r;
+    r.abits = h->d_abits;
+    r.abits_stride = h->abits_stride;
+    r.corr = p.corr;
+    r.corr_stride = p.corr_stride;
+    r.dense_corr = p.dense_corr;
+    r.in = p.in;
+    r.in_stride = in_stride;
+    r.hist_in = p.hist_in;
+    r.taps = h->d_taps;
+    r.n = n;
+    r.N = h->N;
+    r.isps = h->isps;
+    r.mark_delay = h->mark_delay;
+    r.written = h->written;
+    r.emit_port1 = d_corr ? 1 : 0;
+    r.tags = h->d_tags;
+    r.tag_cap = h->tag_cap;
+    r.tag_count = h->d_tag_count;
+    r.atan_tab = h->d_atan;
+    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
+    AISX_HIPCHK(hipGetLastError());
+    h->hist_cur ^= 1;
+    h->written += (uint64_t)n;
+    h->last_emit_port1 = r.emit_port1;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int** d_counts, int* cap)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (d_tags)
+        *d_tags = (const aisx_tag*)h->d_tags;
+    if (d_counts)
+        *d_counts = h->d_tag_count;
+    if (cap)
+        *cap = h->tag_cap;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_cap, int* ntags, void* stream)
+{
+    if (!h || !ntags)
+        return AISX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> counts(h->nchan);
+    AISX_HIPCHK(hipMemcpyAsync(counts.data(), h->d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));
+    AISX_HIPCHK(hipStreamSynchronize(st));
+    int total = 0, rc = AISX_OK;
+    long maxc = 0;
+    for (int c = 0; c < h->nchan; c++) {
+        if (counts[c] > h->tag_cap) {
+            rc = AISX_ERR_OVERFLOW;
+            counts[c] = h->tag_cap;
+        }
+        maxc = std::max<long>(maxc, counts[c]);
+    }
+    if (maxc > 0 && host_tags) {
+        // one strided copy of the used prefix of every channel's segment
+        std::vector<tag_rec> tmp((size_t)h->nchan * maxc);
+        AISX_HIPCHK(hipMemcpy2DAsync(tmp.data(), sizeof(tag_rec) * maxc, h->d_tags, sizeof(tag_rec) * h->tag_cap,
+                                     sizeof(tag_rec) * maxc, h->nchan, hipMemcpyDeviceToHost, st));
+        AISX_HIPCHK(hipStreamSynchronize(st));
+        for (int c = 0; c < h->nchan; c++)
+            for (int k = 0; k < counts[c]; k++) {
+                if (total < host_cap)
+                    memcpy(&host_tags[total], &tmp[(size_t)c * maxc + k], sizeof(tag_rec));
+                else
+                    rc = AISX_ERR_OVERFLOW;
+                total++;
+            }
+    } else {
+        for (int c = 0; c < h->nchan; c++)
+            total += counts[c];
+        if (total > 0 && !host_tags)
+            rc = AISX_ERR_OVERFLOW;
+    }
+    *ntags = std::min(total, host_tags ? host_cap : 0);
+    if (rc == AISX_ERR_OVERFLOW)
+        set_err("aisx_corr_read_tags: tag buffer overflow (%d tags)", total);
+    return rc;
+}
+
+extern "C" int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32* out, aisx_cf32* corr,
+                                   int noutput_items, uint64_t nitems_written, aisx_tag* tags, int tag_cap,
+                                   int* ntags)
+{
+    if (!h || !in || !out || noutput_items < 1 || !ntags)
+        return AISX_ERR_INVALID;
+    if (h->nchan != 1) {
+        set_err("aisx_corr_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
+        return AISX_ERR_INVALID;
+    }
+    const int n = noutput_items;
+    if (n > h->st_cap) {
+        dev_free(h->d_st_in);
+        dev_free(h->d_st_out);
+        dev_free(h->d_st_corr);
+        int rc = dev_alloc(&h->d_st_in, n, false);
+        if (rc == AISX_OK)
+            rc = dev_alloc(&h->d_st_out, n, false);
+        if (rc == AISX_OK)
+            rc = dev_alloc(&h->d_st_corr, n, false);
+        if (rc != AISX_OK)
+            return rc;
+        h->st_cap = n;
+    }
+    // in[0 .. N) is the block's history, in[N .. N+n) the new items (:180-188)
+    AISX_HIPCHK(hipMemcpy(h->d_hist[h->hist_cur], in, sizeof(cf) * h->N, hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemcpy(h->d_st_in, in + h->N, sizeof(cf) * n, hipMemcpyHostToDevice));
+    h->written = nitems_written;
+    int rc = aisx_corr_process(h, (aisx_cf32*)h->d_st_in, n, (aisx_cf32*)h->d_st_out, n,
+                               corr ? (aisx_cf32*)h->d_st_corr : nullptr, n, n, nullptr);
+    if (rc != AISX_OK)
+        return rc;
+    AISX_HIPCHK(hipMemcpy(out, h->d_st_out, sizeof(cf) * n, hipMemcpyDeviceToHost));
+    if (corr)
+        AISX_HIPCHK(hipMemcpy(corr, h->d_st_corr, sizeof(cf) * n, hipMemcpyDeviceToHost));
+    return aisx_corr_read_tags(h, tags, tag_cap, ntags, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// msk_timing_recovery_cc
+// ---------------------------------------------------------------------------
+struct aisx_msk {
+    int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
+    float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
+    static constexpr int carry_cap = 256, ctag_cap = 64;
+    float *d_mu = nullptr, *d_omega = nullptr;
+    int* d_div = nullptr;
+    cf *d_dly1 = nullptr, *d_dly2 = nullptr, *d_diff1 = nullptr, *d_tprev = nullptr;
+    unsigned char* d_tbit = nullptr;
+    unsigned long long* d_nread = nullptr;
+    cf* d_carry[2] = { nullptr, nullptr };
+    int* d_carry_len[2] = { nullptr, nullptr };
+    tag_rec* d_ctag[2] = { nullptr, nullptr };
+    int* d_ctag_n[2] = { nullptr, nullptr };
+    int cur = 0;
+    int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
+    float *d_mmse = nullptr, *d_atan = nullptr;
+    // GNU Radio path staging
+    cf *d_st_in = nullptr, *d_st_sym = nullptr;
+    float *d_st_err = nullptr, *d_st_mu = nullptr;
+    unsigned char* d_st_bits = nullptr;
+    tag_rec* d_st_tags = nullptr;
+    int* d_st_tagn = nullptr;
+    int st_in_cap = 0, st_out_cap = 0, st_tag_cap = 0;
+};
+
+static int msk_init_state(aisx_msk* h)
+{
+    const int nc = h->nchan;
+    std::vector<float> mu(nc, 0.5f), om(nc, h->d_sps); // impl :49-56, :71
+    AISX_HIPCHK(hipMemcpy(h->d_mu, mu.data(), sizeof(float) * nc, hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemcpy(h->d_omega, om.data(), sizeof(float) * nc, hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemset(h->d_div, 0, sizeof(int) * nc));
+    AISX_HIPCHK(hipMemset(h->d_dly1, 0, sizeof(cf) * nc));
+    AISX_HIPCHK(hipMemset(h->d_dly2, 0, sizeof(cf) * nc));
+    AISX_HIPCHK(hipMemset(h->d_diff1, 0, sizeof(cf) * nc));
+    AISX_HIPCHK(hipMemset(h->d_tprev, 0, sizeof(cf) * nc));
+    AISX_HIPCHK(hipMemset(h->d_tbit, 0, nc));
+    AISX_HIPCHK(hipMemset(h->d_nread, 0, sizeof(unsigned long long) * nc));
+    for (int k = 0; k < 2; k++) {
+        AISX_HIPCHK(hipMemset(h->d_carry[k], 0, sizeof(cf) * (size_t)nc * aisx_msk::carry_cap));
+        AISX_HIPCHK(hipMemset(h->d_carry_len[k], 0, sizeof(int) * nc));
+        AISX_HIPCHK(hipMemset(h->d_ctag_n[k], 0, sizeof(int) * nc));
+    }
+    h->cur = 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limit, int osps, int nchan, int max_items)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (nchan < 1 || max_items < 1 || !(sps > 0)) {
+        set_err("aisx_msk_create: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if (!(gain > 0)) { // impl :82
+        set_err("Gain must be positive");
+        return AISX_ERR_OUT_OF_RANGE;
+    }
+    if (osps != 1 && osps != 2) { // impl :61
+        set_err("osps must be 1 or 2");
+        return AISX_ERR_OUT_OF_RANGE;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_msk* h = new aisx_msk();
+    h->nchan = nchan;
+    h->max_items = max_items;
+    h->osps = osps;
+    h->limit = limit;
+    h->d_sps = msk_setup(sps, gain).d_sps; // :70
+    h->gain = gain;
+    h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
+    h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
+#define CK(e)               \
+    do {                    \
+        rc = (e);           \
+        if (rc != AISX_OK) { \
+            aisx_msk_destroy(h); \
+            return rc;      \
+        }                   \
+    } while (0)
+    CK(dev_alloc(&h->d_mu, nchan));
+    CK(dev_alloc(&h->d_omega, nchan));
+    CK(dev_alloc(&h->d_div, nchan));
+    CK(dev_alloc(&h->d_dly1, nchan));
+    CK(dev_alloc(&h->d_dly2, nchan));
+    CK(dev_alloc(&h->d_diff1, nchan));
+    CK(dev_alloc(&h->d_tprev, nchan));
+    CK(dev_alloc(&h->d_tbit, nchan));
+    CK(dev_alloc(&h->d_nread, nchan));
+    for (int k = 0; k < 2; k++) {
+        CK(dev_alloc(&h->d_carry[k], (size_t)nchan * aisx_msk::carry_cap));
+        CK(dev_alloc(&h->d_carry_len[k], nchan));
+        CK(dev_alloc(&h->d_ctag[k], (size_t)nchan * aisx_msk::ctag_cap));
+        CK(dev_alloc(&h->d_ctag_n[k], nchan));
+    }
+    CK(dev_alloc(&h->d_produced, nchan));
+    CK(dev_alloc(&h->d_consumed, nchan));
+    CK(dev_alloc(&h->d_status, nchan));
+    CK(dev_alloc(&h->d_mmse, 129 * 8));
+    CK(dev_alloc(&h->d_atan, 257));
+    if (hipMemcpy(h->d_mmse, aisx_mmse_taps, sizeof(float) * 129 * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("aisx_msk_create: table upload failed");
+        aisx_msk_destroy(h);
+        return AISX_ERR_HIP;
+    }
+    CK(msk_init_state(h));
+#undef CK
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_destroy(aisx_msk* h)
+{
+    if (!h)
+        return AISX_OK;
+    dev_free(h->d_mu);
+    dev_free(h->d_omega);
+    dev_free(h->d_div);
+    dev_free(h->d_dly1);
+    dev_free(h->d_dly2);
+    dev_free(h->d_diff1);
+    dev_free(h->d_tprev);
+    dev_free(h->d_tbit);
+    dev_free(h->d_nread);
+    for (int k = 0; k < 2; k++) {
+        dev_free(h->d_carry[k]);
+        dev_free(h->d_carry_len[k]);
+        dev_free(h->d_ctag[k]);
+        dev_free(h->d_ctag_n[k]);
+    }
+    dev_free(h->d_produced);
+    dev_free(h->d_consumed);
+    dev_free(h->d_status);
+    dev_free(h->d_mmse);
+    dev_free(h->d_atan);
+    dev_free(h->d_st_in);
+    dev_free(h->d_st_sym);
+    dev_free(h->d_st_err);
+    dev_free(h->d_st_mu);
+    dev_free(h->d_st_bits);
+    dev_free(h->d_st_tags);
+    dev_free(h->d_st_tagn);
+    delete h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_set_gain(aisx_msk* h, float gain)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    h->gain = gain; // the reference stores first, then throws (:81-82)
+    if (!(gain > 0)) {
+        set_err("Gain must be positive");
+        return AISX_ERR_OUT_OF_RANGE;
+    }
+    h->gain_omega = (float)(gain * gain * 0.25);
+    return AISX_OK;
+}
+extern "C" float aisx_msk_get_gain(const aisx_msk* h) { return h ? h->gain : 0.f; }
+extern "C" int aisx_msk_set_limit(aisx_msk* h, float limit)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    h->limit = limit;
+    return AISX_OK;
+}
+extern "C" float aisx_msk_get_limit(const aisx_msk* h) { return h ? h->limit : 0.f; }
+extern "C" int aisx_msk_set_sps(aisx_msk* h, float sps)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    h->d_sps = (float)(sps / 2.0); // :70
+    std::vector<float> om(h->nchan, h->d_sps); // :71 d_omega = d_sps
+    AISX_HIPCHK(hipMemcpy(h->d_omega, om.data(), sizeof(float) * h->nchan, hipMemcpyHostToDevice));
+    return AISX_OK;
+}
+extern "C" float aisx_msk_get_sps(const aisx_msk* h) { return h ? h->d_sps : 0.f; }
+extern "C" int aisx_msk_forecast(const aisx_msk* h, int noutput_items)
+{
+    return h ? msk_forecast(h->d_sps, noutput_items) : AISX_ERR_INVALID;
+}
+extern "C" int aisx_msk_out_capacity(const aisx_msk* h) { return h ? h->out_cap : AISX_ERR_INVALID; }
+extern "C" int aisx_msk_reset(aisx_msk* h) { return h ? msk_init_state(h) : AISX_ERR_INVALID; }
+
+static void msk_fill_common(aisx_msk* h, MskParams& p)
+{
+    p.nchan = h->nchan;
+    p.d_sps = h->d_sps;
+    p.gain = h->gain;
+    p.gain_omega = h->gain_omega;
+    p.limit = h->limit;
+    p.osps = h->osps;
+    p.mu = h->d_mu;
+    p.omega = h->d_omega;
+    p.div = h->d_div;
+    p.dly1 = h->d_dly1;
+    p.dly2 = h->d_dly2;
+    p.diff1 = h->d_diff1;
+    p.tail_prev_sym = h->d_tprev;
+    p.tail_prev_bit = h->d_tbit;
+    p.nread = h->d_nread;
+    p.carry_in = h->d_carry[h->cur];
+    p.carry_out = h->d_carry[h->cur ^ 1];
+    p.carry_len_in = h->d_carry_len[h->cur];
+    p.carry_len_out = h->d_carry_len[h->cur ^ 1];
+    p.carry_cap = aisx_msk::carry_cap;
+    p.ctag_in = h->d_ctag[h->cur];
+    p.ctag_out = h->d_ctag[h->cur ^ 1];
+    p.ctag_n_in = h->d_ctag_n[h->cur];
+    p.ctag_n_out = h->d_ctag_n[h->cur ^ 1];
+    p.ctag_cap = aisx_msk::ctag_cap;
+    p.consumed = h->d_consumed;
+    p.status = h->d_status;
+    p.mmse = h->d_mmse;
+    p.atan_tab = h->d_atan;
+}
+
+extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
+                                       const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
+                                       float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
+                                       void* stream)
+{
+    if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n || (d_tags && (!d_tag_counts || tag_cap < 1))) {
+        set_err("aisx_msk_process_stream: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if ((d_syms || d_err || d_mu || d_bits) && out_stride < 1)
+        return AISX_ERR_INVALID;
+    MskParams p;
+    msk_fill_common(h, p);
+    p.in = (const cf*)d_in;
+    p.in_stride = in_stride;
+    p.n = n;
+    p.stream_mode = 1;
+    p.gr_ninput = 0;
+    p.gr_noutput = 0;
+    p.tags = (const tag_rec*)d_tags;
+    p.tag_count = d_tag_counts;
+    p.tag_cap = tag_cap;
+    p.syms = (cf*)d_syms;
+    p.err = d_err;
+    p.mu_out = d_mu;
+    p.bits = d_bits;
+    p.out_stride = out_stride;
+    p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
+    p.produced = d_produced ? d_produced : h->d_produced;
+    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
+    AISX_HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_last_status(aisx_msk* h, int* status, void* stream)
+{
+    if (!h || !status)
+        return AISX_ERR_INVALID;
+    std::vector<int> st(h->nchan);
+    AISX_HIPCHK(hipMemcpyAsync(st.data(), h->d_status, sizeof(int) * h->nchan, hipMemcpyDeviceToHost,
+                               (hipStream_t)stream));
+    AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    int acc = 0;
+    for (int v : st)
+        acc |= v;
+    *status = acc;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ninput_items, const aisx_cf32* in,
+                                          aisx_cf32* out, float* out_err, float* out_mu, uint8_t* out_bits,
+                                          const aisx_tag* tags, int ntags, uint64_t nitems_read,
+                                          int in_has_lookahead, int* consumed, int* produced)
+{
+    if (!h || !in || !out || !consumed || !produced || noutput_items < 0 || ninput_items < 0 || ntags < 0)
+        return AISX_ERR_INVALID;
+    if (h->nchan != 1) {
+        set_err("aisx_msk_general_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
+        return AISX_ERR_INVALID;
+    }
+    *consumed = 0;
+    *produced = 0;
+    if (ninput_items == 0 || noutput_items == 0)
+        return AISX_OK;
+    int rc;
+    // the interpolator reads up to in[ninput_items] (one past): stage one spare item
+    const int nin = ninput_items + 1;
+    if (nin > h->st_in_cap) {
+        dev_free(h->d_st_in);
+        if ((rc = dev_alloc(&h->d_st_in, nin)) != AISX_OK)
+            return rc;
+        h->st_in_cap = nin;
+    }
+    if (noutput_items > h->st_out_cap) {
+        dev_free(h->d_st_sym);
+        dev_free(h->d_st_err);
+        dev_free(h->d_st_mu);
+        dev_free(h->d_st_bits);
+        if ((rc = dev_alloc(&h->d_st_sym, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_err, noutput_items)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_st_mu, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_bits, noutput_items)) != AISX_OK)
+            return rc;
+        h->st_out_cap = noutput_items;
+    }
+    if (ntags + 1 > h->st_tag_cap) {
+        dev_free(h->d_st_tags);
+        dev_free(h->d_st_tagn);
+        if ((rc = dev_alloc(&h->d_st_tags, ntags + 1)) != AISX_OK || (rc = dev_alloc(&h->d_st_tagn, 1)) != AISX_OK)
+            return rc;
+        h->st_tag_cap = ntags + 1;
+    }
+    AISX_HIPCHK(hipMemcpy(h->d_st_in, in, sizeof(cf) * (in_has_lookahead ? nin : ninput_items), hipMemcpyHostToDevice));
+    if (!in_has_lookahead)
+        AISX_HIPCHK(hipMemset(h->d_st_in + ninput_items, 0, sizeof(cf)));
+    if (ntags > 0)
+        AISX_HIPCHK(hipMemcpy(h->d_st_tags, tags, sizeof(tag_rec) * ntags, hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemcpy(h->d_st_tagn, &ntags, sizeof(int), hipMemcpyHostToDevice));
+    unsigned long long R = nitems_read;
+    AISX_HIPCHK(hipMemcpy(h->d_nread, &R, sizeof(R), hipMemcpyHostToDevice));
+    const int zero = 0;
+    AISX_HIPCHK(hipMemcpy(h->d_carry_len[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
+    AISX_HIPCHK(hipMemcpy(h->d_ctag_n[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
+    MskParams p;
+    msk_fill_common(h, p);
+    p.in = h->d_st_in;
+    p.in_stride = nin;
+    p.n = ninput_items;
+    p.stream_mode = 0;
+    p.gr_ninput = ninput_items;
+    p.gr_noutput = noutput_items;
+    p.tags = h->d_st_tags;
+    p.tag_count = h->d_st_tagn;
+    p.tag_cap = ntags + 1;
+    p.syms = h->d_st_sym;
+    p.err = h->d_st_err;
+    p.mu_out = h->d_st_mu;
+    p.bits = h->d_st_bits;
+    p.out_stride = noutput_items;
+    p.out_cap = noutput_items;
+    p.produced = h->d_produced;
+    hipLaunchKernelGGL(k_msk, dim3(1), dim3(64), 0, 0, p);
+    AISX_HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    int st = 0;
+    AISX_HIPCHK(hipMemcpy(produced, h->d_produced, sizeof(int), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(consumed, h->d_consumed, sizeof(int), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    const int np = *produced;
+    if (np > 0) {
+        AISX_HIPCHK(hipMemcpy(out, h->d_st_sym, sizeof(cf) * np, hipMemcpyDeviceToHost));
+        if (out_err)
+            AISX_HIPCHK(hipMemcpy(out_err, h->d_st_err, sizeof(float) * np, hipMemcpyDeviceToHost));
+        if (out_mu)
+            AISX_HIPCHK(hipMemcpy(out_mu, h->d_st_mu, sizeof(float) * np, hipMemcpyDeviceToHost));
+        if (out_bits)
+            AISX_HIPCHK(hipMemcpy(out_bits, h->d_st_bits, np, hipMemcpyDeviceToHost));
+    }
+    if (st & MSK_ST_INTERP_RANGE) {
+        set_err("mmse_fir_interpolator_cc: imu out of bounds."); // upstream std::runtime_error
+        return AISX_ERR_RUNTIME;
+    }
+    return AISX_OK;
+}

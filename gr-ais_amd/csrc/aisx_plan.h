@@ -1,0 +1,83 @@
+// aisx_plan.h -- host-side set-up arithmetic shared by the C-ABI (aisx_lib.hip)
+// and the CPU model in tests/emul: constructor maths of the reference blocks and
+// launch geometry.  No device code.
+#pragma once
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "aisx_common.h"
+#include "k_corr.h"
+
+namespace aisx {
+
+struct CorrSetup {
+    std::vector<cf> symbols; // d_symbols: reversed conjugate (lib/corr_est_cc_impl.cc:58-63)
+    unsigned mark_delay;     // :65-66
+    float thresh;            // :71-74
+    int isps;                // :193
+    int out_multiple;        // :77-85 nsamples of the reference's FFT filter
+};
+
+inline CorrSetup corr_setup(const cf* symbols, int nsym, float sps, unsigned mark_delay, float threshold)
+{
+    CorrSetup s;
+    s.symbols.resize(nsym);
+    for (int i = 0; i < nsym; i++)
+        s.symbols[i] = cconj(symbols[nsym - 1 - i]);
+    s.mark_delay = mark_delay >= (unsigned)nsym ? (unsigned)nsym - 1 : mark_delay;
+    float corr = 0;
+    for (int i = 0; i < nsym; i++)
+        corr += cabs_f(cmul_exact(s.symbols[i], cconj(s.symbols[i])));
+    s.thresh = threshold * corr * corr;
+    s.isps = (int)(sps + 0.5f);
+    int fftsize = (int)(2 * pow(2.0, ceil(log((double)nsym) / log(2.0))));
+    s.out_multiple = fftsize - nsym + 1;
+    return s;
+}
+
+inline std::vector<cf> corr_wtab()
+{
+    std::vector<cf> w(CF_F);
+    for (int k = 0; k < CF_F; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)CF_F;
+        w[k] = mk((float)cos(a), (float)sin(a));
+    }
+    return w;
+}
+
+// taps/F zero padded to F (fft_filter_ccc::set_taps scales the taps by 1/fftsize)
+inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored)
+{
+    std::vector<cf> pad(CF_F, mk(0.f, 0.f));
+    const float scale = 1.0f / (float)CF_F;
+    for (size_t i = 0; i < stored.size(); i++)
+        pad[i] = mk(stored[i].re * scale, stored[i].im * scale);
+    return pad;
+}
+
+// grid of the main kernel: (nseg, nchan) workgroups, each walking tiles_per_seg
+// consecutive tiles of L outputs of one channel
+inline void corr_grid(int nchan, int n, int L, int* nseg, int* tiles_per_seg)
+{
+    const int ntiles = (n + L - 1) / L;
+    int ns = (2048 + nchan - 1) / nchan;
+    ns = std::max(1, std::min(ns, std::max(1, ntiles / 4)));
+    const int tps = (ntiles + ns - 1) / ns;
+    *nseg = (ntiles + tps - 1) / tps;
+    *tiles_per_seg = tps;
+}
+
+struct MskSetup {
+    float d_sps, gain_omega;
+};
+inline MskSetup msk_setup(float sps, float gain)
+{
+    MskSetup m;
+    m.d_sps = (float)(sps / 2.0);                 // lib/msk_timing_recovery_cc_impl.cc:70
+    m.gain_omega = (float)(gain * gain * 0.25);   // :83
+    return m;
+}
+
+} // namespace aisx

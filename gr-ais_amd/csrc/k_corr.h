@@ -1,0 +1,381 @@
+// k_corr.h -- corr_est_cc on the GPU (reference: lib/corr_est_cc_impl.cc).
+//
+//   corr_inith_body   : forward transform of the (1/F-scaled, zero padded) taps,
+//                       left in the FFT's own position order          [init]
+//   corr_main_body    : A2 pass-through (delay N) + A3 overlap-save FFT
+//                       correlation + A4 mag^2 + threshold bitmask     [hot]
+//   corr_resolve_body : A5 peak search / centre of mass / phase / tags [sparse]
+//
+// FFT: F = 2048 = 16 x 16 x 8, 128 threads (2 waves) per transform, 16 points
+// per thread in VGPRs, 2 LDS exchanges per direction.  Forward is DIF (natural
+// in, digit-reversed positions out), the template spectrum H is stored in those
+// same positions, inverse is DIT (natural out): no reordering pass.
+// LDS image: 16 rows x 136 complex (row pad 8 => the radix-16 passes over
+// stride-8 columns hit 64 distinct banks per half wave) with the 16-byte chunk
+// index XOR-ed by (k2>>2)&3 so the stride-1 radix-8 pass reads ds_read_b128
+// conflict free.
+#pragma once
+#include "aisx_common.h"
+#include "k_fft.h"
+
+namespace aisx {
+
+constexpr int CF_F = 2048;    // FFT size
+constexpr int CF_T = 128;     // threads per transform
+constexpr int CF_ROW = 136;   // LDS row pitch in complex elements
+constexpr int CF_LDS_ELEMS = 16 * CF_ROW * 2 + 128; // data + H + tw2
+constexpr int CF_LDS_BYTES = CF_LDS_ELEMS * 8;
+
+AISX_HD int cf_pos(int row, int col)
+{
+    int k2 = col >> 3, n3 = col & 7;
+    return row * CF_ROW + (k2 << 3) + ((((n3 >> 1) ^ ((k2 >> 2) & 3)) << 1) | (n3 & 1));
+}
+
+struct CorrParams {
+    const cf* in;   long in_stride;   // [nchan][n] new samples
+    cf* out;        long out_stride;  // [nchan][n] delayed pass-through
+    cf* corr;       long corr_stride; // correlator output (dense) or sparse scratch
+    int dense_corr;
+    const cf* hist_in;                // [nchan][N] last N samples of the previous call
+    cf* hist_out;                     // [nchan][N]
+    const cf* Hpos;                   // [F]
+    const cf* wtab;                   // [F] W_F^k = exp(-2 pi j k / F)
+    unsigned long long* abits; long abits_stride; // 1 bit per output item: !(mag <= thresh)
+    int n, N, L, nseg, tiles_per_seg;
+    float thresh;
+};
+
+// ---- forward passes shared by init and main -------------------------------
+// On entry x[n1] = w[t + 128*n1].  On exit v[h][k3] holds the spectrum at
+// position (q = t + 128*h, k3), i.e. logical index q*8 + k3.
+template <class Ctx>
+AISX_DI void cf_forward(Ctx& cx, cf (&x)[16], const cf (&tw1)[16], cf* ldsX, const cf* ldsT, cf (&v)[2][8])
+{
+    const int t = cx.tid();
+    dft16<false>(x);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++)
+        x[k1] = cmul_fma(x[k1], tw1[k1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++)
+        ldsX[cf_pos(k1, t)] = x[k1];
+    cx.sync();
+    {
+        const int k1 = t >> 3, n3 = t & 7;
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++)
+            x[n2] = ldsX[cf_pos(k1, n2 * 8 + n3)];
+        dft16<false>(x);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; k2++)
+            x[k2] = cmul_fma(x[k2], ldsT[k2 * 8 + n3]);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++)
+            ldsX[cf_pos(k1, k2 * 8 + n3)] = x[k2];
+    }
+    cx.sync();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int q = t + CF_T * h, k1 = q >> 4, k2 = q & 15, swz = (k2 >> 2) & 3;
+        const int base = k1 * CF_ROW + k2 * 8;
+#pragma unroll
+        for (int pr = 0; pr < 4; pr++) {
+            const int ch = base + 2 * (pr ^ swz);
+            v[h][2 * pr] = ldsX[ch];
+            v[h][2 * pr + 1] = ldsX[ch + 1];
+        }
+        dft8<false>(v[h]);
+    }
+}
+
+struct CorrInitParams {
+    const cf* taps_scaled; // [F] taps/F, zero padded
+    const cf* wtab;
+    cf* Hpos; // [F]
+};
+
+template <class Ctx>
+AISX_DI void corr_inith_body(Ctx& cx, const CorrInitParams& p)
+{
+    const int t = cx.tid();
+    cf* lds = (cf*)cx.lds();
+    cf* ldsX = lds;
+    cf* ldsT = lds + 2 * 16 * CF_ROW;
+    cf tw1[16];
+    tw1[0] = mk(1.f, 0.f);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++)
+        tw1[k1] = p.wtab[k1 * t];
+    ldsT[t] = p.wtab[(16 * (t >> 3) * (t & 7)) & (CF_F - 1)];
+    cx.sync();
+    cf x[16], v[2][8];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++)
+        x[n1] = p.taps_scaled[t + CF_T * n1];
+    cf_forward(cx, x, tw1, ldsX, ldsT, v);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k3 = 0; k3 < 8; k3++)
+            p.Hpos[(t + CF_T * h) * 8 + k3] = v[h][k3];
+}
+
+template <class Ctx>
+AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
+{
+    const int t = cx.tid();
+    const int c = cx.by();
+    const int seg = cx.bx();
+    cf* lds = (cf*)cx.lds();
+    cf* ldsX = lds;
+    cf* ldsH = lds + 16 * CF_ROW;
+    cf* ldsT = lds + 2 * 16 * CF_ROW;
+
+    const int N = p.N, L = p.L, n = p.n;
+    const cf* xin = p.in + (long)c * p.in_stride;
+    cf* xout = p.out + (long)c * p.out_stride;
+    cf* xcorr = p.corr + (long)c * p.corr_stride;
+    const cf* hist = p.hist_in + (long)c * N;
+    unsigned long long* abits = p.abits + (long)c * p.abits_stride;
+
+    cf tw1[16];
+    tw1[0] = mk(1.f, 0.f);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++)
+        tw1[k1] = p.wtab[k1 * t];
+    ldsT[t] = p.wtab[(16 * (t >> 3) * (t & 7)) & (CF_F - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        ldsH[cf_pos(r, t)] = p.Hpos[r * 128 + t];
+    cx.sync();
+
+    for (int tile = 0; tile < p.tiles_per_seg; tile++) {
+        const int k0 = (seg * p.tiles_per_seg + tile) * L;
+        if (k0 >= n)
+            break;
+        cf x[16], v[2][8];
+        // window w[i] = stream[k0 - N + i]; stream index < 0 comes from the history
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) {
+            const int i = t + CF_T * n1;
+            const int s = k0 - N + i;
+            cf val = mk(0.f, 0.f);
+            if (s < 0)
+                val = hist[N + s];
+            else if (s < n)
+                val = xin[s];
+            x[n1] = val;
+        }
+        // A2: out[k0 + i] = stream[k0 + i - N] = w[i]   (lib/corr_est_cc_impl.cc:184)
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) {
+            const int i = t + CF_T * n1;
+            if (i < L && k0 + i < n)
+                xout[k0 + i] = x[n1];
+        }
+        cf_forward(cx, x, tw1, ldsX, ldsT, v);
+        // spectrum x H, inverse radix-8
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q = t + CF_T * h, k1 = q >> 4, k2 = q & 15, swz = (k2 >> 2) & 3;
+            const int base = k1 * CF_ROW + k2 * 8;
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const int ch = base + 2 * (pr ^ swz);
+                v[h][2 * pr] = cmul_fma(v[h][2 * pr], ldsH[ch]);
+                v[h][2 * pr + 1] = cmul_fma(v[h][2 * pr + 1], ldsH[ch + 1]);
+            }
+            dft8<true>(v[h]);
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const int ch = base + 2 * (pr ^ swz);
+                ldsX[ch] = v[h][2 * pr];
+                ldsX[ch + 1] = v[h][2 * pr + 1];
+            }
+        }
+        cx.sync();
+        {
+            const int k1 = t >> 3, n3 = t & 7;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) {
+                cf a = ldsX[cf_pos(k1, k2 * 8 + n3)];
+                x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, ldsT[k2 * 8 + n3]);
+            }
+            dft16<true>(x);
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++)
+                ldsX[cf_pos(k1, n2 * 8 + n3)] = x[n2];
+        }
+        cx.sync();
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) {
+            cf a = ldsX[cf_pos(k1, t)];
+            x[k1] = (k1 == 0) ? a : cmul_conj_fma(a, tw1[k1]);
+        }
+        dft16<true>(x);
+        // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197)
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) {
+            const int i = t + CF_T * n1;
+            const int m = i - N;
+            const int k = k0 + m;
+            if (m >= 0 && m < L && k < n) {
+                const cf y = x[n1];
+                if (p.dense_corr)
+                    xcorr[k] = y;
+                const float mg = mag2(y);
+                if (!(mg <= p.thresh)) {
+                    if (!p.dense_corr)
+                        xcorr[k] = y;
+                    cx.atomic_or64(&abits[k >> 6], 1ull << (k & 63));
+                }
+            }
+        }
+        cx.sync();
+    }
+    // carry the last N stream samples to the next call (set_history(N+1), :95)
+    if (seg == p.nseg - 1) {
+        cf* ho = p.hist_out + (long)c * N;
+        for (int j = t; j < N; j += CF_T) {
+            const int s = n - N + j;
+            ho[j] = (s >= 0) ? xin[s] : hist[N + s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A5: peak search and tag emission, one wave per channel.
+// ---------------------------------------------------------------------------
+struct ResolveParams {
+    const unsigned long long* abits; long abits_stride;
+    const cf* corr; long corr_stride; int dense_corr;
+    const cf* in; long in_stride;
+    const cf* hist_in; // history the correlation of this call started from
+    const cf* taps;    // d_symbols as stored (reversed conjugate), N entries
+    int n, N, isps;
+    unsigned mark_delay;
+    unsigned long long written; // nitems_written(0)
+    int emit_port1;
+    tag_rec* tags; int tag_cap; int* tag_count;
+    const float* atan_tab;
+};
+
+template <class Ctx>
+AISX_DI float resolve_direct_mag(Ctx& cx, const ResolveParams& p, int c, int k)
+{
+    // corr[k] = sum_j taps[j] * x[k - j], recomputed in direct form (double
+    // accumulation) for a below-threshold neighbour of a peak; only feeds the
+    // 3-point centre of mass.
+    const int lane = cx.tid();
+    const cf* xin = p.in + (long)c * p.in_stride;
+    const cf* hist = p.hist_in + (long)c * p.N;
+    double ar = 0.0, ai = 0.0;
+    for (int j = lane; j < p.N; j += 64) {
+        const int s = k - j;
+        cf xv = (s >= 0) ? xin[s] : hist[p.N + s];
+        cf tv = p.taps[j];
+        ar += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
+        ai += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        ar += cx.shfl_xor_f64(ar, o);
+        ai += cx.shfl_xor_f64(ai, o);
+    }
+    return mag2(mk((float)ar, (float)ai));
+}
+
+template <class Ctx>
+AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
+{
+    const int lane = cx.tid();
+    const int c = cx.bx();
+    const unsigned long long* A = p.abits + (long)c * p.abits_stride;
+    const cf* corr = p.corr + (long)c * p.corr_stride;
+    tag_rec* tags = p.tags + (long)c * p.tag_cap;
+    const int n = p.n;
+    const int nwords = (n + 63) >> 6;
+    int ntag = 0;
+    int i = 0;
+    for (int base = 0; base < nwords; base += 64) {
+        if ((long)(base + 64) * 64 <= (long)i)
+            continue;
+        const int wi = base + lane;
+        const unsigned long long w = (wi < nwords) ? A[wi] : 0ull;
+        for (;;) {
+            unsigned long long we = w;
+            const long lo = (long)wi * 64;
+            if (lo + 64 <= (long)i)
+                we = 0ull;
+            else if (lo < (long)i)
+                we &= (~0ull) << (i - lo);
+            const unsigned long long nz = cx.ballot(we != 0ull);
+            if (!nz)
+                break;
+            const int src = cx.ctz64(nz);
+            const unsigned long long word = cx.shfl_u64(we, src);
+            int pk = (base + src) * 64 + cx.ctz64(word);
+            // climb to the local maximum (:202-204)
+            cf cp = corr[pk];
+            float mp = mag2(cp);
+            while (pk < n - 1) {
+                const int q = pk + 1;
+                if (!((A[q >> 6] >> (q & 63)) & 1ull))
+                    break; // mag[q] <= thresh < mag[pk]
+                const cf cq = corr[q];
+                const float mq = mag2(cq);
+                if (!(mp < mq))
+                    break;
+                pk = q;
+                cp = cq;
+                mp = mq;
+            }
+            // centre of mass (:219-227)
+            double center = 0.0;
+            if (pk > 0 && pk < n - 1) {
+                float m0, m2;
+                if (p.dense_corr || ((A[(pk - 1) >> 6] >> ((pk - 1) & 63)) & 1ull))
+                    m0 = mag2(corr[pk - 1]);
+                else
+                    m0 = resolve_direct_mag(cx, p, c, pk - 1);
+                if (p.dense_corr || ((A[(pk + 1) >> 6] >> ((pk + 1) & 63)) & 1ull))
+                    m2 = mag2(corr[pk + 1]);
+                else
+                    m2 = resolve_direct_mag(cx, p, c, pk + 1);
+                double nom = 0, den = 0;
+                nom += (double)(1.0f * m0);
+                den += (double)m0;
+                nom += (double)(2.0f * mp);
+                den += (double)mp;
+                nom += (double)(3.0f * m2);
+                den += (double)m2;
+                center = nom / den - 2.0;
+            }
+            const float phase = fast_atan2f_tab(cp.im, cp.re, p.atan_tab); // :247
+            if (lane == 0) {
+                const unsigned long long o0 = p.written + (unsigned long long)pk;
+                const unsigned long long o1 = o0 + p.mark_delay;
+                if (ntag + 4 <= p.tag_cap) {
+                    tags[ntag + 0] = tag_rec{ o0, (double)mp, KEY_CORR_START, c };
+                    tags[ntag + 1] = tag_rec{ o1, (double)phase, KEY_PHASE_EST, c };
+                    tags[ntag + 2] = tag_rec{ o1, center, KEY_TIME_EST, c };
+                    tags[ntag + 3] = tag_rec{ o1, (double)mp, KEY_CORR_EST, c };
+                }
+                if (p.emit_port1 && ntag + 7 <= p.tag_cap) {
+                    tags[ntag + 4] = tag_rec{ o0, (double)phase, KEY_PHASE_EST | 0x100, c };
+                    tags[ntag + 5] = tag_rec{ o0, center, KEY_TIME_EST | 0x100, c };
+                    tags[ntag + 6] = tag_rec{ o0, (double)mp, KEY_CORR_EST | 0x100, c };
+                }
+            }
+            ntag += p.emit_port1 ? 7 : 4;
+            i = pk + p.isps; // :270
+            if ((long)i >= (long)(base + 64) * 64)
+                break;
+        }
+    }
+    if (lane == 0)
+        p.tag_count[c] = ntag;
+}
+
+} // namespace aisx

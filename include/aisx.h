@@ -1,0 +1,197 @@
+/*
+ * aisx.h -- C ABI of libaisx.so: the MI355X (gfx950) implementation of the gr-ais
+ * per-sample demod hot path.  This is the drop-in boundary: every entry point is
+ * `extern "C"`, takes plain pointers / sizes / an opaque handle, returns an int
+ * status (no exceptions cross the ABI) and corresponds to one method of the
+ * reference's block classes, cited below (paths under bistromath/gr-ais).
+ *
+ * Two ways to drive each block:
+ *   *_process / *_step   batched device path: device pointers, `nchan`
+ *                        independent channels laid out channel-major
+ *                        (`ptr[c * stride + k]`, stride in items), work queued
+ *                        on a hipStream_t passed as void* (NULL = default);
+ *   *_work_host          the GNU Radio path: nchan == 1, HOST pointers exactly
+ *                        as the scheduler hands them to work()/general_work();
+ *                        the call stages, launches and synchronises itself.
+ *
+ * Per-channel carry state (correlator history, timing-loop registers, NCO
+ * phase, AGC window) lives in device memory inside the handle, so a stream is
+ * processed by successive calls.
+ */
+#ifndef AISX_H
+#define AISX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AISX_VERSION 100
+
+/* gr_complex = std::complex<float>: interleaved re, im */
+typedef struct aisx_cf32 { float re, im; } aisx_cf32;
+
+/* stream tag (gr::tag_t with a PMT double value); keys of
+ * lib/corr_est_cc_impl.cc:213-256.  Tags the reference adds on output port 1
+ * (:258-266) carry AISX_KEY_PORT1 or-ed into `key`. */
+enum {
+    AISX_KEY_CORR_START = 0,
+    AISX_KEY_PHASE_EST = 1,
+    AISX_KEY_TIME_EST = 2,
+    AISX_KEY_CORR_EST = 3,
+    AISX_KEY_PORT1 = 0x100
+};
+typedef struct aisx_tag {
+    uint64_t offset; /* absolute item offset (nitems_written(0) + i [+ mark_delay]) */
+    double value;    /* pmt::from_double payload */
+    int32_t key;     /* AISX_KEY_* */
+    int32_t chan;    /* channel index (0 for the GNU Radio path) */
+} aisx_tag;
+
+enum {
+    AISX_OK = 0,
+    AISX_ERR_INVALID = -1,      /* bad argument */
+    AISX_ERR_OUT_OF_RANGE = -2, /* the reference throws std::out_of_range here */
+    AISX_ERR_HIP = -3,          /* HIP runtime error, see aisx_last_error() */
+    AISX_ERR_NO_DEVICE = -4,    /* no gfx950 device: there is no CPU fallback */
+    AISX_ERR_OVERFLOW = -5,     /* a tag / carry buffer was too small; results truncated */
+    AISX_ERR_RUNTIME = -6       /* the reference throws std::runtime_error here */
+};
+
+int aisx_version(void);
+const char* aisx_last_error(void);
+int aisx_device_count(int* count);
+int aisx_set_device(int device);
+
+/* ------------------------------------------------------------------------ */
+/* corr_est_cc  (include/ais/corr_est_cc.h:85-106, lib/corr_est_cc_impl.cc)  */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_corr aisx_corr;
+
+/* corr_est_cc::make(symbols, sps, mark_delay, threshold) (corr_est_cc.h:102-103,
+ * ctor lib/corr_est_cc_impl.cc:48-117).  max_items bounds `n` of one call;
+ * max_tags_per_chan bounds the tags one call can return per channel. */
+int aisx_corr_create(aisx_corr** h, const aisx_cf32* symbols, int nsym, float sps, unsigned mark_delay,
+                     float threshold, int nchan, int max_items, int max_tags_per_chan);
+int aisx_corr_destroy(aisx_corr* h);
+/* symbols() (corr_est_cc.h:105): d_symbols as stored (reversed conjugate) */
+int aisx_corr_symbols(const aisx_corr* h, aisx_cf32* out, int cap);
+/* set_symbols() (corr_est_cc.h:106, impl :132-162); keeps the reference's quirk:
+ * taps stored as given (no conjugate/reverse), threshold not recomputed.
+ * nsym must equal the current template length. */
+int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int nsym);
+int aisx_corr_history(const aisx_corr* h);         /* history() = nsym + 1   (:95)  */
+int aisx_corr_output_multiple(const aisx_corr* h); /* fft_filter nsamples    (:84-85) */
+int aisx_corr_max_noutput_items(const aisx_corr* h); /* 24*1024              (:111-112) */
+float aisx_corr_threshold(const aisx_corr* h);     /* d_thresh               (:71-74) */
+unsigned aisx_corr_mark_delay(const aisx_corr* h); /* d_mark_delay           (:65-66) */
+uint64_t aisx_corr_nitems_written(const aisx_corr* h);
+int aisx_corr_reset(aisx_corr* h); /* zero history, nitems_written = 0 */
+
+/* One work() call of n items on every channel (lib/corr_est_cc_impl.cc:164-279).
+ * d_in  : n NEW items per channel (the handle supplies the N history items);
+ * d_out : n items, the input delayed by N (:184);
+ * d_corr: optional port-1 output, the correlator output (:174-177, :188), or NULL.
+ * Semantics of one call = one work(noutput_items = n): the peak search restarts
+ * at i = 0 and the climb / centre of mass stop at the call's edge.  n need not
+ * be a multiple of output_multiple().  Tags stay in device memory (feed them to
+ * aisx_msk_process_stream via aisx_corr_tags_device, or fetch them with
+ * aisx_corr_read_tags). */
+int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
+                      aisx_cf32* d_corr, long corr_stride, int n, void* stream);
+/* device tag buffers of the last call: tags[c * cap + k], k < min(counts[c], cap) */
+int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int** d_counts, int* cap);
+/* copy the last call's tags to the host, channel by channel in emission order;
+ * synchronises the stream.  Returns AISX_ERR_OVERFLOW if a channel overflowed
+ * max_tags_per_chan or host_cap was too small (what fits is still returned). */
+int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_cap, int* ntags, void* stream);
+/* GNU Radio path (nchan == 1): `in` = input_items[0] as the scheduler passes it
+ * (history()-1 old items, then noutput_items new ones), out = output_items[0],
+ * corr = output_items[1] or NULL, nitems_written = nitems_written(0). */
+int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32* out, aisx_cf32* corr, int noutput_items,
+                        uint64_t nitems_written, aisx_tag* tags, int tag_cap, int* ntags);
+
+/* ------------------------------------------------------------------------ */
+/* msk_timing_recovery_cc (include/ais/msk_timing_recovery_cc.h:46-69,        */
+/* lib/msk_timing_recovery_cc_impl.cc) + fused NRZI bit tail                  */
+/* (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64)                      */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_msk aisx_msk;
+
+/* make(sps, gain, limit, osps) (msk_timing_recovery_cc.h:60, ctor impl :45-62).
+ * AISX_ERR_OUT_OF_RANGE if gain <= 0 or osps not in {1,2} (impl :61,:82). */
+int aisx_msk_create(aisx_msk** h, float sps, float gain, float limit, int osps, int nchan, int max_items);
+int aisx_msk_destroy(aisx_msk* h);
+int aisx_msk_set_gain(aisx_msk* h, float gain); /* :80-84, AISX_ERR_OUT_OF_RANGE if gain <= 0 */
+float aisx_msk_get_gain(const aisx_msk* h);     /* :86-88 */
+int aisx_msk_set_limit(aisx_msk* h, float limit); /* :90-92 */
+float aisx_msk_get_limit(const aisx_msk* h);      /* :94-96 */
+int aisx_msk_set_sps(aisx_msk* h, float sps);     /* :69-74 (d_sps = sps/2, omega reset) */
+float aisx_msk_get_sps(const aisx_msk* h);        /* :76-78 returns d_sps */
+int aisx_msk_forecast(const aisx_msk* h, int noutput_items); /* :98-105 */
+int aisx_msk_out_capacity(const aisx_msk* h);     /* items per channel the output arrays must hold */
+int aisx_msk_reset(aisx_msk* h);
+
+/* One general_work() call per channel under the stream contract:
+ * the n new items are appended to the unconsumed items kept in the handle,
+ * ninput_items = all of them minus one look-ahead item, noutput_items = the
+ * largest count whose forecast() fits; unconsumed items and still-live
+ * time_est tags are carried to the next call.  d_tags/d_tag_counts/tag_cap: this
+ * call's tags as laid out by aisx_corr_tags_device (only key time_est is read,
+ * impl :125-130), or NULL.  Outputs (any may be NULL): d_syms = port 0,
+ * d_err = port 1, d_mu = port 2 (impl :186-191), d_bits = the unpacked NRZI
+ * decoded bit per symbol; all [nchan][out_stride].  d_produced[c] = items
+ * written for channel c. */
+int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_tag* d_tags,
+                            const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms, float* d_err, float* d_mu,
+                            uint8_t* d_bits, long out_stride, int* d_produced, void* stream);
+/* status word per channel of the last call, or-ed over channels (0 = clean) */
+int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
+/* GNU Radio path (nchan == 1), host pointers as general_work() receives them
+ * (impl :107-206): tags = the time_est tags get_tags_in_range would return or
+ * any superset, nitems_read = nitems_read(0).  *consumed is what to pass to
+ * consume_each(), *produced the return value.  The reference's loop bound
+ * (impl :119,:138) lets the 8-tap interpolator read in[ninput_items], one item
+ * past what the scheduler announced; in_has_lookahead = 1 says that item is
+ * readable (always true inside a GNU Radio circular buffer), 0 substitutes 0. */
+int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ninput_items, const aisx_cf32* in, aisx_cf32* out,
+                               float* out_err, float* out_mu, uint8_t* out_bits, const aisx_tag* tags, int ntags,
+                               uint64_t nitems_read, int in_has_lookahead, int* consumed, int* produced);
+
+/* ------------------------------------------------------------------------ */
+/* freqest (include/ais/freqest.h:36-49, lib/freqest_impl.cc) and            */
+/* square_and_fft_sync_cc (python/gmsk_sync.py:14-37)                        */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_freqsync aisx_freqsync;
+/* square_and_fft_sync_cc(samplerate, bits_per_sec, fftlen) (gmsk_sync.py:15);
+ * builds freqest::make(int(samplerate), int(bits_per_sec), fftlen) (:25). */
+int aisx_freqsync_create(aisx_freqsync** h, double samplerate, double bits_per_sec, int fftlen, int nchan,
+                         int max_items);
+int aisx_freqsync_destroy(aisx_freqsync* h);
+int aisx_freqsync_reset(aisx_freqsync* h);
+/* n new items per channel; every complete fftlen-vector is processed (one
+ * freqest work() call per channel); *n_out = items written per channel (a
+ * multiple of fftlen); d_fhat (optional) = one estimate per vector,
+ * [nchan][fhat_stride]. */
+int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out,
+                          long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream);
+/* freqest::work on already transformed vectors (lib/freqest_impl.cc:57-88):
+ * d_vecs [nchan][nvec*fftlen] (fft-shifted spectra), d_out [nchan][nvec]. */
+int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long vec_stride, float* d_out, long out_stride,
+                      int nvec, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* analog.feedforward_agc_cc(nsamples, reference) (python/ais_demod.py:35)   */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_agc aisx_agc;
+int aisx_agc_create(aisx_agc** h, int nsamples, float reference, int nchan, int max_items);
+int aisx_agc_destroy(aisx_agc* h);
+int aisx_agc_reset(aisx_agc* h);
+int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AISX_H */

@@ -1014,19 +1014,23 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
     }
     memcpy(h->msk_buf + 1 + h->msk_pending, y3, sizeof(orc_cf) * n1);
     h->msk_pending += n1;
-    int ninput = h->msk_pending - 1; /* keep one look-ahead item out of sight */
-    int nout = 0;
-    if (ninput > 0) {
-        nout = (int)((ninput - 3.0 * orc_msk_get_sps(h->msk) - 8) / (2.0 * orc_msk_get_sps(h->msk))) + 2;
-        while (nout > 0 && orc_msk_forecast(h->msk, nout) > ninput)
-            nout--;
-    }
-    if (nout > 0) {
+    /* the scheduler calls general_work again and again until forecast(1) no longer fits */
+    for (;;) {
+        int ninput = h->msk_pending - 1; /* keep one look-ahead item out of sight */
+        int nout = 0;
+        if (ninput > 0) {
+            nout = (int)((ninput - 3.0 * orc_msk_get_sps(h->msk) - 8) / (2.0 * orc_msk_get_sps(h->msk))) + 2;
+            while (nout > 0 && orc_msk_forecast(h->msk, nout) > ninput)
+                nout--;
+        }
+        if (nout > max_bits - nbits)
+            nout = max_bits - nbits;
+        if (nout <= 0 || (int)(ninput - 3.0 * orc_msk_get_sps(h->msk)) <= 0)
+            break;
         orc_cf *syms = (orc_cf *)malloc(sizeof(orc_cf) * (size_t)nout);
         int consumed = 0, status = 0;
         int prod = orc_msk_general_work(h->msk, nout, ninput, h->msk_buf + 1, syms, NULL, NULL, h->store, h->nstore,
                                         h->msk_read, &consumed, &status);
-        /* consume */
         if (consumed > 0) {
             memmove(h->msk_buf, h->msk_buf + consumed, sizeof(orc_cf) * (size_t)(h->msk_pending - consumed + 1));
             h->msk_pending -= consumed;
@@ -1039,12 +1043,13 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
                 h->store[w++] = h->store[k];
         h->nstore = w;
         /* 5. bit tail */
-        int nb = prod < max_bits ? prod : max_bits;
-        orc_bittail_process(&h->tail, syms, nb, bits);
+        orc_bittail_process(&h->tail, syms, prod, bits + nbits);
         if (syms_out)
-            memcpy(syms_out, syms, sizeof(orc_cf) * nb);
-        nbits = nb;
+            memcpy(syms_out + nbits, syms, sizeof(orc_cf) * prod);
+        nbits += prod;
         free(syms);
+        if (consumed <= 0 && prod == 0)
+            break;
     }
     free(newtags);
     free(cbuf);

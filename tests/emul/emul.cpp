@@ -1,0 +1,315 @@
+// emul.cpp -- CPU model of the execution context the HIP kernel bodies run
+// under (one OS thread per lane, std::barrier for __syncthreads / wave ops).
+// TEST INFRASTRUCTURE: it instantiates the *same* kernel-body templates the
+// product compiles for gfx950 (gr-ais_amd/csrc/k_*.h) so their index arithmetic
+// can be checked against the oracle on a machine without a GPU.  It is not part
+// of libaisx.so and nothing in the product can reach it.
+#include <barrier>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "../../gr-ais_amd/csrc/aisx_common.h"
+#include "../../gr-ais_amd/csrc/aisx_tables.h"
+#include "../../gr-ais_amd/csrc/k_corr.h"
+#include "../../gr-ais_amd/csrc/k_msk.h"
+#include "../../gr-ais_amd/csrc/aisx_plan.h"
+#if __has_include("../../gr-ais_amd/csrc/k_agc.h")
+#include "../../gr-ais_amd/csrc/k_agc.h"
+#define HAVE_AGC 1
+#endif
+#if __has_include("../../gr-ais_amd/csrc/k_freqsync.h")
+#include "../../gr-ais_amd/csrc/k_freqsync.h"
+#define HAVE_FREQSYNC 1
+#endif
+
+using namespace aisx;
+
+struct EmuShared {
+    std::barrier<> bar;
+    int nthreads;
+    std::vector<char> lds;
+    unsigned long long x64[1024];
+    double xf64[1024];
+    explicit EmuShared(int nt, size_t ldsbytes) : bar(nt), nthreads(nt), lds(ldsbytes + 64) {}
+};
+
+struct EmuCtx {
+    EmuShared* sh;
+    int tid_, bx_, by_;
+    int tid() const { return tid_; }
+    int nthreads() const { return sh->nthreads; }
+    int bx() const { return bx_; }
+    int by() const { return by_; }
+    char* lds() const { return sh->lds.data(); }
+    void sync() const { sh->bar.arrive_and_wait(); }
+    int wave_base() const { return tid_ & ~63; }
+    unsigned long long ballot(bool p) const
+    {
+        sh->x64[tid_] = p ? 1ull : 0ull;
+        sync();
+        unsigned long long m = 0;
+        for (int l = 0; l < 64 && wave_base() + l < sh->nthreads; l++)
+            m |= sh->x64[wave_base() + l] << l;
+        sync();
+        return m;
+    }
+    template <class T>
+    T xchg(T v, int src_lane) const
+    {
+        static_assert(sizeof(T) <= 8, "");
+        unsigned long long raw = 0;
+        memcpy(&raw, &v, sizeof(T));
+        sh->x64[tid_] = raw;
+        sync();
+        int s = wave_base() + (src_lane & 63);
+        if (s >= sh->nthreads)
+            s = tid_;
+        unsigned long long r = sh->x64[s];
+        sync();
+        T out;
+        memcpy(&out, &r, sizeof(T));
+        return out;
+    }
+    unsigned long long shfl_u64(unsigned long long v, int src) const { return xchg(v, src); }
+    float shfl_f32(float v, int src) const { return xchg(v, src); }
+    int shfl_i32(int v, int src) const { return xchg(v, src); }
+    float shfl_up_f32(float v, int d) const { int l = tid_ & 63; return xchg(v, l - d >= 0 ? l - d : l); }
+    float shfl_down_f32(float v, int d) const { int l = tid_ & 63; return xchg(v, l + d < 64 ? l + d : l); }
+    float shfl_xor_f32(float v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
+    int shfl_xor_i32(int v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
+    double shfl_xor_f64(double v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
+    int ctz64(unsigned long long v) const { return __builtin_ctzll(v); }
+    void atomic_or64(unsigned long long* p, unsigned long long v) const { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+};
+
+template <class Body>
+static void run_grid(int gx, int gy, int nthreads, size_t ldsbytes, Body body)
+{
+    for (int by = 0; by < gy; by++)
+        for (int bx = 0; bx < gx; bx++) {
+            EmuShared sh(nthreads, ldsbytes);
+            std::vector<std::thread> th;
+            th.reserve(nthreads);
+            for (int t = 0; t < nthreads; t++)
+                th.emplace_back([&, t]() {
+                    EmuCtx cx{ &sh, t, bx, by };
+                    body(cx);
+                });
+            for (auto& x : th)
+                x.join();
+        }
+}
+
+// lanes that never synchronise can simply run one after another
+template <class Body>
+static void run_independent(int gx, int nthreads, Body body)
+{
+    EmuShared sh(1, 0);
+    sh.nthreads = nthreads;
+    for (int bx = 0; bx < gx; bx++)
+        for (int t = 0; t < nthreads; t++) {
+            EmuCtx cx{ &sh, t, bx, 0 };
+            body(cx);
+        }
+}
+
+extern "C" {
+
+int emu_cf_sizes(int* F, int* T) { *F = CF_F; *T = CF_T; return CF_LDS_BYTES; }
+
+void emu_corr_inith(const cf* taps_scaled, const cf* wtab, cf* Hpos)
+{
+    CorrInitParams p{ taps_scaled, wtab, Hpos };
+    run_grid(1, 1, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_inith_body(cx, p); });
+}
+
+void emu_corr_main(const CorrParams* p, int nchan)
+{
+    run_grid(p->nseg, nchan, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_main_body(cx, *p); });
+}
+
+void emu_corr_resolve(const ResolveParams* p, int nchan)
+{
+    run_grid(nchan, 1, 64, 0, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
+}
+
+void emu_msk(const MskParams* p)
+{
+    run_independent((p->nchan + 63) / 64, 64, [&](EmuCtx& cx) { msk_body(cx, *p); });
+}
+
+// ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
+struct EmuCorr {
+    CorrSetup cs;
+    int N, nchan, L;
+    std::vector<cf> wtab, Hpos, hist[2], scratch;
+    std::vector<unsigned long long> abits;
+    int cur = 0;
+    unsigned long long written = 0;
+};
+
+void* emu_corr_create(const cf* symbols, int nsym, float sps, unsigned mark_delay, float threshold, int nchan)
+{
+    EmuCorr* h = new EmuCorr();
+    h->cs = corr_setup(symbols, nsym, sps, mark_delay, threshold);
+    h->N = nsym;
+    h->nchan = nchan;
+    h->L = CF_F - nsym;
+    h->wtab = corr_wtab();
+    h->Hpos.resize(CF_F);
+    std::vector<cf> pad = corr_padded_taps(h->cs.symbols);
+    emu_corr_inith(pad.data(), h->wtab.data(), h->Hpos.data());
+    h->hist[0].assign((size_t)nchan * nsym, mk(0, 0));
+    h->hist[1].assign((size_t)nchan * nsym, mk(0, 0));
+    return h;
+}
+void emu_corr_destroy(void* hv) { delete (EmuCorr*)hv; }
+float emu_corr_threshold(void* hv) { return ((EmuCorr*)hv)->cs.thresh; }
+int emu_corr_output_multiple(void* hv) { return ((EmuCorr*)hv)->cs.out_multiple; }
+void emu_corr_symbols(void* hv, cf* out) { EmuCorr* h = (EmuCorr*)hv; memcpy(out, h->cs.symbols.data(), sizeof(cf) * h->N); }
+
+int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_stride, cf* corr, long corr_stride,
+                     int n, tag_rec* tags, int tag_cap, int* tag_count, int force_nseg)
+{
+    EmuCorr* h = (EmuCorr*)hv;
+    int nseg, tps;
+    corr_grid(h->nchan, n, h->L, &nseg, &tps);
+    if (force_nseg > 0) {
+        const int ntiles = (n + h->L - 1) / h->L;
+        tps = (ntiles + force_nseg - 1) / force_nseg;
+        nseg = (ntiles + tps - 1) / tps;
+    }
+    const long astride = (n + 63) / 64 + 1;
+    h->abits.assign((size_t)h->nchan * astride, 0ull);
+    h->scratch.assign((size_t)h->nchan * n, mk(-7777.f, -7777.f)); // poison: sparse scratch
+    CorrParams p;
+    p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
+    p.corr = corr ? corr : h->scratch.data(); p.corr_stride = corr ? corr_stride : n; p.dense_corr = corr ? 1 : 0;
+    p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
+    p.Hpos = h->Hpos.data(); p.wtab = h->wtab.data();
+    p.abits = h->abits.data(); p.abits_stride = astride;
+    p.n = n; p.N = h->N; p.L = h->L; p.nseg = nseg; p.tiles_per_seg = tps; p.thresh = h->cs.thresh;
+    emu_corr_main(&p, h->nchan);
+    ResolveParams r;
+    r.abits = p.abits; r.abits_stride = astride; r.corr = p.corr; r.corr_stride = p.corr_stride; r.dense_corr = p.dense_corr;
+    r.in = in; r.in_stride = in_stride; r.hist_in = p.hist_in; r.taps = h->cs.symbols.data();
+    r.n = n; r.N = h->N; r.isps = h->cs.isps; r.mark_delay = h->cs.mark_delay; r.written = h->written;
+    r.emit_port1 = corr ? 1 : 0; r.tags = tags; r.tag_cap = tag_cap; r.tag_count = tag_count; r.atan_tab = aisx_atan_table;
+    emu_corr_resolve(&r, h->nchan);
+    h->cur ^= 1;
+    h->written += (unsigned long long)n;
+    return 0;
+}
+
+// ---- msk_timing_recovery_cc handle mirroring aisx_msk_* ----
+struct EmuMsk {
+    int nchan, osps;
+    float d_sps, gain, gain_omega, limit;
+    static constexpr int carry_cap = 256, ctag_cap = 64;
+    std::vector<float> mu, omega;
+    std::vector<int> div, carry_len[2], ctag_n[2], produced, consumed, status;
+    std::vector<cf> dly1, dly2, diff1, tprev, carry[2];
+    std::vector<unsigned char> tbit;
+    std::vector<unsigned long long> nread;
+    std::vector<tag_rec> ctag[2];
+    int cur = 0;
+};
+
+void* emu_msk_create(float sps, float gain, float limit, int osps, int nchan)
+{
+    EmuMsk* h = new EmuMsk();
+    MskSetup ms = msk_setup(sps, gain);
+    h->nchan = nchan; h->osps = osps; h->d_sps = ms.d_sps; h->gain = gain; h->gain_omega = ms.gain_omega; h->limit = limit;
+    h->mu.assign(nchan, 0.5f); h->omega.assign(nchan, ms.d_sps); h->div.assign(nchan, 0);
+    h->dly1.assign(nchan, mk(0, 0)); h->dly2 = h->dly1; h->diff1 = h->dly1; h->tprev = h->dly1;
+    h->tbit.assign(nchan, 0); h->nread.assign(nchan, 0ull);
+    for (int k = 0; k < 2; k++) {
+        h->carry[k].assign((size_t)nchan * EmuMsk::carry_cap, mk(0, 0));
+        h->carry_len[k].assign(nchan, 0);
+        h->ctag[k].assign((size_t)nchan * EmuMsk::ctag_cap, tag_rec{ 0, 0, 0, 0 });
+        h->ctag_n[k].assign(nchan, 0);
+    }
+    h->produced.assign(nchan, 0); h->consumed.assign(nchan, 0); h->status.assign(nchan, 0);
+    return h;
+}
+void emu_msk_destroy(void* hv) { delete (EmuMsk*)hv; }
+
+static void emu_msk_fill(EmuMsk* h, MskParams& p)
+{
+    p.nchan = h->nchan; p.d_sps = h->d_sps; p.gain = h->gain; p.gain_omega = h->gain_omega; p.limit = h->limit; p.osps = h->osps;
+    p.mu = h->mu.data(); p.omega = h->omega.data(); p.div = h->div.data();
+    p.dly1 = h->dly1.data(); p.dly2 = h->dly2.data(); p.diff1 = h->diff1.data();
+    p.tail_prev_sym = h->tprev.data(); p.tail_prev_bit = h->tbit.data(); p.nread = h->nread.data();
+    p.carry_in = h->carry[h->cur].data(); p.carry_out = h->carry[h->cur ^ 1].data();
+    p.carry_len_in = h->carry_len[h->cur].data(); p.carry_len_out = h->carry_len[h->cur ^ 1].data(); p.carry_cap = EmuMsk::carry_cap;
+    p.ctag_in = h->ctag[h->cur].data(); p.ctag_out = h->ctag[h->cur ^ 1].data();
+    p.ctag_n_in = h->ctag_n[h->cur].data(); p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
+    p.consumed = h->consumed.data(); p.status = h->status.data();
+    p.mmse = &aisx_mmse_taps[0][0]; p.atan_tab = aisx_atan_table;
+}
+
+int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const tag_rec* tags, const int* tag_counts,
+                           int tag_cap, cf* syms, float* err, float* mu, unsigned char* bits, long out_stride,
+                           int* produced, int* consumed_out)
+{
+    EmuMsk* h = (EmuMsk*)hv;
+    MskParams p;
+    emu_msk_fill(h, p);
+    p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
+    p.tags = tags; p.tag_count = tag_counts; p.tag_cap = tag_cap;
+    p.syms = syms; p.err = err; p.mu_out = mu; p.bits = bits; p.out_stride = out_stride; p.out_cap = (int)out_stride;
+    p.produced = produced;
+    emu_msk(&p);
+    h->cur ^= 1;
+    int st = 0;
+    for (int c = 0; c < h->nchan; c++) {
+        st |= h->status[c];
+        if (consumed_out)
+            consumed_out[c] = h->consumed[c];
+    }
+    return st;
+}
+
+int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[ninput] readable */, cf* out,
+                         float* err, float* mu, unsigned char* bits, const tag_rec* tags, int ntags,
+                         unsigned long long nitems_read, int* consumed, int* produced)
+{
+    EmuMsk* h = (EmuMsk*)hv;
+    MskParams p;
+    emu_msk_fill(h, p);
+    h->nread[0] = nitems_read;
+    h->carry_len[h->cur][0] = 0;
+    h->ctag_n[h->cur][0] = 0;
+    p.in = in; p.in_stride = ninput + 1; p.n = ninput; p.stream_mode = 0; p.gr_ninput = ninput; p.gr_noutput = noutput;
+    p.tags = tags; p.tag_count = &ntags; p.tag_cap = ntags + 1;
+    p.syms = out; p.err = err; p.mu_out = mu; p.bits = bits; p.out_stride = noutput; p.out_cap = noutput;
+    p.produced = h->produced.data();
+    emu_msk(&p);
+    h->cur ^= 1;
+    *consumed = h->consumed[0];
+    *produced = h->produced[0];
+    return h->status[0];
+}
+
+const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
+const float* emu_atan_table() { return aisx_atan_table; }
+
+#ifdef HAVE_AGC
+void emu_agc(const AgcParams* p, int gx, int nchan)
+{
+    run_grid(gx, nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, *p); });
+}
+#endif
+#ifdef HAVE_FREQSYNC
+void emu_fs_est(const FsEstParams* p, int gx, int nchan)
+{
+    run_grid(gx, nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, *p); });
+}
+void emu_fs_mix(const FsMixParams* p, int gx)
+{
+    run_grid(gx, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, *p); });
+}
+#endif
+}

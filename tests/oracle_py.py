@@ -274,21 +274,32 @@ class MskStream:
         if len(new_tags):
             self.store = np.concatenate([self.store, np.asarray(new_tags, dtype=TAG_DTYPE)])
             self.store = self.store[np.argsort(self.store["offset"], kind="stable")]
-        pending = self.buf.size - 1
-        ninput = pending - 1
-        nout = 0
-        if ninput > 0:
+        outs, o2s, o3s, total = [], [], [], 0
+        while True:  # the scheduler keeps calling general_work until forecast(1) no longer fits
+            pending = self.buf.size - 1
+            ninput = pending - 1
+            nout = 0
             dsps = lib().orc_msk_get_sps(self.m.h)
-            nout = int((ninput - 3.0 * dsps - 8) / (2.0 * dsps)) + 2
-            while nout > 0 and self.m.forecast(nout) > ninput:
-                nout -= 1
-        if nout <= 0:
-            return np.zeros(0, np.complex64), None, None, 0
-        out, o2, o3, cons, st = self.m.general_work(nout, ninput, self.buf, 1, self.store, self.read, want_aux)
-        self.buf = self.buf[cons:].copy()
-        self.read += cons
-        self.store = self.store[self.store["offset"] >= self.read]
-        return out, o2, o3, cons
+            if ninput > 0:
+                nout = int((ninput - 3.0 * dsps - 8) / (2.0 * dsps)) + 2
+                while nout > 0 and self.m.forecast(nout) > ninput:
+                    nout -= 1
+            if nout <= 0 or int(ninput - 3.0 * dsps) <= 0:
+                break
+            out, o2, o3, cons, st = self.m.general_work(nout, ninput, self.buf, 1, self.store, self.read, want_aux)
+            self.buf = self.buf[cons:].copy()
+            self.read += cons
+            self.store = self.store[self.store["offset"] >= self.read]
+            outs.append(out)
+            o2s.append(o2)
+            o3s.append(o3)
+            total += cons
+            if cons <= 0 and len(out) == 0:
+                break
+        if not outs:
+            return np.zeros(0, np.complex64), np.zeros(0, np.float32), np.zeros(0, np.float32), 0
+        cat = np.concatenate
+        return cat(outs), (cat(o2s) if want_aux else None), (cat(o3s) if want_aux else None), total
 
 
 class BitTail(C.Structure):

@@ -1,0 +1,66 @@
+"""Shared parity helpers for the test-suite (tolerances of BASELINE.json's
+north_star: tag positions within +-1 sample, peak magnitude within 1e-5
+relative, time_est within 1e-4 absolute)."""
+import numpy as np
+
+MAG_RTOL = 1e-5
+TIME_ATOL = 1e-4
+PHASE_ATOL = 2e-4
+
+
+def tag_groups(tags, port1_flag=0x100):
+    """Split a tag array (fields offset,value,key) into detection groups
+    [(corr_start_off, mag, phase, center, mark_off)] for port-0 tags."""
+    groups = []
+    cur = None
+    for t in tags:
+        key = int(t["key"])
+        if "port" in t.dtype.names and int(t["port"]) != 0:
+            continue
+        if key & port1_flag:
+            continue
+        if key == 0:
+            cur = dict(start=int(t["offset"]), mag=float(t["value"]))
+            groups.append(cur)
+        elif cur is not None:
+            if key == 1:
+                cur["phase"] = float(t["value"])
+                cur["mark"] = int(t["offset"])
+            elif key == 2:
+                cur["center"] = float(t["value"])
+            elif key == 3:
+                cur["est"] = float(t["value"])
+    return groups
+
+
+def assert_tags_match(got, want, exact_offsets=True):
+    g, w = tag_groups(got), tag_groups(want)
+    assert len(g) == len(w), "detections: got %d want %d\n%s\n%s" % (len(g), len(w), g[:8], w[:8])
+    for a, b in zip(g, w):
+        if exact_offsets:
+            assert a["start"] == b["start"], (a, b)
+        else:
+            assert abs(a["start"] - b["start"]) <= 1, (a, b)
+        assert a["mark"] - a["start"] == b["mark"] - b["start"]
+        assert abs(a["mag"] - b["mag"]) <= MAG_RTOL * abs(b["mag"]), (a, b)
+        assert abs(a["est"] - b["est"]) <= MAG_RTOL * abs(b["est"]), (a, b)
+        if a["start"] == b["start"]:
+            assert abs(a["center"] - b["center"]) <= TIME_ATOL, (a, b)
+            d = abs(a["phase"] - b["phase"])
+            assert min(d, abs(d - 2 * np.pi)) <= PHASE_ATOL, (a, b)
+    return len(g)
+
+
+def unit_template(rng, N):
+    return np.exp(1j * rng.uniform(-np.pi, np.pi, N)).astype(np.complex64)
+
+
+def planted(rng, nchan, n, tmpl, positions, noise=0.05, amp=1.0):
+    x = (noise * (rng.normal(size=(nchan, n)) + 1j * rng.normal(size=(nchan, n)))).astype(np.complex64)
+    N = tmpl.size
+    for c, plist in enumerate(positions):
+        for p in plist:
+            lo, hi = max(p, 0), min(p + N, n)
+            if hi > lo:
+                x[c, lo:hi] += (amp * tmpl[lo - p:hi - p] * np.exp(1j * rng.uniform(-3, 3))).astype(np.complex64)
+    return x

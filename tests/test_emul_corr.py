@@ -1,0 +1,102 @@
+"""corr_est_cc kernel bodies (gr-ais_amd/csrc/k_corr.h) run under the CPU lane
+model and compared with the oracle.  Exercises the index arithmetic of the
+2048-point register/LDS FFT, overlap-save tiling, history carry, threshold
+bitmask and the tag resolver without a GPU."""
+import numpy as np
+import pytest
+
+import emul_py as emu
+import oracle_py as orc
+from parity import assert_tags_match, planted, unit_template
+
+
+def _oracle_run(tmpl, sps, chunks, mark_delay=1, thr=0.9, want_corr=True):
+    o = orc.CorrEst(tmpl, sps, mark_delay, thr)
+    outs, corrs, tags = [], [], []
+    for x in chunks:
+        a, b, t = o.work(x, want_corr=want_corr)
+        outs.append(a)
+        corrs.append(b)
+        tags.append(t)
+    return outs, corrs, tags, o
+
+
+@pytest.mark.parametrize("N", [1, 20, 112, 896, 1024])
+def test_emul_corr_dense_matches_oracle(N):
+    rng = np.random.default_rng(100 + N)
+    tmpl = unit_template(rng, N)
+    n = 4500 if N < 512 else 3000
+    pos = [[700, 2900], [5, n - N - 3], []]
+    x = planted(rng, 3, n, tmpl, pos)
+    e = emu.CorrEst(tmpl, 4.0, 1, 0.9, nchan=3)
+    out, corr, tags, cnt, _ = e.work(x, want_corr=True)
+    for c in range(3):
+        oo, oc, ot, o = _oracle_run(tmpl, 4.0, [x[c]])
+        assert e.threshold == o.threshold and e.output_multiple == o.output_multiple
+        assert np.array_equal(e.symbols(), o.taps())
+        assert np.array_equal(out[c], oo[0])
+        scale = np.max(np.abs(oc[0])) + 1e-30
+        assert np.max(np.abs(corr[c] - oc[0])) / scale < 2e-6
+        assert_tags_match(tags[c], ot[0])
+    if N > 1:
+        assert sum(len(t) for t in tags) > 0
+
+
+@pytest.mark.parametrize("N,nseg", [(112, 1), (112, 3), (896, 2)])
+def test_emul_corr_sparse_streaming_segments(N, nseg):
+    # sparse scratch (port 1 not connected), several successive calls with
+    # state carried, different lengths incl. n < N, peaks on call boundaries
+    rng = np.random.default_rng(7 * N + nseg)
+    tmpl = unit_template(rng, N)
+    lens = [3000, N // 2 + 1, 1, 2500, 4100]
+    total = sum(lens)
+    edges = np.cumsum(lens)
+    pos = [[400, int(edges[0]) - N, int(edges[0]) - N + 1, int(edges[2]) + 10, int(edges[3]) - N // 2],
+           [int(edges[0]) - N - 1, int(edges[3]) + 777]]
+    xs = planted(rng, 2, total, tmpl, pos, noise=0.03)
+    e = emu.CorrEst(tmpl, 4.0, 1, 0.9, nchan=2)
+    o = [orc.CorrEst(tmpl, 4.0, 1, 0.9) for _ in range(2)]
+    k = 0
+    ndet = 0
+    for L in lens:
+        chunk = xs[:, k:k + L]
+        out, _, tags, cnt, _ = e.work(chunk, want_corr=False, force_nseg=nseg)
+        for c in range(2):
+            oo, _, ot = o[c].work(chunk[c], want_corr=False)
+            assert np.array_equal(out[c], oo)
+            ndet += assert_tags_match(tags[c], ot)
+        k += L
+    assert ndet >= 5
+
+
+def test_emul_corr_dense_detections_and_overflow():
+    # threshold so low that (almost) every isps-th sample fires: the resolver's
+    # serial chain, the climb across word boundaries and the tag-capacity overflow
+    rng = np.random.default_rng(5)
+    N = 20
+    tmpl = unit_template(rng, N)
+    n = 1500
+    x = (rng.normal(size=(1, n)) + 1j * rng.normal(size=(1, n))).astype(np.complex64)
+    e = emu.CorrEst(tmpl, 4.0, 3, 1e-4, nchan=1)
+    out, _, tags, cnt, raw = e.work(x, want_corr=False, tag_cap=4 * n)
+    o = orc.CorrEst(tmpl, 4.0, 3, 1e-4)
+    _, _, ot = o.work(x[0])
+    assert len(ot) > 4 * (n // 8)
+    assert_tags_match(tags[0], ot)
+    e2 = emu.CorrEst(tmpl, 4.0, 3, 1e-4, nchan=1)
+    _, _, tags2, cnt2, _ = e2.work(x, want_corr=False, tag_cap=40)
+    assert cnt2[0] == cnt[0] and len(tags2[0]) == 40
+    assert np.array_equal(tags2[0], tags[0][:40])
+
+
+def test_emul_corr_sps_rounding_and_mark_delay_clamp():
+    rng = np.random.default_rng(9)
+    N = 24
+    tmpl = unit_template(rng, N)
+    x = planted(rng, 1, 2000, tmpl, [[100, 900]], noise=0.2)
+    for sps, md in [(5.2083, 1), (4.0, 1000), (2.4, 0)]:
+        e = emu.CorrEst(tmpl, sps, md, 0.5, nchan=1)
+        o = orc.CorrEst(tmpl, sps, md, 0.5)
+        _, _, tags, _, _ = e.work(x)
+        _, _, ot = o.work(x[0])
+        assert_tags_match(tags[0], ot)

@@ -1,0 +1,98 @@
+"""msk_timing_recovery_cc kernel body (gr-ais_amd/csrc/k_msk.h) under the CPU
+lane model vs the oracle: every output must be BIT-identical."""
+import numpy as np
+import pytest
+
+import emul_py as emu
+import oracle_py as orc
+from ais_amd import synth
+
+
+def _signal(seed, n, sps=4, family="P"):
+    x, infos = synth.make_channel(seed, n, family, sps, amp=1.0, cfo_max=50.0)
+    return x, infos
+
+
+def _rand_tags(rng, n, count, chan=0):
+    offs = np.sort(rng.choice(np.arange(10, n - 10), size=count, replace=False))
+    tags = np.zeros(count, dtype=emu.TAG_DTYPE)
+    tags["offset"] = offs
+    tags["value"] = rng.uniform(-0.9, 0.9, count)
+    tags["key"] = 2
+    tags["chan"] = chan
+    return tags
+
+
+@pytest.mark.parametrize("sps,osps", [(4.0, 1), (4.0, 2), (5.2083, 1), (5.0, 1)])
+def test_emul_msk_stream_bit_exact(sps, osps):
+    rng = np.random.default_rng(int(sps * 10) + osps)
+    nchan, lens = 3, [6000, 37, 4000, 1, 9000]
+    total = sum(lens)
+    xs = np.stack([_signal(50 + c, total, 4)[0] for c in range(nchan)])
+    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan)
+    o = [orc.MskStream(sps, 0.04, 0.01, osps) for _ in range(nchan)]
+    bt = [orc.BitTail() for _ in range(nchan)]
+    # tags: a mix of plausible time_est tags, NaN, other keys, clustered offsets
+    all_tags = []
+    for c in range(nchan):
+        t = _rand_tags(rng, total, 60, c)
+        t["value"][5] = np.nan
+        t["key"][7] = 1
+        t["offset"][20] = t["offset"][19] + 1
+        t["offset"][21] = t["offset"][19] + 2
+        t = t[np.argsort(t["offset"], kind="stable")]
+        all_tags.append(t)
+    k = 0
+    nsym = 0
+    for L in lens:
+        chunk = xs[:, k:k + L]
+        cap = 64
+        tg = np.zeros((nchan, cap), dtype=emu.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        new = []
+        for c in range(nchan):
+            sel = all_tags[c][(all_tags[c]["offset"] >= k) & (all_tags[c]["offset"] < k + L)]
+            tg[c, : len(sel)] = sel
+            cnt[c] = len(sel)
+            new.append(sel)
+        r = e.step(chunk, tg, cnt, want_aux=True)
+        assert r["status"] == 0
+        for c in range(nchan):
+            ot = np.zeros(len(new[c]), dtype=orc.TAG_DTYPE)
+            ot["offset"], ot["value"], ot["key"] = new[c]["offset"], new[c]["value"], new[c]["key"]
+            out, o2, o3, cons = o[c].step(chunk[c], ot, want_aux=True)
+            p = r["produced"][c]
+            assert p == len(out) and r["consumed"][c] == cons
+            assert np.array_equal(r["syms"][c, :p].view(np.uint32), out.view(np.uint32))
+            if p:
+                assert np.array_equal(r["err"][c, :p].view(np.uint32), o2.view(np.uint32))
+                assert np.array_equal(r["mu"][c, :p].view(np.uint32), o3.view(np.uint32))
+            assert np.array_equal(r["bits"][c, :p], bt[c].process(out))
+            nsym += p
+        k += L
+    assert nsym > nchan * total / sps * osps * 0.95
+
+
+def test_emul_msk_general_work_gr_mode():
+    # the GNU Radio path: explicit ninput/noutput, caller re-presents unconsumed items
+    rng = np.random.default_rng(3)
+    x, _ = _signal(77, 30000)
+    buf = np.concatenate([np.zeros(1, np.complex64), x])
+    tags = _rand_tags(rng, 30000, 40)
+    ot = np.zeros(len(tags), dtype=orc.TAG_DTYPE)
+    ot["offset"], ot["value"], ot["key"] = tags["offset"], tags["value"], tags["key"]
+    e = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=1)
+    o = orc.Msk(4.0, 0.04, 0.01, 1)
+    read = 0
+    for nout in [512, 100, 1, 700, 2048, 33]:
+        ninput = o.forecast(nout) + int(rng.integers(0, 40))
+        if read + ninput + 1 > x.size:
+            break
+        a = e.general_work(nout, ninput, buf, 1 + read, tags, read)
+        b = o.general_work(nout, ninput, buf, 1 + read, ot, read, want_aux=True)
+        assert a[4] == b[3] and len(a[0]) == len(b[0]) and a[5] == b[4] == 0
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+        read += a[4]
+    assert read > 10000
