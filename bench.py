@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- complex MS/s through the demod hot path on MI355X, with the
+corr_est_cc kernel's HBM-roofline fraction and a CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the chain over one batch: CHANNELS_PER_GPU channels x
+SAMPLES complex samples per GPU, already resident in HBM.  Weak scaling: every
+rank owns its own channels, no data-path collective (channels are independent,
+SURVEY.md section 8e); torch.distributed (RCCL) is used only for the timing
+barrier and the max-over-ranks reduction.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 4096
+batched channels, 65536 samples each, sps = 4, stock template (N = 896, SURVEY
+D4).  `--chain core` = corr_est -> msk_timing (+NRZI bit tail), the chain the
+metric names; `--chain stock` = freq_sync -> agc -> corr_est -> msk_timing, the
+connect order of python/ais_demod.py:56.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "gr-ais_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CORR_BYTES_PER_SAMPLE = 16  # 8 B read + 8 B delayed pass-through write
+
+
+def make_template(family, sps):
+    from ais_amd import gmsk_mod, modulate_vector_bc, synth
+
+    if family == "S":
+        return modulate_vector_bc(gmsk_mod(sps, 0.4), [1, 1, 0, 0] * 7, [1])
+    lv = [1 if b else -1 for b in synth.sync_bits("P")]
+    return synth.gmsk_waveform(np.array(lv, float), sps)[: len(lv) * sps].astype(np.complex64)
+
+
+def make_input(nchan, T, family, sps, device, rank, stock):
+    """Synthetic IQ resident on the device: `nuniq` CPU-generated channels
+    (seeded) replicated with a per-channel carrier phase, plus
+    per-sample device-generated noise so that no two channels are equal."""
+    import torch
+    from ais_amd import synth
+
+    nuniq = 32
+    amp = 0.3 if stock else 1.0
+    cfo = 500.0 if stock else (15.0 if family == "P" else 3.0)
+    base = np.stack([synth.make_channel(synth.SEED0 + 1000 * rank + c, T, family, sps, amp=amp, cfo_max=cfo,
+                                        noise=False)[0] for c in range(nuniq)])
+    g = torch.Generator(device=device)
+    g.manual_seed(synth.SEED0 + rank)
+    b = torch.as_tensor(base).to(device)
+    reps = (nchan + nuniq - 1) // nuniq
+    x = b.repeat(reps, 1)[:nchan].contiguous()
+    ph = torch.rand(nchan, generator=g, device=device) * (2 * np.pi)
+    x *= torch.polar(torch.ones_like(ph), ph).to(torch.complex64).view(-1, 1)
+    sigma = amp * np.sqrt(sps / (10 ** (20.0 / 10.0)) / 2.0)  # Eb/N0 = 20 dB
+    noise = torch.randn((nchan, T, 2), generator=g, device=device, dtype=torch.float32) * sigma
+    x += torch.view_as_complex(noise)
+    return x
+
+
+def cpu_baseline(chain, family, sps, T, nch=32):
+    """The CPU oracle (a plain-C port of the reference's algorithm, single
+    thread) on a bounded sample of the same workload."""
+    import oracle_py as orc
+    from ais_amd import synth
+
+    tmpl = make_template(family, sps)
+    stock = chain == "stock"
+    xs = [synth.make_channel(synth.SEED0 + c, T, family, sps, amp=0.3 if stock else 1.0,
+                             cfo_max=500.0 if stock else 15.0)[0] for c in range(nch)]
+    dem = [orc.Demod(sps, tmpl, stages=3 if stock else 0) for _ in range(nch)]
+    dem[0].step(xs[0][:4096])  # warm the FFT plan cache
+    dem[0] = orc.Demod(sps, tmpl, stages=3 if stock else 0)
+    t0 = time.perf_counter()
+    for c in range(nch):
+        dem[c].step(xs[c])
+    dt = time.perf_counter() - t0
+    return dict(value=nch * T / dt / 1e6, unit="complex MS/s", cores=1, kind="port",
+                sample="%d channels x %d samples, chain=%s, oracle/ais_oracle.c single thread" % (nch, T, chain))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels-per-gpu", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=65536)
+    ap.add_argument("--template", choices=["S", "P"], default="S", help="S: stock 896-sample template; P: 112-sample preamble")
+    ap.add_argument("--chain", choices=["core", "stock", "corr"], default="core")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libaisx has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import ais_amd
+
+    sps, T, nchan = 4, args.samples, args.channels_per_gpu
+    tmpl = make_template(args.template, sps)
+    stock = args.chain == "stock"
+    x = make_input(nchan, T, args.template, sps, device, rank, stock)
+
+    opts = dict(samples_per_symbol=sps, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
+    dem = ais_amd.ais_demod(opts, nchan=nchan, max_items=T, stages="stock" if stock else "core",
+                            preamble_symbols=tmpl)
+    corr = dem.preamble_detect
+    corr.set_profiling(True)
+    # preallocated inter-stage buffers
+    y_corr = torch.empty((nchan, T), dtype=torch.complex64, device=device)
+    cap = dem.clockrec.out_capacity
+    outs = dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
+                produced=torch.empty(nchan, dtype=torch.int32, device=device))
+
+    def step():
+        y = x
+        if stock:
+            y, _ = dem.freq_sync.work(y)
+            y = dem.agc.work(y)
+        o, _ = corr.work(y, out=y_corr if y.shape[1] == T else None)
+        if args.chain != "corr":
+            dem.clockrec.work(o, tags_from=corr, outs=outs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0:
+            pass
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    barrier()
+    # per-launch duration of the dominant kernel (hipEvents on the launch stream);
+    # sampled outside the timed region so the event waits do not serialise it
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+        kern_ms.append(corr.last_kernel_ms())
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        total_samples = float(nchan) * T * world * args.steps
+        kms = float(np.mean(kern_ms))
+        achieved = CORR_BYTES_PER_SAMPLE * float(nchan) * T / (kms * 1e-3) / 1e9
+        st = dem.clockrec.last_status() if args.chain != "corr" else 0
+        tags = corr.tags(allow_overflow=True)
+        line = {
+            "metric": "complex MS/s through corr_est->msk_timing chain; corr_est %HBM roofline",
+            "value": total_samples / el / 1e6,
+            "unit": "complex MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d batched channels/GPU x %d complex samples/step, sps=4, template N=%d (%s), chain=%s"
+                % (nchan, T, tmpl.size, "stock ais_demod.py" if args.template == "S" else "28-symbol preamble",
+                   {"core": "corr_est->msk_timing+NRZI tail", "stock": "freq_sync->agc->corr_est->msk_timing+NRZI tail",
+                    "corr": "corr_est only"}[args.chain]),
+                "channels_per_gpu": nchan,
+                "samples_per_step": T,
+                "template_len": int(tmpl.size),
+                "chain": args.chain,
+                "parallelism": "channel-sharded x%d, no collective" % world,
+            },
+            "roofline": {
+                "kernel": "k_corr_main",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kms,
+                "algorithmic_bytes_per_launch": CORR_BYTES_PER_SAMPLE * float(nchan) * T,
+            },
+            "detections_last_step": int((tags["key"] == 2).sum()),
+            "msk_status": int(st),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.chain if args.chain != "corr" else "core", args.template, sps, T)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

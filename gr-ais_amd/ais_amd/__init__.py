@@ -1,0 +1,21 @@
+"""ais_amd -- MI355X-native drop-in for the gr-ais per-sample demod hot path.
+
+Mirrors the reference's Python-visible interface for this path
+(python/__init__.py:29-32 + swig/ais_swig.i:16-23): `corr_est_cc`, `freqest`,
+`msk_timing_recovery_cc`, the hier blocks `square_and_fft_sync_cc`
+(python/gmsk_sync.py) and `ais_demod` (python/ais_demod.py), and the template
+helper `modulate_vector_bc`.  All signal processing runs in libaisx.so (hand
+written HIP for gfx950, C ABI in include/aisx.h).
+"""
+from .modulate import gmsk_mod, modulate_vector_bc  # noqa: F401
+
+
+def __getattr__(name):
+    # blocks need torch + libaisx.so; load them on first use so that the host-only
+    # helpers (synth, modulate) stay importable anywhere
+    if name in ("corr_est_cc", "msk_timing_recovery_cc", "square_and_fft_sync_cc", "freqest", "feedforward_agc_cc",
+                "ais_demod", "TAG_DTYPE"):
+        from . import blocks
+
+        return getattr(blocks, name)
+    raise AttributeError(name)

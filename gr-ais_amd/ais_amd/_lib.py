@@ -1,0 +1,117 @@
+"""ctypes loader for libaisx.so (the HIP kernels + C ABI, include/aisx.h).
+
+There is deliberately no fallback: if the shared library is missing the import
+fails, and if no MI355X is visible every block constructor raises.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libaisx.so")
+
+AISX_OK = 0
+AISX_ERR_INVALID = -1
+AISX_ERR_OUT_OF_RANGE = -2
+AISX_ERR_HIP = -3
+AISX_ERR_NO_DEVICE = -4
+AISX_ERR_OVERFLOW = -5
+AISX_ERR_RUNTIME = -6
+
+KEY_CORR_START, KEY_PHASE_EST, KEY_TIME_EST, KEY_CORR_EST, KEY_PORT1 = 0, 1, 2, 3, 0x100
+KEY_NAMES = {0: "corr_start", 1: "phase_est", 2: "time_est", 3: "corr_est"}
+
+
+class AisxError(RuntimeError):
+    pass
+
+
+class NoDeviceError(AisxError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libaisx.so not built (%s): run `make -C gr-ais_amd` or __graft_entry__.build(); "
+            "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, f32, f64, u64, lng = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_uint64, C.c_long
+    pvp, pi32 = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
+
+    def sig(name, res, args):
+        f = getattr(L, name, None)
+        if f is None:  # TEMP (round-1 bring-up): freqsync/agc entry points land next
+            return
+        f.restype = res
+        f.argtypes = args
+
+    sig("aisx_version", i32, [])
+    sig("aisx_last_error", C.c_char_p, [])
+    sig("aisx_device_count", i32, [pi32])
+    sig("aisx_set_device", i32, [i32])
+    sig("aisx_corr_create", i32, [pvp, vp, i32, f32, u32, f32, i32, i32, i32])
+    sig("aisx_corr_destroy", i32, [vp])
+    sig("aisx_corr_symbols", i32, [vp, vp, i32])
+    sig("aisx_corr_set_symbols", i32, [vp, vp, i32])
+    sig("aisx_corr_history", i32, [vp])
+    sig("aisx_corr_output_multiple", i32, [vp])
+    sig("aisx_corr_max_noutput_items", i32, [vp])
+    sig("aisx_corr_threshold", f32, [vp])
+    sig("aisx_corr_mark_delay", u32, [vp])
+    sig("aisx_corr_nitems_written", u64, [vp])
+    sig("aisx_corr_reset", i32, [vp])
+    sig("aisx_corr_process", i32, [vp, vp, lng, vp, lng, vp, lng, i32, vp])
+    sig("aisx_corr_set_profiling", i32, [vp, i32])
+    sig("aisx_corr_last_kernel_ms", i32, [vp, C.POINTER(C.c_float)])
+    sig("aisx_corr_tags_device", i32, [vp, pvp, pvp, pi32])
+    sig("aisx_corr_read_tags", i32, [vp, vp, i32, pi32, vp])
+    sig("aisx_corr_work_host", i32, [vp, vp, vp, vp, i32, u64, vp, i32, pi32])
+    sig("aisx_msk_create", i32, [pvp, f32, f32, f32, i32, i32, i32])
+    sig("aisx_msk_destroy", i32, [vp])
+    sig("aisx_msk_set_gain", i32, [vp, f32])
+    sig("aisx_msk_get_gain", f32, [vp])
+    sig("aisx_msk_set_limit", i32, [vp, f32])
+    sig("aisx_msk_get_limit", f32, [vp])
+    sig("aisx_msk_set_sps", i32, [vp, f32])
+    sig("aisx_msk_get_sps", f32, [vp])
+    sig("aisx_msk_forecast", i32, [vp, i32])
+    sig("aisx_msk_out_capacity", i32, [vp])
+    sig("aisx_msk_reset", i32, [vp])
+    sig("aisx_msk_process_stream", i32, [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp])
+    sig("aisx_msk_last_status", i32, [vp, pi32, vp])
+    sig("aisx_msk_general_work_host", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, i32, pi32, pi32])
+    sig("aisx_freqsync_create", i32, [pvp, f64, f64, i32, i32, i32])
+    sig("aisx_freqsync_destroy", i32, [vp])
+    sig("aisx_freqsync_reset", i32, [vp])
+    sig("aisx_freqsync_process", i32, [vp, vp, lng, i32, vp, lng, vp, lng, pi32, vp])
+    sig("aisx_freqest_work", i32, [vp, vp, lng, vp, lng, i32, vp])
+    sig("aisx_agc_create", i32, [pvp, i32, f32, i32, i32])
+    sig("aisx_agc_destroy", i32, [vp])
+    sig("aisx_agc_reset", i32, [vp])
+    sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    """Map a C-ABI status to the exception the reference's Python binding raises."""
+    if rc >= 0:
+        return rc
+    msg = lib().aisx_last_error().decode("utf-8", "replace")
+    if rc == AISX_ERR_OUT_OF_RANGE:
+        raise IndexError(msg or what)  # SWIG maps std::out_of_range to IndexError
+    if rc == AISX_ERR_NO_DEVICE:
+        raise NoDeviceError(msg or "no HIP device")
+    if rc == AISX_ERR_RUNTIME:
+        raise RuntimeError(msg or what)  # std::runtime_error
+    if rc == AISX_ERR_INVALID:
+        raise ValueError("%s: %s" % (what, msg))
+    if rc == AISX_ERR_OVERFLOW:
+        raise OverflowError("%s: %s" % (what, msg))
+    raise AisxError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,364 @@
+"""Host-side mirror of the reference's block interface for the demod hot path.
+
+Same names, constructor arguments and error behaviour as the reference's Python
+bindings (swig/ais_swig.i:16-26 exposes ais.corr_est_cc, ais.freqest,
+ais.msk_timing_recovery_cc; python/gmsk_sync.py and python/ais_demod.py are
+Python hier blocks), with one addition: `nchan`, the number of independent
+channels batched through one call.  All arithmetic happens in libaisx.so (HIP,
+gfx950); torch is used only for device memory and streams.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+TAG_DTYPE = np.dtype([("offset", "<u8"), ("value", "<f8"), ("key", "<i4"), ("chan", "<i4")])
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _dev_c64(x, nchan):
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.complex64))
+    if x.dtype != torch.complex64:
+        raise TypeError("expected complex64 (gr_complex) items, got %s" % x.dtype)
+    if not x.is_cuda:
+        x = x.cuda()
+    x = x.reshape(nchan, -1)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    return x
+
+
+class corr_est_cc:
+    """ais.corr_est_cc(symbols, sps, mark_delay, threshold=0.9)
+    (include/ais/corr_est_cc.h:102-106, lib/corr_est_cc_impl.cc)."""
+
+    def __init__(self, symbols, sps, mark_delay, threshold=0.9, nchan=1, max_items=65536, max_tags_per_chan=None):
+        L = _lib.lib()
+        s = np.ascontiguousarray(symbols, dtype=np.complex64)
+        self.nchan, self.max_items = int(nchan), int(max_items)
+        self._cap = int(max_tags_per_chan) if max_tags_per_chan else max(64, 4 * (self.max_items // 256))
+        h = C.c_void_p()
+        check(L.aisx_corr_create(C.byref(h), s.ctypes.data_as(C.c_void_p), s.size, float(sps), int(mark_delay),
+                                 float(threshold), self.nchan, self.max_items, self._cap), "corr_est_cc")
+        self._h = h
+        self._N = s.size
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().aisx_corr_destroy(h)
+            self._h = None
+
+    # -- reference API ---------------------------------------------------
+    def symbols(self):
+        out = np.zeros(self._N, dtype=np.complex64)
+        check(_lib.lib().aisx_corr_symbols(self._h, out.ctypes.data_as(C.c_void_p), out.size), "symbols")
+        return out
+
+    def set_symbols(self, symbols):
+        s = np.ascontiguousarray(symbols, dtype=np.complex64)
+        check(_lib.lib().aisx_corr_set_symbols(self._h, s.ctypes.data_as(C.c_void_p), s.size), "set_symbols")
+
+    def history(self):
+        return _lib.lib().aisx_corr_history(self._h)
+
+    def output_multiple(self):
+        return _lib.lib().aisx_corr_output_multiple(self._h)
+
+    def max_noutput_items(self):
+        return _lib.lib().aisx_corr_max_noutput_items(self._h)
+
+    def threshold(self):
+        return _lib.lib().aisx_corr_threshold(self._h)
+
+    def mark_delay(self):
+        return _lib.lib().aisx_corr_mark_delay(self._h)
+
+    def nitems_written(self, port=0):
+        return _lib.lib().aisx_corr_nitems_written(self._h)
+
+    def reset(self):
+        check(_lib.lib().aisx_corr_reset(self._h), "reset")
+
+    # -- batched device path ---------------------------------------------
+    def work(self, x, want_corr=False, out=None, stream=None):
+        """One work() call on x[nchan][n] new items (device tensor).  Returns
+        (out, corr|None); the tags of the call are read with tags()."""
+        x = _dev_c64(x, self.nchan)
+        n = x.shape[1]
+        if out is None:
+            out = torch.empty_like(x)
+        corr = torch.empty_like(x) if want_corr else None
+        check(_lib.lib().aisx_corr_process(self._h, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                                           corr.data_ptr() if want_corr else None, corr.stride(0) if want_corr else 0,
+                                           n, _stream_ptr(stream)), "corr_est_cc.work")
+        return out, corr
+
+    def set_profiling(self, on=True):
+        check(_lib.lib().aisx_corr_set_profiling(self._h, 1 if on else 0), "set_profiling")
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        check(_lib.lib().aisx_corr_last_kernel_ms(self._h, C.byref(ms)), "last_kernel_ms")
+        return ms.value
+
+    def tags_device(self):
+        t, c, cap = C.c_void_p(), C.c_void_p(), C.c_int()
+        check(_lib.lib().aisx_corr_tags_device(self._h, C.byref(t), C.byref(c), C.byref(cap)), "tags_device")
+        return t, c, cap.value
+
+    def tags(self, stream=None, allow_overflow=False):
+        """Host copy of the last call's tags: structured array (offset,value,key,chan)."""
+        cap = self.nchan * self._cap
+        buf = np.zeros(cap, dtype=TAG_DTYPE)
+        nt = C.c_int(0)
+        rc = _lib.lib().aisx_corr_read_tags(self._h, buf.ctypes.data_as(C.c_void_p), cap, C.byref(nt), _stream_ptr(stream))
+        if not (allow_overflow and rc == _lib.AISX_ERR_OVERFLOW):
+            check(rc, "corr_est_cc.tags")
+        return buf[: nt.value].copy()
+
+    # -- GNU Radio path (host pointers, one channel) ----------------------
+    def work_host(self, in_with_history, noutput_items, nitems_written, want_corr=False, tag_cap=4096):
+        a = np.ascontiguousarray(in_with_history, dtype=np.complex64)
+        assert a.size >= noutput_items + self._N
+        out = np.zeros(noutput_items, dtype=np.complex64)
+        corr = np.zeros(noutput_items, dtype=np.complex64) if want_corr else None
+        tags = np.zeros(tag_cap, dtype=TAG_DTYPE)
+        nt = C.c_int(0)
+        check(_lib.lib().aisx_corr_work_host(self._h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                             corr.ctypes.data_as(C.c_void_p) if want_corr else None, noutput_items,
+                                             nitems_written, tags.ctypes.data_as(C.c_void_p), tag_cap, C.byref(nt)),
+              "corr_est_cc.work_host")
+        return out, corr, tags[: nt.value].copy()
+
+
+class msk_timing_recovery_cc:
+    """ais.msk_timing_recovery_cc(sps, gain, limit, osps)
+    (include/ais/msk_timing_recovery_cc.h:60-69, lib/msk_timing_recovery_cc_impl.cc)."""
+
+    def __init__(self, sps, gain, limit, osps=1, nchan=1, max_items=65536):
+        L = _lib.lib()
+        self.nchan, self.max_items = int(nchan), int(max_items)
+        h = C.c_void_p()
+        check(L.aisx_msk_create(C.byref(h), float(sps), float(gain), float(limit), int(osps), self.nchan,
+                                self.max_items), "msk_timing_recovery_cc")
+        self._h = h
+        self.out_capacity = L.aisx_msk_out_capacity(h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().aisx_msk_destroy(h)
+            self._h = None
+
+    def set_gain(self, gain):
+        check(_lib.lib().aisx_msk_set_gain(self._h, float(gain)), "set_gain")
+
+    def get_gain(self):
+        return _lib.lib().aisx_msk_get_gain(self._h)
+
+    def set_limit(self, limit):
+        check(_lib.lib().aisx_msk_set_limit(self._h, float(limit)), "set_limit")
+
+    def get_limit(self):
+        return _lib.lib().aisx_msk_get_limit(self._h)
+
+    def set_sps(self, sps):
+        check(_lib.lib().aisx_msk_set_sps(self._h, float(sps)), "set_sps")
+
+    def get_sps(self):
+        return _lib.lib().aisx_msk_get_sps(self._h)
+
+    def forecast(self, noutput_items):
+        return _lib.lib().aisx_msk_forecast(self._h, int(noutput_items))
+
+    def reset(self):
+        check(_lib.lib().aisx_msk_reset(self._h), "reset")
+
+    def work(self, x, tags_from=None, want_syms=True, want_aux=False, want_bits=True, stream=None, outs=None):
+        """One stream step on x[nchan][n] new items.  `tags_from` = the
+        corr_est_cc block whose last call produced the time_est tags (or None).
+        Returns dict(syms, err, mu, bits, produced) of device tensors."""
+        x = _dev_c64(x, self.nchan)
+        n = x.shape[1]
+        cap = self.out_capacity
+        dev = x.device
+        o = outs or {}
+        syms = o.get("syms") if "syms" in o else (torch.empty((self.nchan, cap), dtype=torch.complex64, device=dev) if want_syms else None)
+        err = o.get("err") if "err" in o else (torch.empty((self.nchan, cap), dtype=torch.float32, device=dev) if want_aux else None)
+        mu = o.get("mu") if "mu" in o else (torch.empty((self.nchan, cap), dtype=torch.float32, device=dev) if want_aux else None)
+        bits = o.get("bits") if "bits" in o else (torch.empty((self.nchan, cap), dtype=torch.uint8, device=dev) if want_bits else None)
+        prod = o.get("produced") if "produced" in o else torch.empty(self.nchan, dtype=torch.int32, device=dev)
+        if tags_from is not None:
+            tptr, cptr, tcap = tags_from.tags_device()
+        else:
+            tptr, cptr, tcap = None, None, 0
+        check(_lib.lib().aisx_msk_process_stream(
+            self._h, x.data_ptr(), x.stride(0), n, tptr, cptr, tcap,
+            syms.data_ptr() if syms is not None else None, err.data_ptr() if err is not None else None,
+            mu.data_ptr() if mu is not None else None, bits.data_ptr() if bits is not None else None, cap,
+            prod.data_ptr(), _stream_ptr(stream)), "msk_timing_recovery_cc.work")
+        return dict(syms=syms, err=err, mu=mu, bits=bits, produced=prod)
+
+    def last_status(self, stream=None):
+        st = C.c_int(0)
+        check(_lib.lib().aisx_msk_last_status(self._h, C.byref(st), _stream_ptr(stream)), "last_status")
+        return st.value
+
+    def general_work_host(self, noutput_items, ninput_items, buf, in_off, tags, nitems_read, in_has_lookahead=True):
+        """GNU Radio path: in = &buf[in_off]; tags: structured array (TAG_DTYPE)."""
+        buf = np.ascontiguousarray(buf, dtype=np.complex64)
+        out = np.zeros(max(noutput_items, 1), np.complex64)
+        err = np.zeros(max(noutput_items, 1), np.float32)
+        mu = np.zeros(max(noutput_items, 1), np.float32)
+        bits = np.zeros(max(noutput_items, 1), np.uint8)
+        tags = np.ascontiguousarray(tags, dtype=TAG_DTYPE)
+        cons, prod = C.c_int(0), C.c_int(0)
+        inp = C.c_void_p(buf.ctypes.data + 8 * in_off)
+        check(_lib.lib().aisx_msk_general_work_host(
+            self._h, noutput_items, ninput_items, inp, out.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p),
+            mu.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p), tags.ctypes.data_as(C.c_void_p), tags.size,
+            nitems_read, 1 if in_has_lookahead else 0, C.byref(cons), C.byref(prod)), "general_work_host")
+        p = prod.value
+        return out[:p], err[:p], mu[:p], bits[:p], cons.value
+
+
+class square_and_fft_sync_cc:
+    """ais.square_and_fft_sync_cc(samplerate, bits_per_sec, fftlen) (python/gmsk_sync.py:14-37),
+    which owns ais.freqest(int(samplerate), int(bits_per_sec), fftlen) (lib/freqest_impl.cc)."""
+
+    def __init__(self, samplerate, bits_per_sec, fftlen, nchan=1, max_items=65536):
+        self.nchan, self.fftlen, self.max_items = int(nchan), int(fftlen), int(max_items)
+        h = C.c_void_p()
+        check(_lib.lib().aisx_freqsync_create(C.byref(h), float(samplerate), float(bits_per_sec), self.fftlen,
+                                              self.nchan, self.max_items), "square_and_fft_sync_cc")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().aisx_freqsync_destroy(h)
+            self._h = None
+
+    def reset(self):
+        check(_lib.lib().aisx_freqsync_reset(self._h), "reset")
+
+    def work(self, x, want_fhat=False, stream=None):
+        x = _dev_c64(x, self.nchan)
+        n = x.shape[1]
+        cap = n + self.fftlen
+        out = torch.empty((self.nchan, cap), dtype=torch.complex64, device=x.device)
+        nv = cap // self.fftlen + 1
+        fh = torch.empty((self.nchan, nv), dtype=torch.float32, device=x.device) if want_fhat else None
+        nout = C.c_int(0)
+        check(_lib.lib().aisx_freqsync_process(self._h, x.data_ptr(), x.stride(0), n, out.data_ptr(), out.stride(0),
+                                               fh.data_ptr() if want_fhat else None, nv if want_fhat else 0,
+                                               C.byref(nout), _stream_ptr(stream)), "square_and_fft_sync_cc.work")
+        m = nout.value
+        return out[:, :m], (fh[:, : m // self.fftlen] if want_fhat else None)
+
+
+class freqest:
+    """ais.freqest(sample_rate, data_rate, fftlen) (include/ais/freqest.h:49): consumes
+    fft-shifted spectra, one float estimate per vector."""
+
+    def __init__(self, sample_rate, data_rate, fftlen, nchan=1):
+        self._fs = square_and_fft_sync_cc(float(sample_rate), float(data_rate), fftlen, nchan=nchan, max_items=fftlen)
+        self.nchan, self.fftlen = nchan, fftlen
+
+    def work(self, vecs, stream=None):
+        v = _dev_c64(vecs, self.nchan)
+        nvec = v.shape[1] // self.fftlen
+        out = torch.empty((self.nchan, max(nvec, 1)), dtype=torch.float32, device=v.device)
+        check(_lib.lib().aisx_freqest_work(self._fs._h, v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0), nvec,
+                                           _stream_ptr(stream)), "freqest.work")
+        return out[:, :nvec]
+
+
+class feedforward_agc_cc:
+    """analog.feedforward_agc_cc(nsamples, reference) as used at python/ais_demod.py:35."""
+
+    def __init__(self, nsamples, reference, nchan=1, max_items=65536):
+        self.nchan = int(nchan)
+        h = C.c_void_p()
+        check(_lib.lib().aisx_agc_create(C.byref(h), int(nsamples), float(reference), self.nchan, int(max_items)),
+              "feedforward_agc_cc")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().aisx_agc_destroy(h)
+            self._h = None
+
+    def reset(self):
+        check(_lib.lib().aisx_agc_reset(self._h), "reset")
+
+    def work(self, x, out=None, stream=None):
+        x = _dev_c64(x, self.nchan)
+        if out is None:
+            out = torch.empty_like(x)
+        check(_lib.lib().aisx_agc_process(self._h, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                                          x.shape[1], _stream_ptr(stream)), "feedforward_agc_cc.work")
+        return out
+
+
+class ais_demod:
+    """ais.ais_demod(options) (python/ais_demod.py:21-56): the demod chain
+    freq_sync -> agc -> corr_est (preamble_detect) -> msk timing recovery (clockrec)
+    -> quadrature demod -> slicer -> diff decoder -> invert (:56), with the same
+    option keys and constants, for `nchan` channels at once.
+
+    `stages` selects the upstream conditioning: 'stock' (freq_sync + agc, the
+    reference's connect order) or 'core' (corr_est -> msk only, the chain
+    BASELINE.json's metric names)."""
+
+    def __init__(self, options, nchan=1, max_items=65536, stages="stock", preamble_symbols=None):
+        from .modulate import gmsk_mod, modulate_vector_bc
+
+        self._samples_per_symbol = options["samples_per_symbol"]
+        self._bits_per_sec = options["bits_per_sec"]
+        self._samplerate = self._samples_per_symbol * self._bits_per_sec
+        self._clockrec_gain = options["clockrec_gain"]
+        self._omega_relative_limit = options["omega_relative_limit"]
+        self.fftlen = options["fftlen"]
+        self.nchan = nchan
+        self.stages = stages
+        if stages == "stock":
+            self.freq_sync = square_and_fft_sync_cc(self._samplerate, self._bits_per_sec, self.fftlen, nchan=nchan,
+                                                    max_items=max_items)
+            self.agc = feedforward_agc_cc(512, 2, nchan=nchan, max_items=max_items + self.fftlen)
+        else:
+            self.freq_sync = self.agc = None
+        if preamble_symbols is None:
+            self.preamble = [1, 1, 0, 0] * 7
+            self.mod = gmsk_mod(int(self._samples_per_symbol), 0.4)
+            self.mod_vector = modulate_vector_bc(self.mod.to_basic_block(), self.preamble, [1])
+        else:
+            self.mod_vector = np.asarray(preamble_symbols, dtype=np.complex64)
+        self.preamble_detect = corr_est_cc(self.mod_vector, self._samples_per_symbol, 1, 0.9, nchan=nchan,
+                                           max_items=max_items + self.fftlen)
+        self.clockrec = msk_timing_recovery_cc(self._samples_per_symbol, self._clockrec_gain,
+                                               self._omega_relative_limit, 1, nchan=nchan,
+                                               max_items=max_items + self.fftlen)
+
+    def work(self, x, want_syms=False, stream=None):
+        """One chain step on x[nchan][n].  Returns dict(bits, produced[, syms])."""
+        y = _dev_c64(x, self.nchan)
+        if self.stages == "stock":
+            y, _ = self.freq_sync.work(y, stream=stream)
+            if y.shape[1] == 0:
+                return dict(bits=None, produced=None, syms=None)
+            y = self.agc.work(y, stream=stream)
+        y, _ = self.preamble_detect.work(y, stream=stream)
+        r = self.clockrec.work(y, tags_from=self.preamble_detect, want_syms=want_syms, stream=stream)
+        return r

@@ -88,6 +88,8 @@ struct aisx_corr {
     float* d_atan = nullptr;
     uint64_t written = 0;
     int last_emit_port1 = 0;
+    int prof = 0; // aisx_corr_set_profiling
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // GNU Radio path staging
     cf *d_st_in = nullptr, *d_st_out = nullptr, *d_st_corr = nullptr;
     int st_cap = 0;
@@ -190,6 +192,10 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
+    if (h->ev0)
+        (void)hipEventDestroy(h->ev0);
+    if (h->ev1)
+        (void)hipEventDestroy(h->ev1);
     delete h;
     return AISX_OK;
 }
@@ -268,8 +274,12 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     p.nseg = nseg;
     p.tiles_per_seg = tps;
     p.thresh = h->thresh;
+    if (h->prof)
+        AISX_HIPCHK(hipEventRecord(h->ev0, st));
     hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
     AISX_HIPCHK(hipGetLastError());
+    if (h->prof)
+        AISX_HIPCHK(hipEventRecord(h->ev1, st));
 
     ResolveParams r;
     r.abits = h->d_abits;
@@ -296,6 +306,27 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     h->hist_cur ^= 1;
     h->written += (uint64_t)n;
     h->last_emit_port1 = r.emit_port1;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_set_profiling(aisx_corr* h, int on)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (on && !h->ev0) {
+        AISX_HIPCHK(hipEventCreate(&h->ev0));
+        AISX_HIPCHK(hipEventCreate(&h->ev1));
+    }
+    h->prof = on ? 1 : 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_last_kernel_ms(aisx_corr* h, float* ms)
+{
+    if (!h || !ms || !h->ev0)
+        return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipEventSynchronize(h->ev1));
+    AISX_HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return AISX_OK;
 }
 

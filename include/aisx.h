@@ -100,6 +100,11 @@ int aisx_corr_reset(aisx_corr* h); /* zero history, nitems_written = 0 */
  * aisx_corr_read_tags). */
 int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
                       aisx_cf32* d_corr, long corr_stride, int n, void* stream);
+/* measurement hook: when on, aisx_corr_process brackets the main correlator
+ * kernel with hipEvents on the launch stream; aisx_corr_last_kernel_ms waits for
+ * the last bracket and returns its duration. */
+int aisx_corr_set_profiling(aisx_corr* h, int on);
+int aisx_corr_last_kernel_ms(aisx_corr* h, float* ms);
 /* device tag buffers of the last call: tags[c * cap + k], k < min(counts[c], cap) */
 int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int** d_counts, int* cap);
 /* copy the last call's tags to the host, channel by channel in emission order;
