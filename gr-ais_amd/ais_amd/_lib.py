@@ -45,9 +45,7 @@ def lib():
     pvp, pi32 = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
 
     def sig(name, res, args):
-        f = getattr(L, name, None)
-        if f is None:  # TEMP (round-1 bring-up): freqsync/agc entry points land next
-            return
+        f = getattr(L, name)  # AttributeError = libaisx.so is older than this binding: rebuild
         f.restype = res
         f.argtypes = args
 

@@ -123,7 +123,7 @@ AISX_HD float fast_atan2f_tab(float y, float x, const float* tab)
 }
 
 // Deterministic sin/cos for the NCO: plain IEEE double + and * only, so the
-// device result is bit-identical to the oracle's orc_det_sincos.
+// device result is bit-identical to the CPU checker's restatement of it.
 AISX_HD void det_sincos(float phase, float* s, float* c)
 {
     const double TWO_OVER_PI = 0.63661977236758134308;

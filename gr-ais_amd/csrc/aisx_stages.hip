@@ -1,0 +1,285 @@
+// aisx_stages.hip -- C ABI for the stages either side of the correlator in the
+// reference's chain (python/ais_demod.py:56): square_and_fft_sync_cc / freqest
+// (python/gmsk_sync.py, lib/freqest_impl.cc) and analog.feedforward_agc_cc.
+#include <math.h>
+
+#include <vector>
+
+#include "aisx_devctx.h"
+#include "aisx_host.h"
+#include "k_agc.h"
+#include "k_freqsync.h"
+
+using namespace aisx;
+
+__global__ __launch_bounds__(FS_T) void k_fs_est(FsEstParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    fs_est_body(cx, p);
+}
+__global__ __launch_bounds__(FSM_T) void k_fs_mix(FsMixParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    fs_mix_body(cx, p);
+}
+__global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
+{
+    DevCtx cx{ nullptr };
+    fs_freqest_body(cx, p);
+}
+__global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    agc_body(cx, p);
+}
+
+// ---------------------------------------------------------------------------
+struct aisx_freqsync {
+    int nchan = 0, fftlen = 0, max_items = 0, offset = 0, max_vec = 0;
+    float binsize = 0, sensitivity = 0;
+    cf* d_pend[2] = { nullptr, nullptr };
+    int cur = 0, npend = 0;
+    cf* d_wtab = nullptr;
+    int* d_maxpos = nullptr;
+    float* d_phase = nullptr;
+};
+
+extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, double bits_per_sec, int fftlen, int nchan,
+                                    int max_items)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (nchan < 1 || max_items < 1 || !(samplerate > 0) || !(bits_per_sec > 0)) {
+        set_err("aisx_freqsync_create: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if (fftlen != FS_F) {
+        set_err("aisx_freqsync_create: fftlen %d not supported (the gfx950 kernel implements fftlen = %d, the value "
+                "python/radio.py:60 uses)", fftlen, FS_F);
+        return AISX_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_freqsync* h = new aisx_freqsync();
+    h->nchan = nchan;
+    h->fftlen = fftlen;
+    h->max_items = max_items;
+    // ais.freqest(int(samplerate), int(bits_per_sec), fftlen)  (gmsk_sync.py:25; freqest_impl.cc:46-47)
+    const float sr = (float)(int)samplerate;
+    const int dr = (int)bits_per_sec;
+    h->offset = (int)(fftlen * ((float)dr / sr));
+    h->binsize = sr / (float)fftlen;
+    // frequency_modulator_fc(-1.0/(float(samplerate)/(2*pi)))  (gmsk_sync.py:27)
+    h->sensitivity = (float)(-1.0 / (samplerate / (2 * M_PI)));
+    h->max_vec = (max_items + fftlen) / fftlen + 1;
+    std::vector<cf> w(FS_F);
+    for (int k = 0; k < FS_F; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)FS_F;
+        w[k] = mk((float)cos(a), (float)sin(a));
+    }
+#define CK(e)               \
+    do {                    \
+        rc = (e);           \
+        if (rc != AISX_OK) { \
+            aisx_freqsync_destroy(h); \
+            return rc;      \
+        }                   \
+    } while (0)
+    CK(dev_alloc(&h->d_pend[0], (size_t)nchan * fftlen));
+    CK(dev_alloc(&h->d_pend[1], (size_t)nchan * fftlen));
+    CK(dev_alloc(&h->d_wtab, FS_F));
+    CK(dev_alloc(&h->d_maxpos, (size_t)nchan * h->max_vec));
+    CK(dev_alloc(&h->d_phase, nchan));
+#undef CK
+    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * FS_F, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("aisx_freqsync_create: table upload failed");
+        aisx_freqsync_destroy(h);
+        return AISX_ERR_HIP;
+    }
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
+{
+    if (!h)
+        return AISX_OK;
+    dev_free(h->d_pend[0]);
+    dev_free(h->d_pend[1]);
+    dev_free(h->d_wtab);
+    dev_free(h->d_maxpos);
+    dev_free(h->d_phase);
+    delete h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipMemset(h->d_phase, 0, sizeof(float) * h->nchan));
+    h->npend = 0;
+    h->cur = 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out,
+                                     long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream)
+{
+    if (!h || !d_in || !d_out || !n_out || n < 1 || n > h->max_items || in_stride < n) {
+        set_err("aisx_freqsync_process: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (h->npend + n) / h->fftlen;
+    if (out_stride < (long)nvec * h->fftlen || (d_fhat && fhat_stride < nvec)) {
+        set_err("aisx_freqsync_process: output stride too small for %d vectors", nvec);
+        return AISX_ERR_INVALID;
+    }
+    if (nvec > 0) {
+        FsEstParams e;
+        e.in = (const cf*)d_in;
+        e.in_stride = in_stride;
+        e.pend = h->d_pend[h->cur];
+        e.npend = h->npend;
+        e.wtab = h->d_wtab;
+        e.maxpos = h->d_maxpos;
+        e.maxpos_stride = h->max_vec;
+        e.nvec = nvec;
+        e.offset = h->offset;
+        hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+        AISX_HIPCHK(hipGetLastError());
+    }
+    FsMixParams m;
+    m.nchan = h->nchan;
+    m.in = (const cf*)d_in;
+    m.in_stride = in_stride;
+    m.pend_in = h->d_pend[h->cur];
+    m.pend_out = h->d_pend[h->cur ^ 1];
+    m.npend = h->npend;
+    m.n = n;
+    m.out = (cf*)d_out;
+    m.out_stride = out_stride;
+    m.maxpos = h->d_maxpos;
+    m.maxpos_stride = h->max_vec;
+    m.fhat = d_fhat;
+    m.fhat_stride = fhat_stride;
+    m.phase = h->d_phase;
+    m.nvec = nvec;
+    m.binsize = h->binsize;
+    m.sensitivity = h->sensitivity;
+    hipLaunchKernelGGL(k_fs_mix, dim3((h->nchan + 63) / 64), dim3(FSM_T), FSM_LDS_BYTES, st, m);
+    AISX_HIPCHK(hipGetLastError());
+    h->npend = h->npend + n - nvec * h->fftlen;
+    h->cur ^= 1;
+    *n_out = nvec * h->fftlen;
+    return AISX_OK;
+}
+
+extern "C" int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long vec_stride, float* d_out,
+                                 long out_stride, int nvec, void* stream)
+{
+    if (!h || !d_vecs || !d_out || nvec < 0 || vec_stride < (long)nvec * h->fftlen || out_stride < nvec)
+        return AISX_ERR_INVALID;
+    if (nvec == 0)
+        return AISX_OK;
+    FsFreqestParams p;
+    p.vecs = (const cf*)d_vecs;
+    p.vec_stride = vec_stride;
+    p.out = d_out;
+    p.out_stride = out_stride;
+    p.nvec = nvec;
+    p.fftlen = h->fftlen;
+    p.offset = h->offset;
+    p.binsize = h->binsize;
+    hipLaunchKernelGGL(k_fs_freqest, dim3(h->nchan), dim3(64), 0, (hipStream_t)stream, p);
+    AISX_HIPCHK(hipGetLastError());
+    return AISX_OK;
+}
+
+// ---------------------------------------------------------------------------
+struct aisx_agc {
+    int nchan = 0, W = 0, max_items = 0;
+    float reference = 0;
+    cf* d_hist[2] = { nullptr, nullptr };
+    int cur = 0;
+};
+
+extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, int nchan, int max_items)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (nsamples < 1) { // [GR] feedforward_agc_cc: std::invalid_argument
+        set_err("feedforward_agc_cc_impl: nsamples must be >= 1");
+        return AISX_ERR_INVALID;
+    }
+    if (nsamples > AGC_MAXW || nchan < 1 || max_items < 1) {
+        set_err("aisx_agc_create: bad argument (window %d, supported up to %d)", nsamples, AGC_MAXW);
+        return AISX_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_agc* h = new aisx_agc();
+    h->nchan = nchan;
+    h->W = nsamples;
+    h->max_items = max_items;
+    h->reference = reference;
+    if ((rc = dev_alloc(&h->d_hist[0], (size_t)nchan * nsamples)) != AISX_OK ||
+        (rc = dev_alloc(&h->d_hist[1], (size_t)nchan * nsamples)) != AISX_OK) {
+        aisx_agc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_destroy(aisx_agc* h)
+{
+    if (!h)
+        return AISX_OK;
+    dev_free(h->d_hist[0]);
+    dev_free(h->d_hist[1]);
+    delete h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_reset(aisx_agc* h)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipMemset(h->d_hist[0], 0, sizeof(cf) * (size_t)h->nchan * h->W));
+    AISX_HIPCHK(hipMemset(h->d_hist[1], 0, sizeof(cf) * (size_t)h->nchan * h->W));
+    h->cur = 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
+                                int n, void* stream)
+{
+    if (!h || !d_in || !d_out || n < 1 || n > h->max_items || in_stride < n || out_stride < n) {
+        set_err("aisx_agc_process: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    AgcParams p;
+    p.in = (const cf*)d_in;
+    p.in_stride = in_stride;
+    p.out = (cf*)d_out;
+    p.out_stride = out_stride;
+    p.hist_in = h->d_hist[h->cur];
+    p.hist_out = h->d_hist[h->cur ^ 1];
+    p.n = n;
+    p.W = h->W;
+    p.reference = h->reference;
+    p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
+    AISX_HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    return AISX_OK;
+}

@@ -1,0 +1,289 @@
+// k_freqsync.h -- square_and_fft_sync_cc (python/gmsk_sync.py:14-37) around
+// ais.freqest (lib/freqest_impl.cc:57-88).
+//
+//   fs_est_body : per (channel, 1024-vector): square (gmsk_sync.py:22,30-31),
+//                 1024-point forward FFT with fftshift (:23-24) done by ONE wave
+//                 (16 points per lane in VGPRs, 16 x 16 x 4, two LDS exchanges),
+//                 |X| = hypot in double as glibc does, then freqest's peak-pair
+//                 search (freqest_impl.cc:74-83: first strict maximum of
+//                 |X[j]| + |X[j+offset]|) with a wave arg-max.  Emits maxpos, or
+//                 -1 when no bin pair had positive energy (the reference then
+//                 re-uses the previous vector's maxpos, :68 vs :74).
+//   fs_mix_body : per 64 channels: resolves the stale-maxpos rule in sequence,
+//                 f = (float(maxpos) - fftlen/2) * binsize / 2 (:84), then
+//                 repeat -> frequency_modulator_fc -> multiply_cc
+//                 (gmsk_sync.py:26-28,33).  The NCO phase is GNU Radio's float
+//                 accumulator with its fmod wrap, a strict recurrence, so one
+//                 lane per channel walks it and the other waves do the
+//                 sin/cos + complex multiply with coalesced traffic.
+// Only fftlen = 1024 (the value the reference uses, python/radio.py:60) is
+// implemented by fs_est_body.
+#pragma once
+#include "aisx_common.h"
+#include "k_fft.h"
+
+namespace aisx {
+
+constexpr int FS_F = 1024;
+constexpr int FS_T = 256;             // 4 waves = 4 vectors per workgroup
+constexpr int FS_ROW = 68;            // LDS row pitch (complex) per k1 row
+constexpr int FS_WAVE_ELEMS = 16 * FS_ROW; // complex slots per wave
+constexpr int FS_LDS_BYTES = (4 * FS_WAVE_ELEMS + 64) * 8; // data per wave + tw2 table
+
+struct FsEstParams {
+    const cf* in; long in_stride;   // [nchan][n] new items
+    const cf* pend; int npend;      // [nchan][fftlen] pending partial vector (npend items valid)
+    const cf* wtab;                 // [1024] W_1024^k
+    int* maxpos; long maxpos_stride; // [nchan][nvec]
+    int nvec, offset;               // freqest d_offset
+};
+
+template <class Ctx>
+AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
+{
+    const int t = cx.tid();
+    const int wave = t >> 6, l = t & 63;
+    const int c = cx.by();
+    const int v = cx.bx() * 4 + wave;
+    cf* lds = (cf*)cx.lds();
+    cf* X = lds + wave * FS_WAVE_ELEMS;
+    cf* T2 = lds + 4 * FS_WAVE_ELEMS; // W_64^{k2*n3}, index k2*4+n3
+    if (t < 64)
+        T2[t] = p.wtab[(16 * (t >> 2) * (t & 3)) & (FS_F - 1)];
+    const bool live = v < p.nvec;
+    const cf* xin = p.in + (long)c * p.in_stride;
+    const cf* pend = p.pend + (long)c * FS_F;
+    cf x[16];
+    cf tw1[16];
+    tw1[0] = mk(1.f, 0.f);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++)
+        tw1[k1] = p.wtab[(k1 * l) & (FS_F - 1)];
+    // P1: lane l = column (n2,n3); x[n1] = s[l + 64 n1]^2
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++) {
+        cf s = mk(0.f, 0.f);
+        if (live) {
+            const long idx = (long)v * FS_F + l + 64 * n1; // index into pending ++ new
+            s = (idx < p.npend) ? pend[idx] : xin[idx - p.npend];
+        }
+        x[n1] = cmul_exact(s, s); // multiply_cc of the stream with itself
+    }
+    dft16<false>(x);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; k1++)
+        x[k1] = cmul_fma(x[k1], tw1[k1]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++)
+        X[k1 * FS_ROW + l] = x[k1];
+    cx.sync();
+    {
+        const int k1 = l >> 2, n3 = l & 3;
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++)
+            x[n2] = X[k1 * FS_ROW + n2 * 4 + n3];
+        dft16<false>(x);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; k2++)
+            x[k2] = cmul_fma(x[k2], T2[k2 * 4 + n3]);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++)
+            X[k1 * FS_ROW + k2 * 4 + n3] = x[k2];
+    }
+    cx.sync();
+    float a[16];
+    int kk[16];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const int q = l + 64 * h, k1 = q >> 4, k2 = q & 15;
+        cf y0 = X[k1 * FS_ROW + k2 * 4 + 0], y1 = X[k1 * FS_ROW + k2 * 4 + 1];
+        cf y2 = X[k1 * FS_ROW + k2 * 4 + 2], y3 = X[k1 * FS_ROW + k2 * 4 + 3];
+        dft4<false>(y0, y1, y2, y3);
+        const int kb = k1 + 16 * k2; // frequency index k = kb + 256*k3
+        a[4 * h + 0] = cabs_f(y0);
+        a[4 * h + 1] = cabs_f(y1);
+        a[4 * h + 2] = cabs_f(y2);
+        a[4 * h + 3] = cabs_f(y3);
+        kk[4 * h + 0] = kb;
+        kk[4 * h + 1] = kb + 256;
+        kk[4 * h + 2] = kb + 512;
+        kk[4 * h + 3] = kb + 768;
+    }
+    cx.sync();
+    // |X| in fft-shifted order: out[j] = X[(j + F/2) mod F]  <=>  j = (k + F/2) mod F
+    float* A = (float*)X;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        A[(kk[e] + FS_F / 2) & (FS_F - 1)] = a[e];
+    cx.sync();
+    // freqest search (lib/freqest_impl.cc:74-83)
+    float best = 0.f;
+    int bestj = -1;
+    const int span = FS_F - p.offset;
+    for (int j = l; j < span; j += 64) {
+        const float e = A[j] + A[j + p.offset];
+        if (e > best) {
+            best = e;
+            bestj = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ob = cx.shfl_xor_f32(best, o);
+        const int oj = cx.shfl_xor_i32(bestj, o);
+        // keep the larger energy; on a tie the smaller index (the sequential loop's first maximum)
+        if (oj >= 0 && (bestj < 0 || ob > best || (ob == best && oj < bestj))) {
+            best = ob;
+            bestj = oj;
+        }
+    }
+    if (live && l == 0)
+        p.maxpos[(long)c * p.maxpos_stride + v] = (bestj >= 0) ? bestj + p.offset / 2 : -1;
+}
+
+// freqest::work on spectra the caller already transformed (lib/freqest_impl.cc:57-88):
+// one wave per channel walks the vectors in order, so maxpos carries over exactly
+// as in the reference.
+struct FsFreqestParams {
+    const cf* vecs; long vec_stride; // [nchan][nvec*fftlen], fft-shifted
+    float* out; long out_stride;     // [nchan][nvec]
+    int nvec, fftlen, offset;
+    float binsize;
+};
+
+template <class Ctx>
+AISX_DI void fs_freqest_body(Ctx& cx, const FsFreqestParams& p)
+{
+    const int l = cx.tid();
+    const int c = cx.bx();
+    const cf* X = p.vecs + (long)c * p.vec_stride;
+    unsigned int maxpos = 0;
+    const int span = p.fftlen - p.offset;
+    for (int v = 0; v < p.nvec; v++) {
+        const cf* V = X + (long)v * p.fftlen;
+        float best = 0.f;
+        int bestj = -1;
+        for (int j = l; j < span; j += 64) {
+            const float e = cabs_f(V[j]) + cabs_f(V[j + p.offset]);
+            if (e > best) {
+                best = e;
+                bestj = j;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ob = cx.shfl_xor_f32(best, o);
+            const int oj = cx.shfl_xor_i32(bestj, o);
+            if (oj >= 0 && (bestj < 0 || ob > best || (ob == best && oj < bestj))) {
+                best = ob;
+                bestj = oj;
+            }
+        }
+        if (bestj >= 0)
+            maxpos = (unsigned)(bestj + p.offset / 2);
+        if (l == 0)
+            p.out[(long)c * p.out_stride + v] = ((float)maxpos - (float)((unsigned)p.fftlen / 2)) * p.binsize / 2.0f;
+    }
+}
+
+// [GR] frequency_modulator_fc: d_phase = fmod(d_phase + pi, 2 pi) - pi.  fmod is an
+// exact operation; for |u| < 4 pi it is u or u -/+ 2 pi (exact by Sterbenz).
+AISX_HD float nco_wrap(float ph)
+{
+    const float F_PI = 3.14159265358979323846f;
+    const float TWO_PI = 2.0f * F_PI;
+    const float u = ph + F_PI;
+    float r;
+    const float au = fabsf(u);
+    if (au < TWO_PI)
+        r = u;
+    else if (au < 2.0f * TWO_PI)
+        r = (u > 0.f) ? (u - TWO_PI) : (u + TWO_PI);
+    else
+        r = fmodf(u, TWO_PI);
+    return r - F_PI;
+}
+
+// ---------------------------------------------------------------------------
+constexpr int FSM_T = 256;
+constexpr int FSM_CH = 64;             // samples per chunk
+constexpr int FSM_PITCH = FSM_CH + 1;  // floats per channel row in LDS
+constexpr int FSM_LDS_BYTES = 64 * FSM_PITCH * 4;
+
+struct FsMixParams {
+    int nchan;
+    const cf* in; long in_stride;
+    const cf* pend_in; cf* pend_out; int npend; // pending partial vector in / out
+    int n;                                       // new items per channel
+    cf* out; long out_stride;
+    const int* maxpos; long maxpos_stride;
+    float* fhat; long fhat_stride;               // optional [nchan][nvec]
+    float* phase;                                // [nchan] NCO phase (d_phase)
+    int nvec;
+    float binsize, sensitivity;
+};
+
+template <class Ctx>
+AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
+{
+    const int t = cx.tid();
+    const int wave = t >> 6, l = t & 63;
+    const int cbase = cx.bx() * 64;
+    float* PH = (float*)cx.lds(); // [64][FSM_PITCH]
+    // wave 0: lane = channel cbase + l
+    const int myc = cbase + l;
+    const bool mylive = (wave == 0) && (myc < p.nchan);
+    float ph = mylive ? p.phase[myc] : 0.f;
+    unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
+    float d = 0.f;
+    const int total = p.nvec * FS_F;
+    for (int k0 = 0; k0 < total; k0 += FSM_CH) {
+        if (mylive) {
+            if ((k0 & (FS_F - 1)) == 0) { // a new vector starts
+                const int v = k0 / FS_F;
+                const int mp = p.maxpos[(long)myc * p.maxpos_stride + v];
+                if (mp >= 0)
+                    maxpos = (unsigned)mp;
+                // out[i] = (float(maxpos) - fftlen/2) * d_binsize/2   (:84)
+                const float f = ((float)maxpos - (float)(FS_F / 2)) * p.binsize / 2.0f;
+                if (p.fhat)
+                    p.fhat[(long)myc * p.fhat_stride + v] = f;
+                d = p.sensitivity * f;
+            }
+            for (int i = 0; i < FSM_CH; i++) {
+                // [GR] frequency_modulator_fc_impl::work
+                ph = ph + d;
+                ph = nco_wrap(ph);
+                PH[l * FSM_PITCH + i] = ph;
+            }
+        }
+        cx.sync();
+        // all waves: channel rows wave, wave+4, ...; lane = sample within the chunk
+        for (int r = wave; r < 64; r += 4) {
+            const int c = cbase + r;
+            if (c < p.nchan) {
+                const long idx = (long)k0 + l;
+                const cf s = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
+                float sn, cs;
+                det_sincos(PH[r * FSM_PITCH + l], &sn, &cs);
+                p.out[(long)c * p.out_stride + idx] = cmul_exact(s, mk(cs, sn));
+            }
+        }
+        cx.sync();
+    }
+    if (mylive)
+        p.phase[myc] = ph;
+    // keep the trailing partial vector (stream_to_vector's pending items)
+    const int rem = p.npend + p.n - total;
+    for (int r = wave; r < 64; r += 4) {
+        const int c = cbase + r;
+        if (c < p.nchan)
+            for (int i = l; i < rem; i += 64) {
+                const long idx = (long)total + i;
+                p.pend_out[(long)c * FS_F + i] =
+                    (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
+            }
+    }
+}
+
+} // namespace aisx

@@ -297,19 +297,91 @@ const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
 const float* emu_atan_table() { return aisx_atan_table; }
 
 #ifdef HAVE_AGC
-void emu_agc(const AgcParams* p, int gx, int nchan)
+struct EmuAgc {
+    int nchan, W;
+    float ref;
+    std::vector<cf> hist[2];
+    int cur = 0;
+};
+void* emu_agc_create(int nsamples, float reference, int nchan)
 {
-    run_grid(gx, nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, *p); });
+    EmuAgc* h = new EmuAgc();
+    h->nchan = nchan; h->W = nsamples; h->ref = reference;
+    h->hist[0].assign((size_t)nchan * nsamples, mk(0, 0));
+    h->hist[1] = h->hist[0];
+    return h;
+}
+void emu_agc_destroy(void* hv) { delete (EmuAgc*)hv; }
+void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_stride, int n)
+{
+    EmuAgc* h = (EmuAgc*)hv;
+    AgcParams p;
+    p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
+    p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
+    p.n = n; p.W = h->W; p.reference = h->ref; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    run_grid(p.ntiles, h->nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, p); });
+    h->cur ^= 1;
 }
 #endif
 #ifdef HAVE_FREQSYNC
-void emu_fs_est(const FsEstParams* p, int gx, int nchan)
+struct EmuFs {
+    int nchan, offset, max_vec;
+    float binsize, sens;
+    std::vector<cf> pend[2], wtab;
+    std::vector<int> maxpos;
+    std::vector<float> phase;
+    int cur = 0, npend = 0;
+};
+void* emu_fs_create(double samplerate, double bits_per_sec, int fftlen, int nchan, int max_items)
 {
-    run_grid(gx, nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, *p); });
+    if (fftlen != FS_F)
+        return nullptr;
+    EmuFs* h = new EmuFs();
+    h->nchan = nchan;
+    const float sr = (float)(int)samplerate;
+    const int dr = (int)bits_per_sec;
+    h->offset = (int)(fftlen * ((float)dr / sr));
+    h->binsize = sr / (float)fftlen;
+    h->sens = (float)(-1.0 / (samplerate / (2 * M_PI)));
+    h->max_vec = (max_items + fftlen) / fftlen + 1;
+    h->pend[0].assign((size_t)nchan * FS_F, mk(0, 0));
+    h->pend[1] = h->pend[0];
+    h->wtab.resize(FS_F);
+    for (int k = 0; k < FS_F; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)FS_F;
+        h->wtab[k] = mk((float)cos(a), (float)sin(a));
+    }
+    h->maxpos.assign((size_t)nchan * h->max_vec, 0);
+    h->phase.assign(nchan, 0.f);
+    return h;
 }
-void emu_fs_mix(const FsMixParams* p, int gx)
+void emu_fs_destroy(void* hv) { delete (EmuFs*)hv; }
+int emu_fs_process(void* hv, const cf* in, long in_stride, int n, cf* out, long out_stride, float* fhat, long fhat_stride)
 {
-    run_grid(gx, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, *p); });
+    EmuFs* h = (EmuFs*)hv;
+    const int nvec = (h->npend + n) / FS_F;
+    if (nvec > 0) {
+        FsEstParams e;
+        e.in = in; e.in_stride = in_stride; e.pend = h->pend[h->cur].data(); e.npend = h->npend; e.wtab = h->wtab.data();
+        e.maxpos = h->maxpos.data(); e.maxpos_stride = h->max_vec; e.nvec = nvec; e.offset = h->offset;
+        run_grid((nvec + 3) / 4, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
+    }
+    FsMixParams m;
+    m.nchan = h->nchan; m.in = in; m.in_stride = in_stride; m.pend_in = h->pend[h->cur].data(); m.pend_out = h->pend[h->cur ^ 1].data();
+    m.npend = h->npend; m.n = n; m.out = out; m.out_stride = out_stride; m.maxpos = h->maxpos.data(); m.maxpos_stride = h->max_vec;
+    m.fhat = fhat; m.fhat_stride = fhat_stride; m.phase = h->phase.data(); m.nvec = nvec; m.binsize = h->binsize; m.sensitivity = h->sens;
+    run_grid((h->nchan + 63) / 64, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, m); });
+    h->npend = h->npend + n - nvec * FS_F;
+    h->cur ^= 1;
+    return nvec * FS_F;
+}
+void emu_freqest_work(void* hv, const cf* vecs, long vec_stride, float* out, long out_stride, int nvec)
+{
+    EmuFs* h = (EmuFs*)hv;
+    FsFreqestParams p;
+    p.vecs = vecs; p.vec_stride = vec_stride; p.out = out; p.out_stride = out_stride; p.nvec = nvec; p.fftlen = FS_F;
+    p.offset = h->offset; p.binsize = h->binsize;
+    run_grid(h->nchan, 1, 64, 0, [&](EmuCtx& cx) { fs_freqest_body(cx, p); });
 }
 #endif
 }

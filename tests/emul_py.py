@@ -42,6 +42,17 @@ def lib():
         L.emu_msk_process_stream.argtypes = [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp]
         L.emu_msk_general_work.restype = i32
         L.emu_msk_general_work.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, vp, vp]
+        f64 = C.c_double
+        L.emu_agc_create.restype = vp
+        L.emu_agc_create.argtypes = [i32, f32, i32]
+        L.emu_agc_destroy.argtypes = [vp]
+        L.emu_agc_process.argtypes = [vp, vp, lng, vp, lng, i32]
+        L.emu_fs_create.restype = vp
+        L.emu_fs_create.argtypes = [f64, f64, i32, i32, i32]
+        L.emu_fs_destroy.argtypes = [vp]
+        L.emu_fs_process.restype = i32
+        L.emu_fs_process.argtypes = [vp, vp, lng, i32, vp, lng, vp, lng]
+        L.emu_freqest_work.argtypes = [vp, vp, lng, vp, lng, i32]
         _LIB = L
     return _LIB
 
@@ -123,3 +134,48 @@ class MskStream:
         st = lib().emu_msk_general_work(self.h, noutput, ninput, inp, _p(out), _p(err), _p(mu), _p(bits), _p(tags),
                                         tags.size, nitems_read, C.byref(cons), C.byref(prod))
         return out[: prod.value], err[: prod.value], mu[: prod.value], bits[: prod.value], cons.value, st
+
+
+class Agc:
+    def __init__(self, nsamples=512, reference=2.0, nchan=1):
+        self.h = lib().emu_agc_create(nsamples, reference, nchan)
+        self.nchan = nchan
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emu_agc_destroy(self.h)
+            self.h = None
+
+    def work(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64).reshape(self.nchan, -1)
+        out = np.zeros_like(x)
+        lib().emu_agc_process(self.h, _p(x), x.shape[1], _p(out), x.shape[1], x.shape[1])
+        return out
+
+
+class FreqSync:
+    def __init__(self, samplerate, bits_per_sec, fftlen=1024, nchan=1, max_items=1 << 20):
+        self.h = lib().emu_fs_create(samplerate, bits_per_sec, fftlen, nchan, max_items)
+        self.nchan, self.fftlen = nchan, fftlen
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emu_fs_destroy(self.h)
+            self.h = None
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64).reshape(self.nchan, -1)
+        n = x.shape[1]
+        cap = n + self.fftlen
+        out = np.zeros((self.nchan, cap), np.complex64)
+        nv = cap // self.fftlen + 1
+        fh = np.zeros((self.nchan, nv), np.float32)
+        m = lib().emu_fs_process(self.h, _p(x), n, n, _p(out), cap, _p(fh), nv)
+        return out[:, :m].copy(), fh[:, : m // self.fftlen].copy()
+
+    def freqest_work(self, vecs):
+        v = np.ascontiguousarray(vecs, dtype=np.complex64).reshape(self.nchan, -1)
+        nvec = v.shape[1] // self.fftlen
+        out = np.zeros((self.nchan, max(nvec, 1)), np.float32)
+        lib().emu_freqest_work(self.h, _p(v), v.shape[1], _p(out), out.shape[1], nvec)
+        return out[:, :nvec]

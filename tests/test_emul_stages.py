@@ -1,0 +1,77 @@
+"""feedforward AGC and square_and_fft_sync_cc / freqest kernel bodies under the
+CPU lane model vs the oracle."""
+import numpy as np
+import pytest
+
+import emul_py as emu
+import oracle_py as orc
+from ais_amd import synth
+
+
+def test_emul_agc_bit_exact():
+    rng = np.random.default_rng(2)
+    nchan = 3
+    lens = [5000, 1, 300, 2048, 4097]
+    total = sum(lens)
+    x = (rng.normal(size=(nchan, total)) + 1j * rng.normal(size=(nchan, total))).astype(np.complex64)
+    x[0, 1000:3000] = 0          # floor 1e-12 path
+    x[1, 200] = np.nan           # NaN envelopes are ignored by std::max
+    x[2] *= np.linspace(0.01, 30, total).astype(np.float32)
+    for W in (512, 1, 37, 2048):
+        e = emu.Agc(W, 2.0, nchan)
+        o = [orc.Agc(W, 2.0) for _ in range(nchan)]
+        k = 0
+        for L in lens:
+            out = e.work(x[:, k:k + L])
+            for c in range(nchan):
+                want = o[c].work(x[c, k:k + L])
+                assert np.array_equal(out[c].view(np.uint32), want.view(np.uint32)), (W, L, c)
+            k += L
+
+
+def _check_freqsync(e, o, x, nchan):
+    out, fh = e.process(x)
+    nbad = 0
+    for c in range(nchan):
+        want, wfh = o[c].process(x[c])
+        assert out.shape[1] == want.size and fh.shape[1] == wfh.size
+        if np.array_equal(fh[c], wfh):
+            assert np.array_equal(out[c].view(np.uint32), want.view(np.uint32))
+        else:
+            nbad += int(np.sum(fh[c] != wfh))
+    return nbad, fh.size
+
+
+def test_emul_freqsync_matches_oracle():
+    nchan = 3
+    fs = 38400.0
+    lens = [4096, 1000, 24, 5000, 3 * 1024 + 7]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(300 + c, total, "P", 4, amp=0.5, cfo_max=500.0)[0] for c in range(nchan)])
+    xs[1, 2048:5120] = 0  # all-zero vectors: the stale-maxpos quirk
+    e = emu.FreqSync(fs, 9600.0, 1024, nchan)
+    o = [orc.FreqSync(fs, 9600.0, 1024) for _ in range(nchan)]
+    k = 0
+    bad = tot = 0
+    for L in lens:
+        b, t = _check_freqsync(e, o, xs[:, k:k + L], nchan)
+        bad += b
+        tot += t
+        k += L
+    assert tot >= 3 * 12 and bad == 0
+
+
+def test_emul_freqest_work_kat():
+    e = emu.FreqSync(38400.0, 9600.0, 1024, 2)
+    v = np.zeros((2, 3, 1024), dtype=np.complex64)
+    v[0, 0, 394] = 5
+    v[0, 0, 650] = 4j
+    v[1, 1, 100] = 1
+    v[1, 1, 356] = 1
+    v[1, 1, 700] = 1
+    v[1, 1, 956] = 1  # tie: the first maximum wins
+    out = e.freqest_work(v)
+    assert out[0].tolist() == [187.5, 187.5, 187.5]  # SURVEY 4.1 KAT + stale maxpos
+    fe = orc.FreqEst.make(38400.0, 9600, 1024)
+    assert np.array_equal(out[1], fe.work(v[1]))
+    assert out[1][0] == -9600.0

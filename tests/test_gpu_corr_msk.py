@@ -251,7 +251,7 @@ def test_core_chain_corr_to_msk_bits_identical(ais, family):
                 fftlen=1024)
     dem = ais.ais_demod(opts, nchan=nchan, max_items=T, stages="core", preamble_symbols=tmpl)
     ora = [orc.Demod(sps, tmpl, stages=0) for _ in range(nchan)]
-    nbits = ntags = 0
+    nbits = ntags = nexact = 0
     for s in range(steps):
         chunk = xs[:, s * T:(s + 1) * T]
         r = dem.work(_dev(chunk), want_syms=True)
@@ -265,11 +265,14 @@ def test_core_chain_corr_to_msk_bits_identical(ais, family):
             ntags += assert_tags_match(tags[c], ot)
             assert prod[c] == len(ob)
             assert np.array_equal(bits[c, : prod[c]], ob)
-            # symbols: bit-exact unless a time_est differed in the last place
+            # symbols: bit-exact unless a time_est differed in its last place and moved
+            # the interpolator to the neighbouring row of the 129-step table
             same = np.array_equal(syms[c, : prod[c]].view(np.uint32), osy.view(np.uint32))
-            assert same or np.max(np.abs(syms[c, : prod[c]] - osy)) < 1e-3
+            nexact += int(same)
+            assert same or np.max(np.abs(syms[c, : prod[c]] - osy)) < 0.05
             nbits += prod[c]
     assert ntags > nchan // 2 and nbits > nchan * T * steps // sps - nchan * 64
+    assert nexact >= 0.8 * nchan * steps
 
 
 def test_full_size_properties(ais):
