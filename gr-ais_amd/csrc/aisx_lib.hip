@@ -62,10 +62,21 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
     corr_resolve_body(cx, p);
 }
 
-__global__ __launch_bounds__(64) void k_msk(MskParams p)
+__global__ __launch_bounds__(MSK_T) void k_msk(MskParams p)
 {
-    DevCtx cx{ nullptr };
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
     msk_body(cx, p);
+}
+
+static int msk_enable_big_lds()
+{
+    static bool done = false;
+    if (!done) {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)k_msk, hipFuncAttributeMaxDynamicSharedMemorySize, MSK_LDS_BYTES));
+        done = true;
+    }
+    return AISX_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -430,7 +441,7 @@ extern "C" int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32*
 struct aisx_msk {
     int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
     float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
-    static constexpr int carry_cap = 256, ctag_cap = 64;
+    static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     float *d_mu = nullptr, *d_omega = nullptr;
     int* d_div = nullptr;
     cf *d_dly1 = nullptr, *d_dly2 = nullptr, *d_diff1 = nullptr, *d_tprev = nullptr;
@@ -678,7 +689,10 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : h->d_produced;
-    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
+    int rc = msk_enable_big_lds();
+    if (rc != AISX_OK)
+        return rc;
+    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(MSK_T), MSK_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     return AISX_OK;
@@ -769,7 +783,9 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     p.out_stride = noutput_items;
     p.out_cap = noutput_items;
     p.produced = h->d_produced;
-    hipLaunchKernelGGL(k_msk, dim3(1), dim3(64), 0, 0, p);
+    if ((rc = msk_enable_big_lds()) != AISX_OK)
+        return rc;
+    hipLaunchKernelGGL(k_msk, dim3(1), dim3(MSK_T), MSK_LDS_BYTES, 0, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     int st = 0;

@@ -1,15 +1,40 @@
 // k_msk.h -- msk_timing_recovery_cc (reference: lib/msk_timing_recovery_cc_impl.cc
 // :107-206) with the NRZI bit tail of python/ais_demod.py:48-52 + lib/invert_impl.cc
-// :62-64 fused into the epilogue.  One lane per channel: the loop is a strict
-// recurrence through (mu, omega, iidx), so the only parallelism is across
-// channels.  All arithmetic is the reference's float/double sequence, unfused,
-// so the symbols are bit-identical to the oracle's.
+// :62-64 fused into the epilogue.
+//
+// The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
+// is across channels, so one lane owns one channel and a wave owns 64.  What
+// the wave does together is memory: every lane keeps a 256-sample ring of its
+// channel in LDS (row pitch 257 => lanes at equal depth hit distinct banks); per
+// tile the wave tops the rings up with coalesced 64-sample chunks that are
+// issued BEFORE the tile's iterations and written to LDS after them (the loads
+// fly under the recurrence), runs MSK_K iterations per lane out of LDS, and
+// flushes the tile's symbols/bits from an LDS staging buffer with coalesced
+// stores.  All arithmetic is the reference's float/double sequence, unfused, so
+// the symbols are bit-identical to the CPU restatement.
 #pragma once
 #include "aisx_common.h"
 
 namespace aisx {
 
 enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERFLOW = 4, MSK_ST_OUT_FULL = 8 };
+
+constexpr int MSK_T = 64;
+constexpr int MSK_RING = 256;   // samples per lane ring (power of two)
+constexpr int MSK_PITCH = 257;  // ring row pitch in complex elements
+constexpr int MSK_CHUNK = 64;   // samples per top-up
+constexpr int MSK_ROOM = 180;   // top up while (loaded - position) <= MSK_ROOM
+constexpr int MSK_K = 28;       // loop iterations per tile
+constexpr int MSK_OB = 32;      // staged outputs per lane per tile (>= MSK_K)
+constexpr int MSK_OPITCH = 33;  // staging row pitch (symbols)
+constexpr int MSK_BPITCH = 36;  // staging row pitch (bits, bytes)
+constexpr int MSK_CARRY_MAX = 128;
+constexpr int MSK_LDS_RING = 64 * MSK_PITCH * 8;
+constexpr int MSK_LDS_MMSE = 129 * 8 * 4;
+constexpr int MSK_LDS_OSYM = 64 * MSK_OPITCH * 8;
+constexpr int MSK_LDS_OBIT = 64 * MSK_BPITCH;
+constexpr int MSK_LDS_LANE = 4 * 64 * 4; // per-lane scalars published to the wave (ld, pending, ocnt, obase)
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE;
 
 struct MskParams {
     int nchan;
@@ -44,33 +69,53 @@ AISX_HD int msk_forecast(float d_sps, int noutput_items)
 template <class Ctx>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
-    const int c = cx.bx() * cx.nthreads() + cx.tid();
-    if (c >= p.nchan)
-        return;
+    const int l = cx.tid();
+    const int cbase = cx.bx() * 64;
+    const int c = cbase + l;
+    const bool live = c < p.nchan;
+    const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
+
+    char* lds = cx.lds();
+    cf* ring = (cf*)lds;
+    float* mm = (float*)(lds + MSK_LDS_RING);
+    cf* osym = (cf*)(lds + MSK_LDS_RING + MSK_LDS_MMSE);
+    unsigned char* obit = (unsigned char*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM);
+    int* sh_ld = (int*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT);
+    int* sh_pend = sh_ld + 64;
+    int* sh_ocnt = sh_ld + 128;
+    int* sh_obase = sh_ld + 192;
+    cf* myring = ring + l * MSK_PITCH;
+
+    for (int i = l; i < 129 * 8; i += 64)
+        mm[i] = p.mmse[i];
+
     const float d_sps = p.d_sps;
-    float d_mu = p.mu[c], d_omega = p.omega[c];
-    int d_div = p.div[c];
-    cf d_dly_conj_1 = p.dly1[c], d_dly_conj_2 = p.dly2[c], d_dly_diff_1 = p.diff1[c];
-    cf tprev = p.tail_prev_sym[c];
-    unsigned char tbit = p.tail_prev_bit[c];
-    const unsigned long long R = p.nread[c];
+    float d_mu = p.mu[cc], d_omega = p.omega[cc];
+    int d_div = p.div[cc];
+    cf d_dly_conj_1 = p.dly1[cc], d_dly_conj_2 = p.dly2[cc], d_dly_diff_1 = p.diff1[cc];
+    cf tprev = p.tail_prev_sym[cc];
+    unsigned char tbit = p.tail_prev_bit[cc];
+    const unsigned long long R = p.nread[cc];
     int status = 0;
 
-    const cf* cin = p.carry_in + (long)c * p.carry_cap; // [0] = item before R, then pending
-    const int pending = p.carry_len_in[c];
-    const cf* xin = p.in + (long)c * p.in_stride;
+    // items on offer: logical index q in [-1, navail): q = -1 the item before
+    // nitems_read, then the `pending` carried items, then the n new ones.
+    const cf* cin = p.carry_in + (long)cc * p.carry_cap;
+    int pending = p.carry_len_in[cc];
+    if (pending > MSK_CARRY_MAX)
+        pending = MSK_CARRY_MAX;
     const int navail = pending + p.n;
-    // item idx of the items on offer, idx in [-1, navail)
-    auto fetch = [&](int idx) -> cf {
-        const int q = idx + 1;
-        return (q <= pending) ? cin[q] : xin[q - 1 - pending];
-    };
+    // ring slot of logical index q is (q + 1) & 255; seed it with the carry
+    for (int q = -1; q < pending; q++)
+        myring[(q + 1) & (MSK_RING - 1)] = cin[q + 1];
+    int ld = pending; // logical index up to which the ring is filled (exclusive)
+    sh_pend[l] = pending;
 
     // logical tag list = carried tags, then this call's tags
-    const tag_rec* ctg = p.ctag_in + (long)c * p.ctag_cap;
-    const int nct = p.ctag_n_in[c];
-    const tag_rec* ntg = p.tags ? p.tags + (long)c * p.tag_cap : nullptr;
-    int nnt = p.tags ? p.tag_count[c] : 0;
+    const tag_rec* ctg = p.ctag_in + (long)cc * p.ctag_cap;
+    const int nct = p.ctag_n_in[cc];
+    const tag_rec* ntg = p.tags ? p.tags + (long)cc * p.tag_cap : nullptr;
+    int nnt = p.tags ? p.tag_count[cc] : 0;
     if (nnt > p.tag_cap)
         nnt = p.tag_cap;
     const int ntot = nct + nnt;
@@ -81,18 +126,17 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             tpos++;
     };
 
-    cf* osym = p.syms ? p.syms + (long)c * p.out_stride : nullptr;
-    float* oerr = p.err ? p.err + (long)c * p.out_stride : nullptr;
-    float* omu = p.mu_out ? p.mu_out + (long)c * p.out_stride : nullptr;
-    unsigned char* obit = p.bits ? p.bits + (long)c * p.out_stride : nullptr;
+    float* oerr = p.err ? p.err + (long)cc * p.out_stride : nullptr;
+    float* omu = p.mu_out ? p.mu_out + (long)cc * p.out_stride : nullptr;
 
-    // Stream mode plays the scheduler: general_work() is called again and again on
-    // what is left until forecast(1) no longer fits.  `base` = items consumed and
-    // `ototal` = items produced by the calls made so far in this launch.
-    int base = 0, ototal = 0;
-    for (;;) {
-        const unsigned long long Rc = R + (unsigned long long)base; // nitems_read(0) of this call
-        int ninput, noutput;
+    // ---- "scheduler": one general_work() call after another (stream mode) ----
+    int base = 0, ototal = 0;     // items consumed / produced by finished calls
+    int iidx = 0, oidx = 0;       // of the call in progress
+    int ninp = 0, noutput = 0;
+    unsigned long long Rc = R, rend = R;
+    bool done = !live;
+    auto setup_round = [&]() {
+        int ninput;
         if (p.stream_mode) {
             ninput = (navail - base) - 1; // one look-ahead item is kept out of sight
             noutput = 0;
@@ -109,103 +153,195 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             ninput = p.gr_ninput;
             noutput = p.gr_noutput;
         }
-        const int ninp = (int)(ninput - 3.0 * d_sps); // :119
-        if (ninp <= 0 || noutput <= 0)
-            break;
+        ninp = (int)(ninput - 3.0 * d_sps); // :119
+        iidx = 0;
+        oidx = 0;
+        if (ninp <= 0 || noutput <= 0) {
+            done = true;
+            return;
+        }
         // get_tags_in_range(nitems_read, nitems_read + ninp, "time_est") (:125-130)
+        Rc = R + (unsigned long long)base;
+        rend = Rc + (unsigned long long)ninp;
         tpos = 0;
         skip_other_keys();
         while (tpos < ntot && tag_at(tpos).offset < Rc) {
             tpos++;
             skip_other_keys();
         }
-        const unsigned long long rend = Rc + (unsigned long long)ninp;
-        int oidx = 0, iidx = 0;
-        float err_out = 0;
-        while (oidx < noutput && iidx < ninp) { // :138
-            if (tpos < ntot && tag_at(tpos).offset < rend) { // tags.size() > 0
-                const int offset = (int)(tag_at(tpos).offset - Rc);
-                if ((offset >= iidx) && ((float)offset < ((float)iidx + d_sps))) { // :142
-                    const float center = (float)tag_at(tpos).value;
-                    if (center != center) { // NaN :144-147
-                        tpos++;
-                        skip_other_keys();
-                    } else {
-                        d_mu = center;
-                        iidx = offset;
-                        if (d_mu < 0) {
-                            d_mu++;
-                            iidx--;
+    };
+    if (!done)
+        setup_round();
+    const int jump_margin = (int)ceilf(d_sps) + 1; // a tag may move iidx forward by < d_sps
+
+    cx.sync();
+    for (int tile = 0;; tile++) {
+        // ---------------- top-up: issue the loads ----------------
+        const int pos0 = base + iidx;
+        const bool room = live && (ld < navail) && (ld - pos0 <= MSK_ROOM);
+        sh_ld[l] = ld;
+        const unsigned long long needmask = cx.ballot(room);
+        const unsigned long long livemask = cx.ballot(!done);
+        cx.sync(); // sh_ld visible to the whole wave
+        if (needmask == 0ull && livemask == 0ull)
+            break;
+        cf r[MSK_CHUNK];
+        if (needmask != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                r[j] = mk(0.f, 0.f);
+                if ((needmask >> j) & 1ull) {
+                    const int pj = sh_pend[j];
+                    const int q = sh_ld[j] + l;
+                    if (q < pj + p.n) // navail of channel j
+                        r[j] = p.in[(long)(cbase + j) * p.in_stride + (q - pj)];
+                }
+            }
+        }
+        // ---------------- the recurrence, MSK_K iterations ----------------
+        int ocnt = 0;
+        const int obase = ototal + oidx;
+        const int kiter = (tile < 3) ? 0 : MSK_K; // the first tiles only prime the rings
+        for (int it = 0; it < kiter; it++) {
+            if (!done && !(oidx < noutput && iidx < ninp)) { // :138 -- this call is over
+                base += iidx;                                 // consume_each(iidx)
+                ototal += oidx;
+                const bool progress = (iidx > 0) || (oidx > 0);
+                if (!p.stream_mode || !progress)
+                    done = true;
+                else
+                    setup_round();
+            }
+            const int pos = base + iidx;
+            const bool can = !done && ((pos + 8 + jump_margin <= ld) || (ld >= navail));
+            if (can) {
+                if (tpos < ntot && tag_at(tpos).offset < rend) { // tags.size() > 0
+                    const int offset = (int)(tag_at(tpos).offset - Rc);
+                    if ((offset >= iidx) && ((float)offset < ((float)iidx + d_sps))) { // :142
+                        const float center = (float)tag_at(tpos).value;
+                        if (center != center) { // NaN :144-147
+                            tpos++;
+                            skip_other_keys();
+                        } else {
+                            d_mu = center;
+                            iidx = offset;
+                            if (d_mu < 0) {
+                                d_mu++;
+                                iidx--;
+                            }
+                            d_div = 0;
+                            d_omega = d_sps;
+                            d_dly_conj_2 = d_dly_conj_1;
+                            tpos++;
+                            skip_other_keys();
                         }
-                        d_div = 0;
-                        d_omega = d_sps;
-                        d_dly_conj_2 = d_dly_conj_1;
-                        tpos++;
-                        skip_other_keys();
                     }
                 }
-            }
-            // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
-            const int imu = (int)rint(d_mu * 128.0f);
-            cf in_interp = mk(0.f, 0.f);
-            if (imu < 0 || imu > 128) {
-                status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
-            } else {
-                const float* tp = p.mmse + imu * 8;
+                // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
+                const int imu = (int)rint(d_mu * 128.0f);
+                cf in_interp = mk(0.f, 0.f);
+                if (imu < 0 || imu > 128) {
+                    status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
+                } else {
+                    const float* tp = mm + imu * 8;
+                    const int q0 = base + iidx + 1; // ring slot of in[iidx]
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const cf s = fetch(base + iidx + k);
-                    const float tk = tp[7 - k];
-                    in_interp.re += s.re * tk;
-                    in_interp.im += s.im * tk;
+                    for (int k = 0; k < 8; k++) {
+                        const cf s = myring[(q0 + k) & (MSK_RING - 1)];
+                        const float tk = tp[7 - k];
+                        in_interp.re += s.re * tk;
+                        in_interp.im += s.im * tk;
+                    }
                 }
-            }
-            const cf sq = cmul_exact(in_interp, in_interp);                      // :171
-            const cf dly_conj = cconj(cmul_exact(d_dly_conj_2, d_dly_conj_2));   // :173
-            const cf nlin_out = cmul_exact(sq, dly_conj);                        // :174
-            err_out = (nlin_out - d_dly_diff_1).re;                              // :178
-            if (d_div % 2) {                                                     // :179-184
-                err_out = branchless_clip(err_out, 3.0f);
-                d_omega += p.gain_omega * err_out;
-                d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
-                d_mu += p.gain * err_out;
-            }
-            if (!(d_div % 2) || p.osps == 2) { // :186-191
-                const int oo = ototal + oidx;
-                if (osym)
-                    osym[oo] = in_interp;
-                if (oerr)
-                    oerr[oo] = err_out;
-                if (omu)
-                    omu[oo] = d_mu;
-                if (obit) {
+                const cf sq = cmul_exact(in_interp, in_interp);                    // :171
+                const cf dly_conj = cconj(cmul_exact(d_dly_conj_2, d_dly_conj_2)); // :173
+                const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
+                float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
+                if (d_div % 2) {                                                   // :179-184
+                    err_out = branchless_clip(err_out, 3.0f);
+                    d_omega += p.gain_omega * err_out;
+                    d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+                    d_mu += p.gain * err_out;
+                }
+                if (!(d_div % 2) || p.osps == 2) { // :186-191
+                    const int oo = ototal + oidx;
+                    osym[l * MSK_OPITCH + ocnt] = in_interp;
+                    if (oerr)
+                        oerr[oo] = err_out;
+                    if (omu)
+                        omu[oo] = d_mu;
                     // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert
                     const cf prod = cmul_exact(in_interp, cconj(tprev));
                     const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, p.atan_tab);
                     const unsigned char b = fm >= 0 ? 1 : 0;
                     const unsigned char d = (unsigned char)(((unsigned)(b - tbit)) % 2u);
-                    obit[oo] = (unsigned char)((d ^ 0x01) & 0x01);
+                    obit[l * MSK_BPITCH + ocnt] = (unsigned char)((d ^ 0x01) & 0x01);
                     tprev = in_interp;
                     tbit = b;
+                    ocnt++;
+                    oidx++;
                 }
-                oidx++;
+                d_div++;
+                d_dly_conj_1 = in_interp; // :194-196
+                d_dly_conj_2 = d_dly_conj_1;
+                d_dly_diff_1 = nlin_out;
+                d_mu += d_omega; // :199-201
+                const float fl = floorf(d_mu);
+                iidx += (int)fl;
+                d_mu = d_mu - fl;
             }
-            d_div++;
-            d_dly_conj_1 = in_interp; // :194-196
-            d_dly_conj_2 = d_dly_conj_1;
-            d_dly_diff_1 = nlin_out;
-            d_mu += d_omega; // :199-201
-            const float fl = floorf(d_mu);
-            iidx += (int)fl;
-            d_mu = d_mu - fl;
         }
-        base += iidx; // consume_each(iidx)
-        ototal += oidx;
-        if (!p.stream_mode || (iidx <= 0 && oidx == 0))
-            break;
+        // ---------------- top-up: land the chunks in the rings ----------------
+        if (needmask != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                if ((needmask >> j) & 1ull) {
+                    const int ldj = sh_ld[j];
+                    // items at or past navail are written as zeros (the reference may read
+                    // a few items past ninput_items for sps < 4)
+                    ring[j * MSK_PITCH + ((ldj + l + 1) & (MSK_RING - 1))] = r[j];
+                }
+            }
+            if (room) {
+                ld += MSK_CHUNK;
+                if (ld >= navail) {
+                    ld = navail;
+                }
+            }
+        }
+        cx.sync();
+        if (room && ld == navail) {
+            // end of input: zero guard for reads past the last item (the reference's loop
+            // bound lets the interpolator look a few items past ninput_items; here they are 0)
+            for (int k = 0; k < 8; k++)
+                myring[(navail + k + 1) & (MSK_RING - 1)] = mk(0.f, 0.f);
+        }
+        // ---------------- flush the tile's outputs ----------------
+        sh_ocnt[l] = ocnt;
+        sh_obase[l] = obase;
+        const bool anyout = cx.ballot(ocnt > 0) != 0ull; // (also orders the LDS stores above)
+        cx.sync();
+        if (anyout) {
+#pragma unroll 4
+            for (int jp = 0; jp < 32; jp++) {
+                const int j = 2 * jp + (l >> 5);
+                const int i = l & 31;
+                const int cnt = sh_ocnt[j];
+                const int ob = sh_obase[j];
+                if (i < cnt && (cbase + j) < p.nchan) {
+                    const long o = (long)(cbase + j) * p.out_stride + ob + i;
+                    if (p.syms)
+                        p.syms[o] = osym[j * MSK_OPITCH + i];
+                    if (p.bits)
+                        p.bits[o] = obit[j * MSK_BPITCH + i];
+                }
+            }
+        }
+        cx.sync();
     }
-    const int iidx = base, oidx = ototal;
-    // consume_each(iidx)
+
+    if (!live)
+        return;
     p.mu[c] = d_mu;
     p.omega[c] = d_omega;
     p.div[c] = d_div;
@@ -214,20 +350,21 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     p.diff1[c] = d_dly_diff_1;
     p.tail_prev_sym[c] = tprev;
     p.tail_prev_bit[c] = tbit;
-    const unsigned long long Rn = R + (unsigned long long)iidx;
+    const unsigned long long Rn = R + (unsigned long long)base;
     p.nread[c] = Rn;
-    p.produced[c] = oidx;
-    p.consumed[c] = iidx;
+    p.produced[c] = ototal;
+    p.consumed[c] = base;
 
     cf* cout = p.carry_out + (long)c * p.carry_cap;
     if (p.stream_mode) {
-        int left = navail - iidx; // pending items for the next call
-        if (left + 1 > p.carry_cap) {
+        int left = navail - base; // pending items for the next call
+        int cap = p.carry_cap < MSK_CARRY_MAX ? p.carry_cap : MSK_CARRY_MAX;
+        if (left + 1 > cap) {
             status |= MSK_ST_CARRY_OVERFLOW;
-            left = p.carry_cap - 1;
+            left = cap - 1;
         }
         for (int k = 0; k <= left; k++)
-            cout[k] = fetch(iidx - 1 + k);
+            cout[k] = myring[(base - 1 + k + 1) & (MSK_RING - 1)];
         p.carry_len_out[c] = left;
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
@@ -244,7 +381,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
     } else {
-        cout[0] = (iidx > 0) ? fetch(iidx - 1) : cin[0];
+        cout[0] = myring[(base - 1 + 1) & (MSK_RING - 1)];
         p.carry_len_out[c] = 0;
         p.ctag_n_out[c] = 0;
     }

@@ -1008,7 +1008,7 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
         h->nstore++;
     }
     /* 4. msk timing recovery */
-    if (h->msk_pending + n1 + 2 > h->msk_cap) {
+    if (h->msk_pending + n1 + 2 + 8 > h->msk_cap) {
         h->msk_cap = h->msk_pending + n1 + 1024;
         h->msk_buf = (orc_cf *)realloc(h->msk_buf, sizeof(orc_cf) * h->msk_cap);
     }
@@ -1029,6 +1029,9 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
             break;
         orc_cf *syms = (orc_cf *)malloc(sizeof(orc_cf) * (size_t)nout);
         int consumed = 0, status = 0;
+        /* items past the ones on offer read as zero (the reference may look a few
+         * items past ninput_items when sps < 4) */
+        memset(h->msk_buf + 1 + h->msk_pending, 0, sizeof(orc_cf) * 8);
         int prod = orc_msk_general_work(h->msk, nout, ninput, h->msk_buf + 1, syms, NULL, NULL, h->store, h->nstore,
                                         h->msk_read, &consumed, &status);
         if (consumed > 0) {

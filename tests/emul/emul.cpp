@@ -137,7 +137,7 @@ void emu_corr_resolve(const ResolveParams* p, int nchan)
 
 void emu_msk(const MskParams* p)
 {
-    run_independent((p->nchan + 63) / 64, 64, [&](EmuCtx& cx) { msk_body(cx, *p); });
+    run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) { msk_body(cx, *p); });
 }
 
 // ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
@@ -207,7 +207,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
 struct EmuMsk {
     int nchan, osps;
     float d_sps, gain, gain_omega, limit;
-    static constexpr int carry_cap = 256, ctag_cap = 64;
+    static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     std::vector<float> mu, omega;
     std::vector<int> div, carry_len[2], ctag_n[2], produced, consumed, status;
     std::vector<cf> dly1, dly2, diff1, tprev, carry[2];

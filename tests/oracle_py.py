@@ -286,7 +286,10 @@ class MskStream:
                     nout -= 1
             if nout <= 0 or int(ninput - 3.0 * dsps) <= 0:
                 break
-            out, o2, o3, cons, st = self.m.general_work(nout, ninput, self.buf, 1, self.store, self.read, want_aux)
+            # items past the ones on offer read as zero (the reference may look a few items
+            # past ninput_items when sps < 4)
+            padded = np.concatenate([self.buf, np.zeros(8, np.complex64)])
+            out, o2, o3, cons, st = self.m.general_work(nout, ninput, padded, 1, self.store, self.read, want_aux)
             self.buf = self.buf[cons:].copy()
             self.read += cons
             self.store = self.store[self.store["offset"] >= self.read]

@@ -64,3 +64,27 @@ def planted(rng, nchan, n, tmpl, positions, noise=0.05, amp=1.0):
             if hi > lo:
                 x[c, lo:hi] += (amp * tmpl[lo - p:hi - p] * np.exp(1j * rng.uniform(-3, 3))).astype(np.complex64)
     return x
+
+
+def assert_decoded_bursts_identical(got_bits, want_bits, infos, min_frac_equal=0.97):
+    """Chain-level gate: every burst the oracle's bit stream contains
+    must appear, bit for bit, at the same position in the GPU's stream.  Bits
+    demodulated from noise between bursts are not compared one by one: a
+    time_est that differs in its last place (FFT rounding) legitimately flips a
+    few of them; only their overall agreement is bounded.  Returns
+    (bursts compared, bursts transmitted)."""
+    from ais_amd import synth
+
+    got_bits = np.asarray(got_bits, dtype=np.uint8)
+    want_bits = np.asarray(want_bits, dtype=np.uint8)
+    assert got_bits.size == want_bits.size
+    ncmp = 0
+    for inf in infos:
+        pat = np.asarray(inf["data_bits"], dtype=np.uint8)
+        for pos in synth.find_bits(want_bits, pat):
+            assert np.array_equal(got_bits[pos:pos + pat.size], pat), "burst at bit %d differs" % pos
+            ncmp += 1
+    if want_bits.size:
+        frac = float(np.mean(got_bits == want_bits))
+        assert frac >= min_frac_equal, "only %.4f of the bits agree" % frac
+    return ncmp, len(infos)
