@@ -205,10 +205,12 @@ AISX_HD float nco_wrap(float ph)
 }
 
 // ---------------------------------------------------------------------------
-constexpr int FSM_T = 256;
+constexpr int FSM_T = 512;             // wave 0 walks the NCO phases, waves 1..7 mix
+constexpr int FSM_MIXW = FSM_T / 64 - 1;
 constexpr int FSM_CH = 64;             // samples per chunk
 constexpr int FSM_PITCH = FSM_CH + 1;  // floats per channel row in LDS
-constexpr int FSM_LDS_BYTES = 64 * FSM_PITCH * 4;
+constexpr int FSM_ROWS = (64 + FSM_MIXW - 1) / FSM_MIXW; // channel rows per mixing wave
+constexpr int FSM_LDS_BYTES = 2 * 64 * FSM_PITCH * 4;    // two phase buffers
 
 struct FsMixParams {
     int nchan;
@@ -229,7 +231,7 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
     const int t = cx.tid();
     const int wave = t >> 6, l = t & 63;
     const int cbase = cx.bx() * 64;
-    float* PH = (float*)cx.lds(); // [64][FSM_PITCH]
+    float* PH = (float*)cx.lds(); // [2][64][FSM_PITCH]
     // wave 0: lane = channel cbase + l
     const int myc = cbase + l;
     const bool mylive = (wave == 0) && (myc < p.nchan);
@@ -237,36 +239,54 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
     unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
     float d = 0.f;
     const int total = p.nvec * FS_F;
-    for (int k0 = 0; k0 < total; k0 += FSM_CH) {
-        if (mylive) {
-            if ((k0 & (FS_F - 1)) == 0) { // a new vector starts
-                const int v = k0 / FS_F;
-                const int mp = p.maxpos[(long)myc * p.maxpos_stride + v];
-                if (mp >= 0)
-                    maxpos = (unsigned)mp;
-                // out[i] = (float(maxpos) - fftlen/2) * d_binsize/2   (:84)
-                const float f = ((float)maxpos - (float)(FS_F / 2)) * p.binsize / 2.0f;
-                if (p.fhat)
-                    p.fhat[(long)myc * p.fhat_stride + v] = f;
-                d = p.sensitivity * f;
+    const int nchunks = total / FSM_CH;
+    // software pipeline: wave 0 produces the phases of chunk k while waves 1..7 mix chunk k-1
+    for (int k = 0; k <= nchunks; k++) {
+        if (wave == 0) {
+            if (mylive && k < nchunks) {
+                const int k0 = k * FSM_CH;
+                float* dst = PH + (k & 1) * 64 * FSM_PITCH + l * FSM_PITCH;
+                if ((k0 & (FS_F - 1)) == 0) { // a new vector starts
+                    const int v = k0 / FS_F;
+                    const int mp = p.maxpos[(long)myc * p.maxpos_stride + v];
+                    if (mp >= 0)
+                        maxpos = (unsigned)mp;
+                    // out[i] = (float(maxpos) - fftlen/2) * d_binsize/2   (:84)
+                    const float f = ((float)maxpos - (float)(FS_F / 2)) * p.binsize / 2.0f;
+                    if (p.fhat)
+                        p.fhat[(long)myc * p.fhat_stride + v] = f;
+                    d = p.sensitivity * f;
+                }
+#pragma unroll 8
+                for (int i = 0; i < FSM_CH; i++) {
+                    // [GR] frequency_modulator_fc_impl::work
+                    ph = ph + d;
+                    ph = nco_wrap(ph);
+                    dst[i] = ph;
+                }
             }
-            for (int i = 0; i < FSM_CH; i++) {
-                // [GR] frequency_modulator_fc_impl::work
-                ph = ph + d;
-                ph = nco_wrap(ph);
-                PH[l * FSM_PITCH + i] = ph;
+        } else if (k > 0) {
+            const long k0 = (long)(k - 1) * FSM_CH;
+            const float* src = PH + ((k - 1) & 1) * 64 * FSM_PITCH;
+            const long idx = k0 + l;
+            cf s[FSM_ROWS];
+#pragma unroll
+            for (int q = 0; q < FSM_ROWS; q++) {
+                const int r = (wave - 1) + FSM_MIXW * q;
+                const int c = cbase + r;
+                s[q] = mk(0.f, 0.f);
+                if (r < 64 && c < p.nchan)
+                    s[q] = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
             }
-        }
-        cx.sync();
-        // all waves: channel rows wave, wave+4, ...; lane = sample within the chunk
-        for (int r = wave; r < 64; r += 4) {
-            const int c = cbase + r;
-            if (c < p.nchan) {
-                const long idx = (long)k0 + l;
-                const cf s = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
-                float sn, cs;
-                det_sincos(PH[r * FSM_PITCH + l], &sn, &cs);
-                p.out[(long)c * p.out_stride + idx] = cmul_exact(s, mk(cs, sn));
+#pragma unroll
+            for (int q = 0; q < FSM_ROWS; q++) {
+                const int r = (wave - 1) + FSM_MIXW * q;
+                const int c = cbase + r;
+                if (r < 64 && c < p.nchan) {
+                    float sn, cs;
+                    det_sincos(src[r * FSM_PITCH + l], &sn, &cs);
+                    p.out[(long)c * p.out_stride + idx] = cmul_exact(s[q], mk(cs, sn));
+                }
             }
         }
         cx.sync();
@@ -275,7 +295,7 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
         p.phase[myc] = ph;
     // keep the trailing partial vector (stream_to_vector's pending items)
     const int rem = p.npend + p.n - total;
-    for (int r = wave; r < 64; r += 4) {
+    for (int r = wave; r < 64; r += FSM_T / 64) {
         const int c = cbase + r;
         if (c < p.nchan)
             for (int i = l; i < rem; i += 64) {

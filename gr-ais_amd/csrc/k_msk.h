@@ -34,7 +34,8 @@ constexpr int MSK_LDS_MMSE = 129 * 8 * 4;
 constexpr int MSK_LDS_OSYM = 64 * MSK_OPITCH * 8;
 constexpr int MSK_LDS_OBIT = 64 * MSK_BPITCH;
 constexpr int MSK_LDS_LANE = 4 * 64 * 4; // per-lane scalars published to the wave (ld, pending, ocnt, obase)
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE;
+constexpr int MSK_LDS_ATAN = 260 * 4;
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE + MSK_LDS_ATAN;
 
 struct MskParams {
     int nchan;
@@ -84,10 +85,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int* sh_pend = sh_ld + 64;
     int* sh_ocnt = sh_ld + 128;
     int* sh_obase = sh_ld + 192;
+    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE);
     cf* myring = ring + l * MSK_PITCH;
 
     for (int i = l; i < 129 * 8; i += 64)
         mm[i] = p.mmse[i];
+    for (int i = l; i < 257; i += 64)
+        at[i] = p.atan_tab[i];
 
     const float d_sps = p.d_sps;
     float d_mu = p.mu[cc], d_omega = p.omega[cc];
@@ -121,9 +125,19 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int ntot = nct + nnt;
     int tpos = 0;
     auto tag_at = [&](int k) -> const tag_rec& { return (k < nct) ? ctg[k] : ntg[k - nct]; };
+    // the front of the tag queue is kept in registers: the loop below tests it on
+    // every iteration and must not pay a global load for that
+    unsigned long long nt_off = ~0ull;
+    float nt_val = 0.f;
     auto skip_other_keys = [&]() {
         while (tpos < ntot && tag_at(tpos).key != KEY_TIME_EST)
             tpos++;
+        if (tpos < ntot) {
+            nt_off = tag_at(tpos).offset;
+            nt_val = (float)tag_at(tpos).value;
+        } else {
+            nt_off = ~0ull;
+        }
     };
 
     float* oerr = p.err ? p.err + (long)cc * p.out_stride : nullptr;
@@ -165,7 +179,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         rend = Rc + (unsigned long long)ninp;
         tpos = 0;
         skip_other_keys();
-        while (tpos < ntot && tag_at(tpos).offset < Rc) {
+        while (nt_off < Rc) {
             tpos++;
             skip_other_keys();
         }
@@ -215,10 +229,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             const int pos = base + iidx;
             const bool can = !done && ((pos + 8 + jump_margin <= ld) || (ld >= navail));
             if (can) {
-                if (tpos < ntot && tag_at(tpos).offset < rend) { // tags.size() > 0
-                    const int offset = (int)(tag_at(tpos).offset - Rc);
+                if (nt_off < rend) { // tags.size() > 0
+                    const int offset = (int)(nt_off - Rc);
                     if ((offset >= iidx) && ((float)offset < ((float)iidx + d_sps))) { // :142
-                        const float center = (float)tag_at(tpos).value;
+                        const float center = nt_val;
                         if (center != center) { // NaN :144-147
                             tpos++;
                             skip_other_keys();
@@ -272,7 +286,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                         omu[oo] = d_mu;
                     // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert
                     const cf prod = cmul_exact(in_interp, cconj(tprev));
-                    const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, p.atan_tab);
+                    const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, at);
                     const unsigned char b = fm >= 0 ? 1 : 0;
                     const unsigned char d = (unsigned char)(((unsigned)(b - tbit)) % 2u);
                     obit[l * MSK_BPITCH + ocnt] = (unsigned char)((d ^ 0x01) & 0x01);
