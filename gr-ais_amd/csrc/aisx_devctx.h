@@ -26,6 +26,8 @@ struct DevCtx {
     __device__ __forceinline__ float shfl_xor_f32(float v, int m) const { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ int shfl_xor_i32(int v, int m) const { return __shfl_xor(v, m, 64); }
     __device__ __forceinline__ double shfl_xor_f64(double v, int m) const { return __shfl_xor(v, m, 64); }
+    // value of `v` in lane `lane` (lane must be wave-uniform): v_readlane_b32, no LDS
+    __device__ __forceinline__ int readlane_i32(int v, int lane) const { return __builtin_amdgcn_readlane(v, lane); }
     __device__ __forceinline__ int ctz64(unsigned long long v) const { return __ffsll((long long)v) - 1; }
     __device__ __forceinline__ void atomic_or64(unsigned long long* p, unsigned long long v) const { atomicOr(p, v); }
 };

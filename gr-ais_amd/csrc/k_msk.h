@@ -4,12 +4,13 @@
 //
 // The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
 // is across channels, so one lane owns one channel and a wave owns 64.  What
-// the wave does together is memory: every lane keeps a 256-sample ring of its
-// channel in LDS (row pitch 257 => lanes at equal depth hit distinct banks); per
-// tile the wave tops the rings up with coalesced 64-sample chunks that are
-// issued BEFORE the tile's iterations and written to LDS after them (the loads
-// fly under the recurrence), runs MSK_K iterations per lane out of LDS, and
-// flushes the tile's symbols/bits from an LDS staging buffer with coalesced
+// the wave does together is memory, on a schedule that is the same for every
+// lane: chunk t = new samples [64t, 64t+64) of all 64 channels is fetched with
+// 64 coalesced wave-wide loads issued BEFORE the iterations that consume chunk
+// t-1 (so the loads fly under the recurrence) and landed afterwards in per-lane
+// 256-sample rings in LDS (row pitch 257 => lanes at equal depth hit distinct
+// banks).  Lanes then iterate, each at its own pace, until none can go on without
+// the next chunk.  Symbols/bits are staged in LDS and flushed with coalesced
 // stores.  All arithmetic is the reference's float/double sequence, unfused, so
 // the symbols are bit-identical to the CPU restatement.
 #pragma once
@@ -22,20 +23,19 @@ enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERF
 constexpr int MSK_T = 64;
 constexpr int MSK_RING = 256;   // samples per lane ring (power of two)
 constexpr int MSK_PITCH = 257;  // ring row pitch in complex elements
-constexpr int MSK_CHUNK = 64;   // samples per top-up
-constexpr int MSK_ROOM = 180;   // top up while (loaded - position) <= MSK_ROOM
-constexpr int MSK_K = 28;       // loop iterations per tile
-constexpr int MSK_OB = 32;      // staged outputs per lane per tile (>= MSK_K)
-constexpr int MSK_OPITCH = 33;  // staging row pitch (symbols)
-constexpr int MSK_BPITCH = 36;  // staging row pitch (bits, bytes)
+constexpr int MSK_CHUNK = 64;   // samples per chunk
+constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_OFF) & 255
+constexpr int MSK_OB = 40;      // staged outputs per lane
+constexpr int MSK_OPITCH = 41;  // staging row pitch (symbols)
+constexpr int MSK_BPITCH = 44;  // staging row pitch (bits, bytes)
+constexpr int MSK_FLUSH_AT = 20; // flush once a lane holds this many staged outputs
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_LDS_RING = 64 * MSK_PITCH * 8;
 constexpr int MSK_LDS_MMSE = 129 * 8 * 4;
 constexpr int MSK_LDS_OSYM = 64 * MSK_OPITCH * 8;
 constexpr int MSK_LDS_OBIT = 64 * MSK_BPITCH;
-constexpr int MSK_LDS_LANE = 4 * 64 * 4; // per-lane scalars published to the wave (ld, pending, ocnt, obase)
 constexpr int MSK_LDS_ATAN = 260 * 4;
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE + MSK_LDS_ATAN;
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_ATAN;
 
 struct MskParams {
     int nchan;
@@ -81,11 +81,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     float* mm = (float*)(lds + MSK_LDS_RING);
     cf* osym = (cf*)(lds + MSK_LDS_RING + MSK_LDS_MMSE);
     unsigned char* obit = (unsigned char*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM);
-    int* sh_ld = (int*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT);
-    int* sh_pend = sh_ld + 64;
-    int* sh_ocnt = sh_ld + 128;
-    int* sh_obase = sh_ld + 192;
-    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_LANE);
+    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT);
     cf* myring = ring + l * MSK_PITCH;
 
     for (int i = l; i < 129 * 8; i += 64)
@@ -101,19 +97,18 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     unsigned char tbit = p.tail_prev_bit[cc];
     const unsigned long long R = p.nread[cc];
     int status = 0;
+    const int n = p.n;
 
     // items on offer: logical index q in [-1, navail): q = -1 the item before
-    // nitems_read, then the `pending` carried items, then the n new ones.
+    // nitems_read, then the `pending` carried items, then the n new ones.  The new
+    // sample index is s = q - pending; ring slot of s is (s + MSK_OFF) & 255.
     const cf* cin = p.carry_in + (long)cc * p.carry_cap;
     int pending = p.carry_len_in[cc];
     if (pending > MSK_CARRY_MAX)
         pending = MSK_CARRY_MAX;
-    const int navail = pending + p.n;
-    // ring slot of logical index q is (q + 1) & 255; seed it with the carry
+    const int navail = pending + n;
     for (int q = -1; q < pending; q++)
-        myring[(q + 1) & (MSK_RING - 1)] = cin[q + 1];
-    int ld = pending; // logical index up to which the ring is filled (exclusive)
-    sh_pend[l] = pending;
+        myring[(q - pending + MSK_OFF) & (MSK_RING - 1)] = cin[q + 1];
 
     // logical tag list = carried tags, then this call's tags
     const tag_rec* ctg = p.ctag_in + (long)cc * p.ctag_cap;
@@ -188,35 +183,42 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         setup_round();
     const int jump_margin = (int)ceilf(d_sps) + 1; // a tag may move iidx forward by < d_sps
 
-    cx.sync();
-    for (int tile = 0;; tile++) {
-        // ---------------- top-up: issue the loads ----------------
-        const int pos0 = base + iidx;
-        const bool room = live && (ld < navail) && (ld - pos0 <= MSK_ROOM);
-        sh_ld[l] = ld;
-        const unsigned long long needmask = cx.ballot(room);
-        const unsigned long long livemask = cx.ballot(!done);
-        cx.sync(); // sh_ld visible to the whole wave
-        if (needmask == 0ull && livemask == 0ull)
-            break;
-        cf r[MSK_CHUNK];
-        if (needmask != 0ull) {
+    // chunks cover the new samples plus an 8-sample zero guard: the reference's loop
+    // bound lets the interpolator look a few items past ninput_items when sps < 4;
+    // here those items read as zero
+    const int nchunks = (n + 8 + MSK_CHUNK - 1) / MSK_CHUNK;
+    cf r[MSK_CHUNK];
+    auto issue_chunk = [&](int t) {
+        const int sidx = t * MSK_CHUNK + l;
 #pragma unroll
-            for (int j = 0; j < 64; j++) {
-                r[j] = mk(0.f, 0.f);
-                if ((needmask >> j) & 1ull) {
-                    const int pj = sh_pend[j];
-                    const int q = sh_ld[j] + l;
-                    if (q < pj + p.n) // navail of channel j
-                        r[j] = p.in[(long)(cbase + j) * p.in_stride + (q - pj)];
-                }
-            }
+        for (int j = 0; j < 64; j++) {
+            r[j] = mk(0.f, 0.f);
+            if (sidx < n && (cbase + j) < p.nchan)
+                r[j] = p.in[(long)(cbase + j) * p.in_stride + sidx];
         }
-        // ---------------- the recurrence, MSK_K iterations ----------------
-        int ocnt = 0;
-        const int obase = ototal + oidx;
-        const int kiter = (tile < 3) ? 0 : MSK_K; // the first tiles only prime the rings
-        for (int it = 0; it < kiter; it++) {
+    };
+    auto land_chunk = [&](int t) {
+        const int slot = (t * MSK_CHUNK + l + MSK_OFF) & (MSK_RING - 1);
+#pragma unroll
+        for (int j = 0; j < 64; j++)
+            ring[j * MSK_PITCH + slot] = r[j];
+    };
+    issue_chunk(0);
+    land_chunk(0);
+    int landed = 1; // chunks in the rings
+    cx.sync();
+
+    int ocnt = 0;            // staged outputs of this lane
+    int obase = 0;           // output index of staged output 0
+    for (;;) {
+        if (cx.ballot(!done) == 0ull)
+            break;
+        const bool more = landed < nchunks;
+        if (more)
+            issue_chunk(landed);
+        const int loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
+        // ---------------- the recurrence: every lane goes as far as its data allows ----------------
+        for (;;) {
             if (!done && !(oidx < noutput && iidx < ninp)) { // :138 -- this call is over
                 base += iidx;                                 // consume_each(iidx)
                 ototal += oidx;
@@ -226,8 +228,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 else
                     setup_round();
             }
-            const int pos = base + iidx;
-            const bool can = !done && ((pos + 8 + jump_margin <= ld) || (ld >= navail));
+            const int pos_s = base + iidx - pending;
+            const bool can = !done && (ocnt < MSK_OB) && (!more || (pos_s + 8 + jump_margin <= loaded_s));
+            if (cx.ballot(can) == 0ull)
+                break;
             if (can) {
                 if (nt_off < rend) { // tags.size() > 0
                     const int offset = (int)(nt_off - Rc);
@@ -258,10 +262,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
                 } else {
                     const float* tp = mm + imu * 8;
-                    const int q0 = base + iidx + 1; // ring slot of in[iidx]
+                    const int s0 = base + iidx - pending + MSK_OFF; // ring slot of in[iidx]
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const cf s = myring[(q0 + k) & (MSK_RING - 1)];
+                        const cf s = myring[(s0 + k) & (MSK_RING - 1)];
                         const float tk = tp[7 - k];
                         in_interp.re += s.re * tk;
                         in_interp.im += s.im * tk;
@@ -279,6 +283,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 }
                 if (!(d_div % 2) || p.osps == 2) { // :186-191
                     const int oo = ototal + oidx;
+                    if (ocnt == 0)
+                        obase = oo;
                     osym[l * MSK_OPITCH + ocnt] = in_interp;
                     if (oerr)
                         oerr[oo] = err_out;
@@ -305,51 +311,27 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_mu = d_mu - fl;
             }
         }
-        // ---------------- top-up: land the chunks in the rings ----------------
-        if (needmask != 0ull) {
-#pragma unroll
+        // ---------------- land the prefetched chunk ----------------
+        if (more) {
+            land_chunk(landed);
+            landed++;
+        }
+        // ---------------- flush staged outputs ----------------
+        if (cx.ballot(ocnt >= MSK_FLUSH_AT || (ocnt > 0 && (done || !more))) != 0ull) {
+            cx.sync();
+#pragma unroll 8
             for (int j = 0; j < 64; j++) {
-                if ((needmask >> j) & 1ull) {
-                    const int ldj = sh_ld[j];
-                    // items at or past navail are written as zeros (the reference may read
-                    // a few items past ninput_items for sps < 4)
-                    ring[j * MSK_PITCH + ((ldj + l + 1) & (MSK_RING - 1))] = r[j];
-                }
-            }
-            if (room) {
-                ld += MSK_CHUNK;
-                if (ld >= navail) {
-                    ld = navail;
-                }
-            }
-        }
-        cx.sync();
-        if (room && ld == navail) {
-            // end of input: zero guard for reads past the last item (the reference's loop
-            // bound lets the interpolator look a few items past ninput_items; here they are 0)
-            for (int k = 0; k < 8; k++)
-                myring[(navail + k + 1) & (MSK_RING - 1)] = mk(0.f, 0.f);
-        }
-        // ---------------- flush the tile's outputs ----------------
-        sh_ocnt[l] = ocnt;
-        sh_obase[l] = obase;
-        const bool anyout = cx.ballot(ocnt > 0) != 0ull; // (also orders the LDS stores above)
-        cx.sync();
-        if (anyout) {
-#pragma unroll 4
-            for (int jp = 0; jp < 32; jp++) {
-                const int j = 2 * jp + (l >> 5);
-                const int i = l & 31;
-                const int cnt = sh_ocnt[j];
-                const int ob = sh_obase[j];
-                if (i < cnt && (cbase + j) < p.nchan) {
-                    const long o = (long)(cbase + j) * p.out_stride + ob + i;
+                const int cnt = cx.readlane_i32(ocnt, j);
+                const int ob = cx.readlane_i32(obase, j);
+                if (l < cnt && (cbase + j) < p.nchan) {
+                    const long o = (long)(cbase + j) * p.out_stride + ob + l;
                     if (p.syms)
-                        p.syms[o] = osym[j * MSK_OPITCH + i];
+                        p.syms[o] = osym[j * MSK_OPITCH + l];
                     if (p.bits)
-                        p.bits[o] = obit[j * MSK_BPITCH + i];
+                        p.bits[o] = obit[j * MSK_BPITCH + l];
                 }
             }
+            ocnt = 0;
         }
         cx.sync();
     }
@@ -378,7 +360,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             left = cap - 1;
         }
         for (int k = 0; k <= left; k++)
-            cout[k] = myring[(base - 1 + k + 1) & (MSK_RING - 1)];
+            cout[k] = myring[(base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)];
         p.carry_len_out[c] = left;
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
@@ -395,7 +377,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
     } else {
-        cout[0] = myring[(base - 1 + 1) & (MSK_RING - 1)];
+        cout[0] = myring[(base - 1 - pending + MSK_OFF) & (MSK_RING - 1)];
         p.carry_len_out[c] = 0;
         p.ctag_n_out[c] = 0;
     }

@@ -45,14 +45,18 @@ struct EmuCtx {
     char* lds() const { return sh->lds.data(); }
     void sync() const { sh->bar.arrive_and_wait(); }
     int wave_base() const { return tid_ & ~63; }
+    // wave collectives: one barrier per call; the exchange slots are double-buffered
+    // (bank = parity of this lane's call count; all lanes of a block call in lock-step)
+    mutable unsigned ncall = 0;
+    unsigned long long* bank() const { return sh->x64 + ((ncall++ & 1u) ? 512 : 0); }
     unsigned long long ballot(bool p) const
     {
-        sh->x64[tid_] = p ? 1ull : 0ull;
+        unsigned long long* b = bank();
+        b[tid_] = p ? 1ull : 0ull;
         sync();
         unsigned long long m = 0;
         for (int l = 0; l < 64 && wave_base() + l < sh->nthreads; l++)
-            m |= sh->x64[wave_base() + l] << l;
-        sync();
+            m |= b[wave_base() + l] << l;
         return m;
     }
     template <class T>
@@ -61,13 +65,13 @@ struct EmuCtx {
         static_assert(sizeof(T) <= 8, "");
         unsigned long long raw = 0;
         memcpy(&raw, &v, sizeof(T));
-        sh->x64[tid_] = raw;
+        unsigned long long* b = bank();
+        b[tid_] = raw;
         sync();
         int s = wave_base() + (src_lane & 63);
         if (s >= sh->nthreads)
             s = tid_;
-        unsigned long long r = sh->x64[s];
-        sync();
+        unsigned long long r = b[s];
         T out;
         memcpy(&out, &r, sizeof(T));
         return out;
@@ -80,6 +84,7 @@ struct EmuCtx {
     float shfl_xor_f32(float v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
     int shfl_xor_i32(int v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
     double shfl_xor_f64(double v, int m) const { return xchg(v, (tid_ & 63) ^ m); }
+    int readlane_i32(int v, int lane) const { return xchg(v, lane); }
     int ctz64(unsigned long long v) const { return __builtin_ctzll(v); }
     void atomic_or64(unsigned long long* p, unsigned long long v) const { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 };
