@@ -163,10 +163,9 @@ def main():
     for _ in range(max(3, min(args.steps, 10))):
         step()
         kern_ms.append(corr.last_kernel_ms())
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    from ais_amd.shard import max_over_ranks
+
+    el = max_over_ranks(el, device=device)
 
     if rank == 0:
         total_samples = float(nchan) * T * world * args.steps

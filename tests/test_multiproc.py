@@ -1,0 +1,90 @@
+"""N > 1 path: channel sharding with two `gloo` ranks on the CPU.  The per-rank
+worker here is the CPU oracle (the HIP path needs a GPU); what is under test is
+the sharding arithmetic, the rendezvous and the rank-0 aggregation that
+bench.py --gpus N uses: every channel is processed exactly once and the union of
+the shards equals the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_shard_channels_partition():
+    from ais_amd.shard import shard_channels
+
+    for total in (1, 7, 4096, 65536, 100):
+        for world in (1, 2, 3, 8):
+            got = [shard_channels(total, world, r) for r in range(world)]
+            assert sum(c for _, c in got) == total
+            pos = 0
+            for first, cnt in got:
+                assert first == pos
+                pos += cnt
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    with pytest.raises(ValueError):
+        shard_channels(10, 2, 2)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, os.path.join(ROOT, "gr-ais_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import oracle_py as orc
+    from ais_amd import synth
+    from ais_amd.shard import gather_counts, max_over_ranks, shard_channels
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, cnt = shard_channels(total, world, rank)
+    lv = [1 if b else -1 for b in synth.sync_bits("P")]
+    tmpl = synth.gmsk_waveform(np.array(lv, float), 4)[: len(lv) * 4].astype(np.complex64)
+    ndet = []
+    for c in range(first, first + cnt):
+        x, _ = synth.make_channel(5000 + c, 8192, "P", 4, amp=1.0, cfo_max=10.0)
+        _, _, tags = orc.Demod(4, tmpl, stages=0).step(x)
+        ndet.append(int((tags["key"] == 2).sum()))
+    dist.barrier()
+    allc = gather_counts(np.array(ndet))
+    tmax = max_over_ranks(1.0 + rank)
+    if rank == 0:
+        q.put((allc.tolist(), tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_cover_all_channels():
+    import torch.multiprocessing as mp
+
+    import oracle_py as orc
+    from ais_amd import synth
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    total, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    allc, tmax = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lv = [1 if b else -1 for b in synth.sync_bits("P")]
+    tmpl = synth.gmsk_waveform(np.array(lv, float), 4)[: len(lv) * 4].astype(np.complex64)
+    want = []
+    for c in range(total):
+        x, _ = synth.make_channel(5000 + c, 8192, "P", 4, amp=1.0, cfo_max=10.0)
+        _, _, tags = orc.Demod(4, tmpl, stages=0).step(x)
+        want.append(int((tags["key"] == 2).sum()))
+    assert allc == want and tmax == 2.0
