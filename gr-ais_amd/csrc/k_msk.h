@@ -22,13 +22,13 @@ enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERF
 
 constexpr int MSK_T = 64;
 constexpr int MSK_RING = 256;   // samples per lane ring (power of two)
-constexpr int MSK_PITCH = 257;  // ring row pitch in complex elements
+constexpr int MSK_PITCH = 265;  // ring row pitch: 256 slots + 8 mirror slots (an 8-tap read never wraps) + 1
 constexpr int MSK_CHUNK = 64;   // samples per chunk
 constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_OFF) & 255
-constexpr int MSK_OB = 40;      // staged outputs per lane
-constexpr int MSK_OPITCH = 41;  // staging row pitch (symbols)
-constexpr int MSK_BPITCH = 44;  // staging row pitch (bits, bytes)
-constexpr int MSK_FLUSH_AT = 20; // flush once a lane holds this many staged outputs
+constexpr int MSK_OB = 36;      // staged outputs per lane
+constexpr int MSK_OPITCH = 37;  // staging row pitch (symbols)
+constexpr int MSK_BPITCH = 40;  // staging row pitch (bits, bytes)
+constexpr int MSK_FLUSH_AT = 18; // flush once a lane holds this many staged outputs
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_LDS_RING = 64 * MSK_PITCH * 8;
 constexpr int MSK_LDS_MMSE = 129 * 8 * 4;
@@ -107,8 +107,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     if (pending > MSK_CARRY_MAX)
         pending = MSK_CARRY_MAX;
     const int navail = pending + n;
-    for (int q = -1; q < pending; q++)
-        myring[(q - pending + MSK_OFF) & (MSK_RING - 1)] = cin[q + 1];
+    for (int q = -1; q < pending; q++) {
+        const int slot = (q - pending + MSK_OFF) & (MSK_RING - 1);
+        myring[slot] = cin[q + 1];
+        if (slot < 8)
+            myring[MSK_RING + slot] = cin[q + 1];
+    }
 
     // logical tag list = carried tags, then this call's tags
     const tag_rec* ctg = p.ctag_in + (long)cc * p.ctag_cap;
@@ -124,6 +128,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // every iteration and must not pay a global load for that
     unsigned long long nt_off = ~0ull;
     float nt_val = 0.f;
+    int nt_rel = 0x7fffffff; // offset of the front tag relative to this call's nitems_read, if in range
     auto skip_other_keys = [&]() {
         while (tpos < ntot && tag_at(tpos).key != KEY_TIME_EST)
             tpos++;
@@ -178,6 +183,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             tpos++;
             skip_other_keys();
         }
+        nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
     };
     if (!done)
         setup_round();
@@ -202,6 +208,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #pragma unroll
         for (int j = 0; j < 64; j++)
             ring[j * MSK_PITCH + slot] = r[j];
+        if (((t * MSK_CHUNK + MSK_OFF) & (MSK_RING - 1)) == 0 && l < 8) { // this chunk starts at slot 0: mirror
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                ring[j * MSK_PITCH + MSK_RING + slot] = r[j];
+        }
     };
     issue_chunk(0);
     land_chunk(0);
@@ -219,53 +230,56 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const int loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
         // ---------------- the recurrence: every lane goes as far as its data allows ----------------
         for (;;) {
-            if (!done && !(oidx < noutput && iidx < ninp)) { // :138 -- this call is over
-                base += iidx;                                 // consume_each(iidx)
-                ototal += oidx;
-                const bool progress = (iidx > 0) || (oidx > 0);
-                if (!p.stream_mode || !progress)
-                    done = true;
-                else
-                    setup_round();
+            // (rare) this general_work() call is over (:138): consume, start the next one
+            const bool round_ev = !done && !(oidx < noutput && iidx < ninp);
+            if (cx.ballot(round_ev) != 0ull) {
+                if (round_ev) {
+                    base += iidx; // consume_each(iidx)
+                    ototal += oidx;
+                    const bool progress = (iidx > 0) || (oidx > 0);
+                    if (!p.stream_mode || !progress)
+                        done = true;
+                    else
+                        setup_round();
+                }
             }
             const int pos_s = base + iidx - pending;
             const bool can = !done && (ocnt < MSK_OB) && (!more || (pos_s + 8 + jump_margin <= loaded_s));
             if (cx.ballot(can) == 0ull)
                 break;
-            if (can) {
-                if (nt_off < rend) { // tags.size() > 0
-                    const int offset = (int)(nt_off - Rc);
-                    if ((offset >= iidx) && ((float)offset < ((float)iidx + d_sps))) { // :142
-                        const float center = nt_val;
-                        if (center != center) { // NaN :144-147
-                            tpos++;
-                            skip_other_keys();
-                        } else {
-                            d_mu = center;
-                            iidx = offset;
-                            if (d_mu < 0) {
-                                d_mu++;
-                                iidx--;
-                            }
-                            d_div = 0;
-                            d_omega = d_sps;
-                            d_dly_conj_2 = d_dly_conj_1;
-                            tpos++;
-                            skip_other_keys();
+            // (rare) a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
+            const bool tag_ev = can && (nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps));
+            if (cx.ballot(tag_ev) != 0ull) {
+                if (tag_ev) {
+                    const float center = nt_val;
+                    if (center == center) { // not NaN (:144-147)
+                        d_mu = center;
+                        iidx = nt_rel;
+                        if (d_mu < 0) {
+                            d_mu++;
+                            iidx--;
                         }
+                        d_div = 0;
+                        d_omega = d_sps;
+                        d_dly_conj_2 = d_dly_conj_1;
                     }
+                    tpos++;
+                    skip_other_keys();
+                    nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
                 }
+            }
+            if (can) {
                 // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
-                const int imu = (int)rint(d_mu * 128.0f);
+                const int imu = (int)rintf(d_mu * 128.0f);
                 cf in_interp = mk(0.f, 0.f);
                 if (imu < 0 || imu > 128) {
                     status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
                 } else {
                     const float* tp = mm + imu * 8;
-                    const int s0 = base + iidx - pending + MSK_OFF; // ring slot of in[iidx]
+                    const cf* sp = myring + ((base + iidx - pending + MSK_OFF) & (MSK_RING - 1));
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const cf s = myring[(s0 + k) & (MSK_RING - 1)];
+                        const cf s = sp[k]; // mirror slots: no wrap inside the 8 taps
                         const float tk = tp[7 - k];
                         in_interp.re += s.re * tk;
                         in_interp.im += s.im * tk;
@@ -275,13 +289,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 const cf dly_conj = cconj(cmul_exact(d_dly_conj_2, d_dly_conj_2)); // :173
                 const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
                 float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
-                if (d_div % 2) {                                                   // :179-184
+                if (d_div & 1) {                                                   // :179-184
                     err_out = branchless_clip(err_out, 3.0f);
                     d_omega += p.gain_omega * err_out;
                     d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
                     d_mu += p.gain * err_out;
                 }
-                if (!(d_div % 2) || p.osps == 2) { // :186-191
+                if (!(d_div & 1) || p.osps == 2) { // :186-191
                     const int oo = ototal + oidx;
                     if (ocnt == 0)
                         obase = oo;
