@@ -74,52 +74,32 @@ AISX_HD float branchless_clip(float x, float clip)
     return 0.5f * x1;
 }
 
-// gr::fast_atan2f (gnuradio-runtime fast_atan2f.cc); `tab` = 257-entry table
+// gr::fast_atan2f (gnuradio-runtime fast_atan2f.cc); `tab` = 257-entry table.
+// Written with selects instead of the upstream if/else ladder (a divergent
+// ladder costs a wave every arm); every arithmetic operation and operand is the
+// one the upstream code executes on the arm it would take, so the result is
+// bit-identical (tests/test_oracle_kat.py checks it against the ladder).
 AISX_HD float fast_atan2f_tab(float y, float x, const float* tab)
 {
     const float TAN_MAP_RES = 0.003921569f;
-    float y_abs = fabsf(y), x_abs = fabsf(x), z, base_angle, angle;
-    if (!((y_abs > 0.0f) || (x_abs > 0.0f)))
-        return 0.0f;
-    if (y_abs < x_abs)
-        z = fdiv_rn(y_abs, x_abs);
-    else
-        z = fdiv_rn(x_abs, y_abs);
-    if (z < TAN_MAP_RES) {
-        base_angle = z;
-    } else {
-        float alpha = z * 255.0f;
-        int index = ((int)alpha) & 0xff;
-        alpha -= (float)index;
-        base_angle = tab[index];
-        base_angle += (tab[index + 1] - tab[index]) * alpha;
-    }
-    if (x_abs > y_abs) {
-        if (x >= 0.0f) {
-            angle = (y >= 0.0f) ? base_angle : -base_angle;
-        } else {
-            angle = 3.14159265358979323846f;
-            if (y >= 0.0f)
-                angle -= base_angle;
-            else
-                angle = base_angle - angle;
-        }
-    } else {
-        if (y >= 0.0f) {
-            angle = 1.57079632679489661923f;
-            if (x >= 0.0f)
-                angle -= base_angle;
-            else
-                angle += base_angle;
-        } else {
-            angle = -1.57079632679489661923f;
-            if (x >= 0.0f)
-                angle += base_angle;
-            else
-                angle -= base_angle;
-        }
-    }
-    return angle;
+    const float PI_F = 3.14159265358979323846f, PI2_F = 1.57079632679489661923f;
+    const float y_abs = fabsf(y), x_abs = fabsf(x);
+    const bool ylt = y_abs < x_abs;
+    const float z = fdiv_rn(ylt ? y_abs : x_abs, ylt ? x_abs : y_abs);
+    float alpha = z * 255.0f;
+    const int index = ((int)alpha) & 0xff;
+    alpha -= (float)index;
+    const float t0 = tab[index], t1 = tab[index + 1];
+    float base_angle = t0 + (t1 - t0) * alpha;
+    base_angle = (z < TAN_MAP_RES) ? z : base_angle;
+    const bool xge = x >= 0.0f, yge = y >= 0.0f;
+    // x_abs > y_abs: -45..45 or 135..225
+    const float a_h = xge ? (yge ? base_angle : -base_angle) : (yge ? (PI_F - base_angle) : (base_angle - PI_F));
+    // otherwise: 45..135 or -135..-45
+    const float a_v = yge ? (xge ? (PI2_F - base_angle) : (PI2_F + base_angle))
+                          : (xge ? (-PI2_F + base_angle) : (-PI2_F - base_angle));
+    const float angle = (x_abs > y_abs) ? a_h : a_v;
+    return ((y_abs > 0.0f) || (x_abs > 0.0f)) ? angle : 0.0f;
 }
 
 // Deterministic sin/cos for the NCO: plain IEEE double + and * only, so the

@@ -31,7 +31,8 @@ constexpr int MSK_BPITCH = 40;  // staging row pitch (bits, bytes)
 constexpr int MSK_FLUSH_AT = 18; // flush once a lane holds this many staged outputs
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_LDS_RING = 64 * MSK_PITCH * 8;
-constexpr int MSK_LDS_MMSE = 129 * 8 * 4;
+constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
+constexpr int MSK_LDS_MMSE = ((129 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
 constexpr int MSK_LDS_OSYM = 64 * MSK_OPITCH * 8;
 constexpr int MSK_LDS_OBIT = 64 * MSK_BPITCH;
 constexpr int MSK_LDS_ATAN = 260 * 4;
@@ -85,7 +86,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     cf* myring = ring + l * MSK_PITCH;
 
     for (int i = l; i < 129 * 8; i += 64)
-        mm[i] = p.mmse[i];
+        mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
     for (int i = l; i < 257; i += 64)
         at[i] = p.atan_tab[i];
 
@@ -93,6 +94,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     float d_mu = p.mu[cc], d_omega = p.omega[cc];
     int d_div = p.div[cc];
     cf d_dly_conj_1 = p.dly1[cc], d_dly_conj_2 = p.dly2[cc], d_dly_diff_1 = p.diff1[cc];
+    cf prev_sq = cmul_exact(d_dly_conj_2, d_dly_conj_2);
     cf tprev = p.tail_prev_sym[cc];
     unsigned char tbit = p.tail_prev_bit[cc];
     const unsigned long long R = p.nread[cc];
@@ -261,7 +263,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                         }
                         d_div = 0;
                         d_omega = d_sps;
-                        d_dly_conj_2 = d_dly_conj_1;
+                        d_dly_conj_2 = d_dly_conj_1; // (prev_sq already is d_dly_conj_1^2)
                     }
                     tpos++;
                     skip_other_keys();
@@ -275,7 +277,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 if (imu < 0 || imu > 128) {
                     status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
                 } else {
-                    const float* tp = mm + imu * 8;
+                    const float* tp = mm + imu * MSK_TAPS_PITCH;
                     const cf* sp = myring + ((base + iidx - pending + MSK_OFF) & (MSK_RING - 1));
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -286,7 +288,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     }
                 }
                 const cf sq = cmul_exact(in_interp, in_interp);                    // :171
-                const cf dly_conj = cconj(cmul_exact(d_dly_conj_2, d_dly_conj_2)); // :173
+                // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
+                // (:194-195, also after a tag reset :160), so its square is the previous sq
+                const cf dly_conj = cconj(prev_sq);
                 const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
                 float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
                 if (d_div & 1) {                                                   // :179-184
@@ -318,6 +322,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_div++;
                 d_dly_conj_1 = in_interp; // :194-196
                 d_dly_conj_2 = d_dly_conj_1;
+                prev_sq = sq;
                 d_dly_diff_1 = nlin_out;
                 d_mu += d_omega; // :199-201
                 const float fl = floorf(d_mu);

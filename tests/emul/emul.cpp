@@ -298,6 +298,7 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
     return h->status[0];
 }
 
+float emu_fast_atan2f(float y, float x) { return fast_atan2f_tab(y, x, aisx_atan_table); }
 const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
 const float* emu_atan_table() { return aisx_atan_table; }
 

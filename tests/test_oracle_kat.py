@@ -159,3 +159,25 @@ def test_gmsk_template_shape():
     t = orc.gmsk_modulate_vector(4, 0.4, [1, 1, 0, 0] * 7)
     assert t.size == 224 * 4  # packed bytes -> 224 symbols
     assert np.allclose(np.abs(t), 1.0, atol=1e-6)
+
+
+def test_select_form_of_fast_atan2f_equals_the_ladder():
+    # the HIP kernels evaluate fast_atan2f with selects; the CPU lane model
+    # exports that very function -- it must equal the oracle's if/else ladder bit for bit
+    import ctypes as C
+
+    import emul_py as emu
+
+    L = emu.lib()
+    L.emu_fast_atan2f.restype = C.c_float
+    L.emu_fast_atan2f.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(8)
+    vals = list(rng.normal(size=4000).astype(np.float32)) + [0.0, -0.0, 1.0, -1.0, 1e-38, -1e-38, 1e-45, -1e-45, 3e38,
+                                                              -3e38, np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan)]
+    vals = [float(v) for v in vals]
+    pairs = [(vals[i], vals[(7 * i + 3) % len(vals)]) for i in range(len(vals))]
+    pairs += [(a, b) for a in vals[-13:] for b in vals[-13:]]
+    for y, x in pairs:
+        a = np.float32(L.emu_fast_atan2f(y, x))
+        b = np.float32(orc.fast_atan2f(y, x))
+        assert a.tobytes() == b.tobytes() or (np.isnan(a) and np.isnan(b)), (y, x, a, b)
