@@ -49,7 +49,7 @@ __global__ __launch_bounds__(CF_T) void k_corr_inith(CorrInitParams p)
     corr_inith_body(cx, p);
 }
 
-__global__ __launch_bounds__(CF_T) void k_corr_main(CorrParams p)
+__global__ __launch_bounds__(CF_T, 3) void k_corr_main(CorrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
