@@ -58,13 +58,31 @@ inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored)
 }
 
 // grid of the main kernel: (nseg, nchan) workgroups, each walking tiles_per_seg
-// consecutive tiles of L outputs of one channel
+// consecutive tiles of L outputs of one channel.  The segment count is chosen so
+// that the grid is close to a whole number of full-chip rounds (256 CUs x 6
+// resident workgroups at 154 VGPRs / 18 KB LDS): a ragged last round is pure loss
+// for a kernel whose workgroups all take the same time.
 inline void corr_grid(int nchan, int n, int L, int* nseg, int* tiles_per_seg)
 {
     const int ntiles = (n + L - 1) / L;
-    int ns = (2048 + nchan - 1) / nchan;
-    ns = std::max(1, std::min(ns, std::max(1, ntiles / 4)));
-    const int tps = (ntiles + ns - 1) / ns;
+    const long slots = 256L * 6;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ns = 1; ns <= 16; ns++) {
+        const int tps = (ntiles + ns - 1) / ns;
+        if (ns > 1 && tps < 6)
+            break; // keep segments long: each one re-reads N samples of overlap
+        const int real_ns = (ntiles + tps - 1) / tps;
+        const long wgs = (long)nchan * real_ns;
+        const long rounds = (wgs + slots - 1) / slots;
+        // time ~ rounds * tiles per workgroup (+ a little for the extra overlap reads)
+        const double cost = (double)rounds * tps * (1.0 + 0.01 * real_ns);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = real_ns;
+        }
+    }
+    const int tps = (ntiles + best - 1) / best;
     *nseg = (ntiles + tps - 1) / tps;
     *tiles_per_seg = tps;
 }
