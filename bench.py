@@ -67,6 +67,21 @@ def make_input(nchan, T, family, sps, device, rank, stock):
     return x
 
 
+def pmc_traffic(nchan, T, N):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    summary (collected in separate --pmc passes, see profiles/), if it was taken on
+    this workload; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_corr_main_pmc.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = d.get("workload", {})
+    if (w.get("channels"), w.get("samples"), w.get("template_len")) != (nchan, T, N):
+        return None
+    return d.get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(chain, family, sps, T, nch=32):
     """The CPU oracle (a plain-C port of the reference's algorithm, single
     thread) on a bounded sample of the same workload."""
@@ -204,7 +219,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(nchan, T, int(tmpl.size)),
+                "traffic_source": "profiles/r01_corr_main_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                 "kernel_ms": kms,
                 "algorithmic_bytes_per_launch": CORR_BYTES_PER_SAMPLE * float(nchan) * T,
             },
