@@ -190,7 +190,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     if (!done)
         setup_round();
     const int jump_margin = (int)ceilf(d_sps) + 1; // a tag may move iidx forward by < d_sps
-    const int adv1 = (int)floorf(1.0f + d_sps + fabsf(p.limit)) + 1; // > any advance of an iteration without loop update
 
     // chunks cover the new samples plus an 8-sample zero guard: the reference's loop
     // bound lets the interpolator look a few items past ninput_items when sps < 4;
@@ -271,9 +270,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
                 }
             }
-            // one loop iteration (:170-201); `upd` = the error loop runs (d_div odd),
-            // `outp` = a symbol is emitted (d_div even, or osps == 2)
-            auto iterate = [&](bool upd, bool outp) {
+            if (can) {
                 // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
                 const int imu = (int)rintf(d_mu * 128.0f);
                 cf in_interp = mk(0.f, 0.f);
@@ -290,19 +287,19 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                         in_interp.im += s.im * tk;
                     }
                 }
-                const cf sq = cmul_exact(in_interp, in_interp); // :171
+                const cf sq = cmul_exact(in_interp, in_interp);                    // :171
                 // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
                 // (:194-195, also after a tag reset :160), so its square is the previous sq
                 const cf dly_conj = cconj(prev_sq);
-                const cf nlin_out = cmul_exact(sq, dly_conj); // :174
-                float err_out = (nlin_out - d_dly_diff_1).re;   // :178
-                if (upd) {                                      // :179-184
+                const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
+                float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
+                if (d_div & 1) {                                                   // :179-184
                     err_out = branchless_clip(err_out, 3.0f);
                     d_omega += p.gain_omega * err_out;
                     d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
                     d_mu += p.gain * err_out;
                 }
-                if (outp) { // :186-191
+                if (!(d_div & 1) || p.osps == 2) { // :186-191
                     const int oo = ototal + oidx;
                     if (ocnt == 0)
                         obase = oo;
@@ -331,22 +328,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 const float fl = floorf(d_mu);
                 iidx += (int)fl;
                 d_mu = d_mu - fl;
-            };
-            // Fast path: an even iteration and the odd one after it, back to back, when
-            // neither can hit a tag, the end of the call, the end of the loaded data or
-            // a full staging row.  adv1 bounds the first iteration's advance:
-            // floor(mu + omega) with mu < 1, omega <= d_sps + limit.
-            const bool fast2 = can && !tag_ev && (p.osps == 1) && !(d_div & 1) && (oidx + 1 < noutput) && (iidx + adv1 < ninp) &&
-                               (nt_rel < iidx || nt_rel >= iidx + adv1 + jump_margin) &&
-                               (!more || (pos_s + adv1 + 8 <= loaded_s)) && (ocnt + 1 <= MSK_OB);
-            if (cx.ballot(can && !fast2) == 0ull) {
-                if (can) {
-                    iterate(false, true);
-                    iterate(true, false);
-                }
-            } else if (can) {
-                const bool odd = (d_div & 1) != 0;
-                iterate(odd, !odd || p.osps == 2);
             }
         }
         // ---------------- land the prefetched chunk ----------------
