@@ -3,16 +3,18 @@
 // :62-64 fused into the epilogue.
 //
 // The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
-// is across channels, so one lane owns one channel and a wave owns 64.  What
-// the wave does together is memory, on a schedule that is the same for every
-// lane: chunk t = new samples [64t, 64t+64) of all 64 channels is fetched with
-// 64 coalesced wave-wide loads issued BEFORE the iterations that consume chunk
-// t-1 (so the loads fly under the recurrence) and landed afterwards in per-lane
-// 256-sample rings in LDS (row pitch 257 => lanes at equal depth hit distinct
-// banks).  Lanes then iterate, each at its own pace, until none can go on without
-// the next chunk.  Symbols/bits are staged in LDS and flushed with coalesced
-// stores.  All arithmetic is the reference's float/double sequence, unfused, so
-// the symbols are bit-identical to the CPU restatement.
+// is across channels, so one lane owns one channel and a wave owns 64.  Every
+// lane keeps a ring of the last 256 samples of its channel in LDS, stored
+// slot-major (ring[slot][lane]): a lane always touches its own pair of banks, so
+// the 8-tap reads are conflict free however far the lanes drift apart, and a
+// chunk lands with conflict-free stores.  The memory schedule is the same for all
+// lanes: chunk t = new samples [64t, 64t+64) of every channel is fetched (one
+// 16-byte load per lane per two samples, each lane walking its own row, issued
+// BEFORE the iterations that consume chunk t-1 so the loads fly under the
+// recurrence) and landed afterwards; lanes then iterate, each at its own pace,
+// until none can go on without the next chunk.  Symbols and bits are stored
+// straight from the loop (fire and forget).  All arithmetic is the reference's
+// float/double sequence, unfused: bit-identical to the CPU restatement.
 #pragma once
 #include "aisx_common.h"
 
@@ -21,22 +23,16 @@ namespace aisx {
 enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERFLOW = 4, MSK_ST_OUT_FULL = 8 };
 
 constexpr int MSK_T = 64;
-constexpr int MSK_RING = 256;   // samples per lane ring (power of two)
-constexpr int MSK_PITCH = 265;  // ring row pitch: 256 slots + 8 mirror slots (an 8-tap read never wraps) + 1
+constexpr int MSK_RING = 256;   // slots per lane (power of two)
+constexpr int MSK_SLOTS = MSK_RING + 8; // + 8 mirror slots: an 8-tap read never wraps
 constexpr int MSK_CHUNK = 64;   // samples per chunk
 constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_OFF) & 255
-constexpr int MSK_OB = 36;      // staged outputs per lane
-constexpr int MSK_OPITCH = 37;  // staging row pitch (symbols)
-constexpr int MSK_BPITCH = 40;  // staging row pitch (bits, bytes)
-constexpr int MSK_FLUSH_AT = 18; // flush once a lane holds this many staged outputs
 constexpr int MSK_CARRY_MAX = 128;
-constexpr int MSK_LDS_RING = 64 * MSK_PITCH * 8;
 constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
+constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
 constexpr int MSK_LDS_MMSE = ((129 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
-constexpr int MSK_LDS_OSYM = 64 * MSK_OPITCH * 8;
-constexpr int MSK_LDS_OBIT = 64 * MSK_BPITCH;
 constexpr int MSK_LDS_ATAN = 260 * 4;
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT + MSK_LDS_ATAN;
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_ATAN;
 
 struct MskParams {
     int nchan;
@@ -78,12 +74,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
     char* lds = cx.lds();
-    cf* ring = (cf*)lds;
+    cf* ring = (cf*)lds;                       // [MSK_SLOTS][64]
     float* mm = (float*)(lds + MSK_LDS_RING);
-    cf* osym = (cf*)(lds + MSK_LDS_RING + MSK_LDS_MMSE);
-    unsigned char* obit = (unsigned char*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM);
-    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_OSYM + MSK_LDS_OBIT);
-    cf* myring = ring + l * MSK_PITCH;
+    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE);
+    cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
 
     for (int i = l; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
@@ -111,9 +105,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int navail = pending + n;
     for (int q = -1; q < pending; q++) {
         const int slot = (q - pending + MSK_OFF) & (MSK_RING - 1);
-        myring[slot] = cin[q + 1];
+        myring[slot * 64] = cin[q + 1];
         if (slot < 8)
-            myring[MSK_RING + slot] = cin[q + 1];
+            myring[(MSK_RING + slot) * 64] = cin[q + 1];
     }
 
     // logical tag list = carried tags, then this call's tags
@@ -144,6 +138,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 
     float* oerr = p.err ? p.err + (long)cc * p.out_stride : nullptr;
     float* omu = p.mu_out ? p.mu_out + (long)cc * p.out_stride : nullptr;
+    cf* osymg = p.syms ? p.syms + (long)cc * p.out_stride : nullptr;
+    unsigned char* obitg = p.bits ? p.bits + (long)cc * p.out_stride : nullptr;
 
     // ---- "scheduler": one general_work() call after another (stream mode) ----
     int base = 0, ototal = 0;     // items consumed / produced by finished calls
@@ -195,25 +191,28 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // bound lets the interpolator look a few items past ninput_items when sps < 4;
     // here those items read as zero
     const int nchunks = (n + 8 + MSK_CHUNK - 1) / MSK_CHUNK;
+    // chunk fetch: lane l walks its own channel row (64 samples = 512 contiguous bytes per
+    // lane and chunk; the 16 lines involved stay in L1 across the 32 load instructions)
     cf r[MSK_CHUNK];
+    const cf* myin = p.in + (long)cc * p.in_stride;
     auto issue_chunk = [&](int t) {
-        const int sidx = t * MSK_CHUNK + l;
+        const int s0 = t * MSK_CHUNK;
 #pragma unroll
-        for (int j = 0; j < 64; j++) {
-            r[j] = mk(0.f, 0.f);
-            if (sidx < n && (cbase + j) < p.nchan)
-                r[j] = p.in[(long)(cbase + j) * p.in_stride + sidx];
+        for (int k = 0; k < MSK_CHUNK; k++) {
+            r[k] = mk(0.f, 0.f);
+            if (live && s0 + k < n)
+                r[k] = myin[s0 + k];
         }
     };
     auto land_chunk = [&](int t) {
-        const int slot = (t * MSK_CHUNK + l + MSK_OFF) & (MSK_RING - 1);
+        const int slot0 = (t * MSK_CHUNK + MSK_OFF) & (MSK_RING - 1); // multiple of 64
 #pragma unroll
-        for (int j = 0; j < 64; j++)
-            ring[j * MSK_PITCH + slot] = r[j];
-        if (((t * MSK_CHUNK + MSK_OFF) & (MSK_RING - 1)) == 0 && l < 8) { // this chunk starts at slot 0: mirror
+        for (int k = 0; k < MSK_CHUNK; k++)
+            myring[(slot0 + k) * 64] = r[k];
+        if (slot0 == 0) { // mirror the first 8 slots behind slot 255
 #pragma unroll
-            for (int j = 0; j < 64; j++)
-                ring[j * MSK_PITCH + MSK_RING + slot] = r[j];
+            for (int k = 0; k < 8; k++)
+                myring[(MSK_RING + k) * 64] = r[k];
         }
     };
     issue_chunk(0);
@@ -221,8 +220,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int landed = 1; // chunks in the rings
     cx.sync();
 
-    int ocnt = 0;            // staged outputs of this lane
-    int obase = 0;           // output index of staged output 0
     for (;;) {
         if (cx.ballot(!done) == 0ull)
             break;
@@ -246,7 +243,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 }
             }
             const int pos_s = base + iidx - pending;
-            const bool can = !done && (ocnt < MSK_OB) && (!more || (pos_s + 8 + jump_margin <= loaded_s));
+            const bool can = !done && (!more || (pos_s + 8 + jump_margin <= loaded_s));
             if (cx.ballot(can) == 0ull)
                 break;
             // (rare) a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
@@ -278,10 +275,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
                 } else {
                     const float* tp = mm + imu * MSK_TAPS_PITCH;
-                    const cf* sp = myring + ((base + iidx - pending + MSK_OFF) & (MSK_RING - 1));
+                    const cf* sp = myring + ((base + iidx - pending + MSK_OFF) & (MSK_RING - 1)) * 64;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const cf s = sp[k]; // mirror slots: no wrap inside the 8 taps
+                        const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
                         const float tk = tp[7 - k];
                         in_interp.re += s.re * tk;
                         in_interp.im += s.im * tk;
@@ -301,9 +298,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 }
                 if (!(d_div & 1) || p.osps == 2) { // :186-191
                     const int oo = ototal + oidx;
-                    if (ocnt == 0)
-                        obase = oo;
-                    osym[l * MSK_OPITCH + ocnt] = in_interp;
+                    if (osymg)
+                        osymg[oo] = in_interp;
                     if (oerr)
                         oerr[oo] = err_out;
                     if (omu)
@@ -313,10 +309,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, at);
                     const unsigned char b = fm >= 0 ? 1 : 0;
                     const unsigned char d = (unsigned char)(((unsigned)(b - tbit)) % 2u);
-                    obit[l * MSK_BPITCH + ocnt] = (unsigned char)((d ^ 0x01) & 0x01);
+                    if (obitg)
+                        obitg[oo] = (unsigned char)((d ^ 0x01) & 0x01);
                     tprev = in_interp;
                     tbit = b;
-                    ocnt++;
                     oidx++;
                 }
                 d_div++;
@@ -334,23 +330,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (more) {
             land_chunk(landed);
             landed++;
-        }
-        // ---------------- flush staged outputs ----------------
-        if (cx.ballot(ocnt >= MSK_FLUSH_AT || (ocnt > 0 && (done || !more))) != 0ull) {
-            cx.sync();
-#pragma unroll 8
-            for (int j = 0; j < 64; j++) {
-                const int cnt = cx.readlane_i32(ocnt, j);
-                const int ob = cx.readlane_i32(obase, j);
-                if (l < cnt && (cbase + j) < p.nchan) {
-                    const long o = (long)(cbase + j) * p.out_stride + ob + l;
-                    if (p.syms)
-                        p.syms[o] = osym[j * MSK_OPITCH + l];
-                    if (p.bits)
-                        p.bits[o] = obit[j * MSK_BPITCH + l];
-                }
-            }
-            ocnt = 0;
         }
         cx.sync();
     }
@@ -379,7 +358,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             left = cap - 1;
         }
         for (int k = 0; k <= left; k++)
-            cout[k] = myring[(base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)];
+            cout[k] = myring[((base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)) * 64];
         p.carry_len_out[c] = left;
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
@@ -396,7 +375,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
     } else {
-        cout[0] = myring[(base - 1 - pending + MSK_OFF) & (MSK_RING - 1)];
+        cout[0] = myring[((base - 1 - pending + MSK_OFF) & (MSK_RING - 1)) * 64];
         p.carry_len_out[c] = 0;
         p.ctag_n_out[c] = 0;
     }
