@@ -141,20 +141,39 @@ def main():
                             preamble_symbols=tmpl)
     corr = dem.preamble_detect
     corr.set_profiling(True)
-    # preallocated inter-stage buffers
-    y_corr = torch.empty((nchan, T), dtype=torch.complex64, device=device)
+    # preallocated inter-stage buffers, double-buffered by step parity: the timing
+    # recovery of step k (latency-bound, 64 waves) runs on its own stream under the
+    # bandwidth-bound stages of step k+1
+    y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(2)]
     cap = dem.clockrec.out_capacity
-    outs = dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
-                produced=torch.empty(nchan, dtype=torch.int32, device=device))
+    outs = [dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
+                 produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(2)]
+    s_main, s_msk = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    msk_done = [None, None]
+    state = dict(k=0)
 
     def step():
-        y = x
-        if stock:
-            y, _ = dem.freq_sync.work(y)
-            y = dem.agc.work(y)
-        o, _ = corr.work(y, out=y_corr if y.shape[1] == T else None)
+        k = state["k"]
+        par = k & 1
+        with torch.cuda.stream(s_main):
+            if msk_done[par] is not None:
+                s_main.wait_event(msk_done[par])  # step k-2 released y_corr[par] and its tags
+            y = x
+            if stock:
+                y, _ = dem.freq_sync.work(y)
+                y = dem.agc.work(y)
+            o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
+            tags_ptrs = corr.tags_device()
+            ready = torch.cuda.Event()
+            ready.record(s_main)
         if args.chain != "corr":
-            dem.clockrec.work(o, tags_from=corr, outs=outs)
+            with torch.cuda.stream(s_msk):
+                s_msk.wait_event(ready)
+                dem.clockrec.work(o, tags_ptrs=tags_ptrs, outs=outs[par])
+                ev = torch.cuda.Event()
+                ev.record(s_msk)
+                msk_done[par] = ev
+        state["k"] = k + 1
 
     def barrier():
         if world > 1:

@@ -184,7 +184,8 @@ class msk_timing_recovery_cc:
     def reset(self):
         check(_lib.lib().aisx_msk_reset(self._h), "reset")
 
-    def work(self, x, tags_from=None, want_syms=True, want_aux=False, want_bits=True, stream=None, outs=None):
+    def work(self, x, tags_from=None, want_syms=True, want_aux=False, want_bits=True, stream=None, outs=None,
+             tags_ptrs=None):
         """One stream step on x[nchan][n] new items.  `tags_from` = the
         corr_est_cc block whose last call produced the time_est tags (or None).
         Returns dict(syms, err, mu, bits, produced) of device tensors."""
@@ -198,7 +199,9 @@ class msk_timing_recovery_cc:
         mu = o.get("mu") if "mu" in o else (torch.empty((self.nchan, cap), dtype=torch.float32, device=dev) if want_aux else None)
         bits = o.get("bits") if "bits" in o else (torch.empty((self.nchan, cap), dtype=torch.uint8, device=dev) if want_bits else None)
         prod = o.get("produced") if "produced" in o else torch.empty(self.nchan, dtype=torch.int32, device=dev)
-        if tags_from is not None:
+        if tags_ptrs is not None:
+            tptr, cptr, tcap = tags_ptrs  # as returned by corr_est_cc.tags_device() right after its work()
+        elif tags_from is not None:
             tptr, cptr, tcap = tags_from.tags_device()
         else:
             tptr, cptr, tcap = None, None, 0

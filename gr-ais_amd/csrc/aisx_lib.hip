@@ -94,6 +94,11 @@ struct aisx_corr {
     long abits_stride = 0;
     cf* d_scratch = nullptr;
     long scratch_stride = 0;
+    // tags are double-buffered by call parity so that a consumer on another stream
+    // (the timing-recovery kernel) can still read call k's tags while call k+1 runs
+    tag_rec* d_tags2[2] = { nullptr, nullptr };
+    int* d_tag_count2[2] = { nullptr, nullptr };
+    int tag_cur = 0; // buffer the LAST call wrote
     tag_rec* d_tags = nullptr;
     int* d_tag_count = nullptr;
     float* d_atan = nullptr;
@@ -170,8 +175,12 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     CK(dev_alloc(&h->d_hist[1], (size_t)nchan * nsym));
     CK(dev_alloc(&h->d_abits, (size_t)nchan * h->abits_stride));
     CK(dev_alloc(&h->d_scratch, (size_t)nchan * h->scratch_stride, false));
-    CK(dev_alloc(&h->d_tags, (size_t)nchan * h->tag_cap));
-    CK(dev_alloc(&h->d_tag_count, nchan));
+    for (int k = 0; k < 2; k++) {
+        CK(dev_alloc(&h->d_tags2[k], (size_t)nchan * h->tag_cap));
+        CK(dev_alloc(&h->d_tag_count2[k], nchan));
+    }
+    h->d_tags = h->d_tags2[0];
+    h->d_tag_count = h->d_tag_count2[0];
     CK(dev_alloc(&h->d_atan, 257));
     if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * CF_F, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
@@ -197,8 +206,10 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_hist[1]);
     dev_free(h->d_abits);
     dev_free(h->d_scratch);
-    dev_free(h->d_tags);
-    dev_free(h->d_tag_count);
+    for (int k = 0; k < 2; k++) {
+        dev_free(h->d_tags2[k]);
+        dev_free(h->d_tag_count2[k]);
+    }
     dev_free(h->d_atan);
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
@@ -308,6 +319,9 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.mark_delay = h->mark_delay;
     r.written = h->written;
     r.emit_port1 = d_corr ? 1 : 0;
+    h->tag_cur ^= 1;
+    h->d_tags = h->d_tags2[h->tag_cur];
+    h->d_tag_count = h->d_tag_count2[h->tag_cur];
     r.tags = h->d_tags;
     r.tag_cap = h->tag_cap;
     r.tag_count = h->d_tag_count;
