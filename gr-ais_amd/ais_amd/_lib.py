@@ -67,6 +67,7 @@ def lib():
     sig("aisx_corr_process", i32, [vp, vp, lng, vp, lng, vp, lng, i32, vp])
     sig("aisx_corr_set_profiling", i32, [vp, i32])
     sig("aisx_corr_last_kernel_ms", i32, [vp, C.POINTER(C.c_float)])
+    sig("aisx_corr_kernel_ms_history", i32, [vp, C.POINTER(C.c_float), i32, pi32])
     sig("aisx_corr_tags_device", i32, [vp, pvp, pvp, pi32])
     sig("aisx_corr_read_tags", i32, [vp, vp, i32, pi32, vp])
     sig("aisx_corr_work_host", i32, [vp, vp, vp, vp, i32, u64, vp, i32, pi32])

@@ -111,6 +111,12 @@ class corr_est_cc:
         check(_lib.lib().aisx_corr_last_kernel_ms(self._h, C.byref(ms)), "last_kernel_ms")
         return ms.value
 
+    def kernel_ms_history(self):
+        buf = (C.c_float * 64)()
+        n = C.c_int(0)
+        check(_lib.lib().aisx_corr_kernel_ms_history(self._h, buf, 64, C.byref(n)), "kernel_ms_history")
+        return [float(buf[i]) for i in range(n.value)]
+
     def tags_device(self):
         t, c, cap = C.c_void_p(), C.c_void_p(), C.c_int()
         check(_lib.lib().aisx_corr_tags_device(self._h, C.byref(t), C.byref(c), C.byref(cap)), "tags_device")

@@ -105,7 +105,9 @@ struct aisx_corr {
     uint64_t written = 0;
     int last_emit_port1 = 0;
     int prof = 0; // aisx_corr_set_profiling
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int NEV = 64; // ring of event pairs: one per call, read back after the timed region
+    hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
+    long ncalls_prof = 0;
     // GNU Radio path staging
     cf *d_st_in = nullptr, *d_st_out = nullptr, *d_st_corr = nullptr;
     int st_cap = 0;
@@ -214,10 +216,12 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
-    if (h->ev0)
-        (void)hipEventDestroy(h->ev0);
-    if (h->ev1)
-        (void)hipEventDestroy(h->ev1);
+    for (int k = 0; k < aisx_corr::NEV; k++) {
+        if (h->ev0[k])
+            (void)hipEventDestroy(h->ev0[k]);
+        if (h->ev1[k])
+            (void)hipEventDestroy(h->ev1[k]);
+    }
     delete h;
     return AISX_OK;
 }
@@ -296,12 +300,15 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     p.nseg = nseg;
     p.tiles_per_seg = tps;
     p.thresh = h->thresh;
+    const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
-        AISX_HIPCHK(hipEventRecord(h->ev0, st));
+        AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
     hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
     AISX_HIPCHK(hipGetLastError());
-    if (h->prof)
-        AISX_HIPCHK(hipEventRecord(h->ev1, st));
+    if (h->prof) {
+        AISX_HIPCHK(hipEventRecord(h->ev1[evi], st));
+        h->ncalls_prof++;
+    }
 
     ResolveParams r;
     r.abits = h->d_abits;
@@ -338,20 +345,40 @@ extern "C" int aisx_corr_set_profiling(aisx_corr* h, int on)
 {
     if (!h)
         return AISX_ERR_INVALID;
-    if (on && !h->ev0) {
-        AISX_HIPCHK(hipEventCreate(&h->ev0));
-        AISX_HIPCHK(hipEventCreate(&h->ev1));
+    if (on && !h->ev0[0]) {
+        for (int k = 0; k < aisx_corr::NEV; k++) {
+            AISX_HIPCHK(hipEventCreate(&h->ev0[k]));
+            AISX_HIPCHK(hipEventCreate(&h->ev1[k]));
+        }
     }
     h->prof = on ? 1 : 0;
+    h->ncalls_prof = 0;
     return AISX_OK;
 }
 
 extern "C" int aisx_corr_last_kernel_ms(aisx_corr* h, float* ms)
 {
-    if (!h || !ms || !h->ev0)
+    if (!h || !ms || !h->ev0[0] || h->ncalls_prof < 1)
         return AISX_ERR_INVALID;
-    AISX_HIPCHK(hipEventSynchronize(h->ev1));
-    AISX_HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    const int evi = (int)((h->ncalls_prof - 1) % aisx_corr::NEV);
+    AISX_HIPCHK(hipEventSynchronize(h->ev1[evi]));
+    AISX_HIPCHK(hipEventElapsedTime(ms, h->ev0[evi], h->ev1[evi]));
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_kernel_ms_history(aisx_corr* h, float* ms, int cap, int* n)
+{
+    if (!h || !ms || !n || !h->ev0[0])
+        return AISX_ERR_INVALID;
+    const long have = h->ncalls_prof < aisx_corr::NEV ? h->ncalls_prof : aisx_corr::NEV;
+    int w = 0;
+    for (long k = h->ncalls_prof - have; k < h->ncalls_prof && w < cap; k++) {
+        const int evi = (int)(k % aisx_corr::NEV);
+        AISX_HIPCHK(hipEventSynchronize(h->ev1[evi]));
+        AISX_HIPCHK(hipEventElapsedTime(&ms[w], h->ev0[evi], h->ev1[evi]));
+        w++;
+    }
+    *n = w;
     return AISX_OK;
 }
 

@@ -105,6 +105,9 @@ int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_
  * the last bracket and returns its duration. */
 int aisx_corr_set_profiling(aisx_corr* h, int on);
 int aisx_corr_last_kernel_ms(aisx_corr* h, float* ms);
+/* durations of the main kernel in the calls made since profiling was switched on
+ * (the most recent 64 at most), oldest first */
+int aisx_corr_kernel_ms_history(aisx_corr* h, float* ms, int cap, int* n);
 /* device tag buffers of the last call: tags[c * cap + k], k < min(counts[c], cap) */
 int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int** d_counts, int* cap);
 /* copy the last call's tags to the host, channel by channel in emission order;
