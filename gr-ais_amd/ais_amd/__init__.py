@@ -7,6 +7,7 @@ Mirrors the reference's Python-visible interface for this path
 helper `modulate_vector_bc`.  All signal processing runs in libaisx.so (hand
 written HIP for gfx950, C ABI in include/aisx.h).
 """
+from .framing import hdlc_deframer_bp, pdu_to_nmea  # noqa: F401
 from .modulate import gmsk_mod, modulate_vector_bc  # noqa: F401
 
 

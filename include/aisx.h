@@ -199,6 +199,25 @@ int aisx_agc_reset(aisx_agc* h);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* host-side tail of the receive chain (python/radio.py:64-73): per-packet,   */
+/* bytes-per-second work, plain CPU code, HOST pointers                      */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_hdlc aisx_hdlc;
+/* digital.hdlc_deframer_bp(length_min, length_max) (python/radio.py:64): flag
+ * search, bit unstuffing, bytes packed LSB first, CRC-16/X.25 check. */
+int aisx_hdlc_create(aisx_hdlc** h, int length_min, int length_max);
+int aisx_hdlc_destroy(aisx_hdlc* h);
+/* feeds nbits unpacked bits (one per byte); every frame whose CRC checks is
+ * appended to pdu_bytes, frame k = pdu_bytes[pdu_offsets[k] .. pdu_offsets[k+1]);
+ * *npdus = frames found (AISX_ERR_OVERFLOW if they did not all fit). */
+int aisx_hdlc_work(aisx_hdlc* h, const uint8_t* bits, int nbits, uint8_t* pdu_bytes, int pdu_cap, int* pdu_offsets,
+                   int max_pdus, int* npdus);
+/* ais.pdu_to_nmea(designator)::msg_to_sentence (lib/pdu_to_nmea_impl.cc:63-131):
+ * writes the NUL-terminated !AIVDM sentence(s) (fragments separated by '\n');
+ * returns the string length. */
+int aisx_pdu_to_nmea(const char* designator, const uint8_t* pdu, int len, char* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

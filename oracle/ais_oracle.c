@@ -14,6 +14,7 @@
 #include "orc_tables.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1060,4 +1061,121 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
     free(y2);
     free(y1);
     return nbits;
+}
+
+/* ------------------------------------------------------------------ */
+/* N4: [GR] gr-digital hdlc_deframer_bp_impl::work as      */
+/* python/radio.py:64 uses it, and ais.pdu_to_nmea                     */
+/* (lib/pdu_to_nmea_impl.cc:63-131).                                   */
+/* ------------------------------------------------------------------ */
+static unsigned short orc_crc_ccitt(const unsigned char *data, int len)
+{
+    unsigned int POLY = 0x8408;
+    unsigned short crc = 0xFFFF;
+    for (int i = 0; i < len; i++) {
+        crc ^= data[i];
+        for (int j = 0; j < 8; j++) {
+            if (crc & 0x01)
+                crc = (crc >> 1) ^ POLY;
+            else
+                crc = (crc >> 1);
+        }
+    }
+    return crc ^ 0xFFFF;
+}
+
+void orc_hdlc_init(orc_hdlc *h, int length_min, int length_max)
+{
+    memset(h, 0, sizeof(*h));
+    h->length_min = length_min;
+    h->length_max = length_max;
+}
+
+/* returns number of frames; frame k = out[offs[k] .. offs[k+1]) */
+int orc_hdlc_work(orc_hdlc *h, const unsigned char *in, int n, unsigned char *out, int out_cap, int *offs, int max_frames)
+{
+    int nf = 0, used = 0;
+    offs[0] = 0;
+    for (int i = 0; i < n; i++) {
+        unsigned char bit = in[i];
+        if (h->ones >= 5) {
+            if (bit) { /* six ones is a frame delimiter */
+                if (h->bytectr >= h->length_min) {
+                    int len = h->bytectr - 2;
+                    unsigned short crc = orc_crc_ccitt(h->pktbuf, len);
+                    unsigned short pktcrc = h->pktbuf[len + 1] << 8 | h->pktbuf[len];
+                    if (crc == pktcrc && nf < max_frames && used + len <= out_cap) {
+                        memcpy(out + used, h->pktbuf, len);
+                        used += len;
+                        nf++;
+                        offs[nf] = used;
+                    }
+                    memset(h->pktbuf, 0, sizeof(h->pktbuf));
+                }
+                h->bitctr = 0;
+                h->bytectr = 0;
+            } /* else unstuff */
+        } else {
+            if (h->bytectr > h->length_max) {
+                h->bitctr = 0;
+                h->bytectr = 0;
+                memset(h->pktbuf, 0, sizeof(h->pktbuf));
+            } else {
+                h->pktbuf[h->bytectr] >>= 1;
+                if (bit)
+                    h->pktbuf[h->bytectr] |= 0x80;
+                h->bitctr++;
+                if (h->bitctr == 8) {
+                    h->bitctr = 0;
+                    h->bytectr++;
+                }
+            }
+        }
+        h->ones = (bit) ? h->ones + 1 : 0;
+    }
+    return nf;
+}
+
+/* lib/pdu_to_nmea_impl.cc: unpack_bits :63-79, to_ascii :81-88, get_checksum :90-96,
+ * to_sentence :99-124.  Returns the string length. */
+int orc_pdu_to_nmea(const char *designator, const unsigned char *p, int len, char *out, int cap)
+{
+    int nbits = len * 8;
+    int npad = (6 - (nbits % 6)) % 6;
+    int nsix = (nbits + npad) / 6;
+    unsigned char *up = (unsigned char *)calloc(nsix + 1, 1);
+    for (int i = 0; i < nbits; i++) {
+        unsigned char bit = (p[i / 8] >> (7 - (i % 8))) & 1;
+        up[i / 6] |= (bit << (5 - (i % 6)));
+    }
+    for (int i = 0; i < npad; i++)
+        up[nbits / 6] <<= 1;
+    char *ascii = (char *)malloc(nsix + 1);
+    for (int i = 0; i < nsix; i++) {
+        char c = (char)up[i];
+        if (c > 39)
+            c += 8;
+        c += 48;
+        ascii[i] = c;
+    }
+    ascii[nsix] = 0;
+    const int nmea_max = 56;
+    int num_frags = 1 + ((nsix - 1) / nmea_max);
+    int frag_id = 1, frag_offset = 0, o = 0;
+    out[0] = 0;
+    while (frag_id <= num_frags) {
+        char sent[256];
+        int flen = nsix - frag_offset < nmea_max ? nsix - frag_offset : nmea_max;
+        int k = snprintf(sent, sizeof(sent), "!AIVDM,%d,%d,,%s,%.*s,%d", num_frags, frag_id, designator, flen,
+                         ascii + frag_offset, npad);
+        frag_id++;
+        frag_offset += flen;
+        unsigned char sum = 0;
+        for (int i = (sent[0] == '!') ? 1 : 0; i < k; i++)
+            sum ^= (unsigned char)sent[i];
+        o += snprintf(out + o, cap - o, "%s%s*%02X", frag_id > 2 ? "\n" : "", sent, sum);
+    }
+    free(up);
+    free(ascii);
+    return o;
 }

@@ -113,6 +113,15 @@ void orc_demod_destroy(orc_demod *h);
 int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, int max_bits, orc_cf *syms_or_null,
                    orc_tag *tags_out, int max_tags, int *ntags);
 
+/* ---- N4: hdlc_deframer_bp (python/radio.py:64) + pdu_to_nmea (lib/pdu_to_nmea_impl.cc) ---- */
+typedef struct {
+    int length_min, length_max, ones, bitctr, bytectr;
+    unsigned char pktbuf[1024];
+} orc_hdlc;
+void orc_hdlc_init(orc_hdlc *h, int length_min, int length_max);
+int orc_hdlc_work(orc_hdlc *h, const unsigned char *in, int n, unsigned char *out, int out_cap, int *offs, int max_frames);
+int orc_pdu_to_nmea(const char *designator, const unsigned char *p, int len, char *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

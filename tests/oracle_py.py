@@ -89,6 +89,11 @@ def lib():
         L.orc_demod_destroy.argtypes = [vp]
         L.orc_demod_step.restype = i32
         L.orc_demod_step.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, pi32]
+        L.orc_hdlc_init.argtypes = [vp, i32, i32]
+        L.orc_hdlc_work.restype = i32
+        L.orc_hdlc_work.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+        L.orc_pdu_to_nmea.restype = i32
+        L.orc_pdu_to_nmea.argtypes = [C.c_char_p, vp, i32, C.c_char_p, i32]
         _LIB = L
     return _LIB
 
@@ -342,3 +347,27 @@ class Demod:
         nb = lib().orc_demod_step(self.h, _ptr(x), x.size, _ptr(bits), maxb, _ptr(syms) if want_syms else None,
                                   _ptr(tags), maxt, C.byref(nt))
         return bits[:nb].copy(), (syms[:nb].copy() if want_syms else None), tags[: min(nt.value, maxt)].copy()
+
+
+class Hdlc(C.Structure):
+    _fields_ = [("length_min", C.c_int), ("length_max", C.c_int), ("ones", C.c_int), ("bitctr", C.c_int),
+                ("bytectr", C.c_int), ("pktbuf", C.c_ubyte * 1024)]
+
+    def __init__(self, length_min=11, length_max=64):
+        super().__init__()
+        lib().orc_hdlc_init(C.byref(self), length_min, length_max)
+
+    def work(self, bits):
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        maxf = b.size // 16 + 2
+        out = np.zeros(maxf * 66, dtype=np.uint8)
+        offs = np.zeros(maxf + 1, dtype=np.int32)
+        n = lib().orc_hdlc_work(C.byref(self), _ptr(b), b.size, _ptr(out), out.size, _ptr(offs), maxf)
+        return [bytes(out[offs[k]:offs[k + 1]]) for k in range(n)]
+
+
+def pdu_to_nmea(designator, pdu):
+    p = np.frombuffer(bytes(pdu), dtype=np.uint8)
+    out = C.create_string_buffer(4096)
+    n = lib().orc_pdu_to_nmea(designator.encode(), _ptr(p), p.size, out, 4096)
+    return out.raw[:n].decode("latin-1")
