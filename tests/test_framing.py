@@ -68,10 +68,12 @@ def test_hdlc_deframer_matches_oracle_and_recovers_payloads():
         got += d.work(bits[k:k + 777])
         want += o.work(bits[k:k + 777])
     assert got == want
-    ok = [p for n, p in sent if 11 <= n + 2 and n <= 64 and n + 2 >= 11]
-    for p in ok:
-        if len(p) >= 9 and len(p) <= 64:
-            assert p in got
+    # a frame passes when payload + 2 CRC bytes is within [length_min, length_max]
+    for n, pl in sent:
+        if 11 <= n + 2 <= 64:
+            assert pl in got
+        else:
+            assert pl not in got
     assert len(got) >= 15
 
 
