@@ -94,6 +94,9 @@ def lib():
     sig("aisx_agc_destroy", i32, [vp])
     sig("aisx_agc_reset", i32, [vp])
     sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
+    sig("aisx_pfb_create", i32, [pvp, i32, i32, vp, i32, i32, i32])
+    sig("aisx_pfb_destroy", i32, [vp])
+    sig("aisx_pfb_process", i32, [vp, vp, lng, i32, vp, lng, pi32, vp])
     sig("aisx_hdlc_create", i32, [pvp, i32, i32])
     sig("aisx_hdlc_destroy", i32, [vp])
     sig("aisx_hdlc_work", i32, [vp, vp, i32, vp, i32, vp, i32, pi32])

@@ -371,3 +371,52 @@ class ais_demod:
         y, _ = self.preamble_detect.work(y, stream=stream)
         r = self.clockrec.work(y, tags_from=self.preamble_detect, want_syms=want_syms, stream=stream)
         return r
+
+
+def firdes_low_pass(gain, sampling_freq, cutoff_freq, transition_width):
+    """filter.firdes.low_pass(gain, fs, cutoff, transition) with the default Hamming
+    window, as python/radio.py:51 calls it ([GR] firdes.cc: windowed sinc, DC gain
+    normalised).  Host side, init only."""
+    ntaps = int(53.0 * sampling_freq / (22.0 * transition_width))
+    if (ntaps & 1) == 0:
+        ntaps += 1
+    m = (ntaps - 1) // 2
+    n = np.arange(-m, m + 1, dtype=np.float64)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(ntaps) / (ntaps - 1))
+    fwt0 = 2 * np.pi * cutoff_freq / sampling_freq
+    with np.errstate(invalid="ignore", divide="ignore"):
+        taps = np.where(n == 0, fwt0 / np.pi, np.sin(n * fwt0) / (n * np.pi)) * w
+    taps = taps.astype(np.float32).astype(np.float64)
+    fmax = taps[m] + 2 * taps[m + 1:].sum()
+    return (taps * (gain / fmax)).astype(np.float32)
+
+
+class pfb_channelizer_ccf:
+    """Wideband front end (BASELINE config 5): all `nlanes` uniformly spaced channels of
+    one wideband stream at once; lane m is what
+    freq_xlating_fir_filter_ccf(decim, taps, m*fs/nlanes, fs) (python/radio.py:52-54)
+    would produce."""
+
+    def __init__(self, nlanes, taps, decim=None, nstreams=1, max_frames=4096):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        self.nlanes, self.decim, self.nstreams = int(nlanes), int(decim or nlanes), int(nstreams)
+        h = C.c_void_p()
+        check(_lib.lib().aisx_pfb_create(C.byref(h), self.nlanes, self.decim, t.ctypes.data_as(C.c_void_p), t.size,
+                                         self.nstreams, int(max_frames)), "pfb_channelizer_ccf")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().aisx_pfb_destroy(h)
+            self._h = None
+
+    def work(self, x, stream=None):
+        x = _dev_c64(x, self.nstreams)
+        n = x.shape[1]
+        nf = n // self.decim
+        out = torch.empty((self.nstreams * self.nlanes, max(nf, 1)), dtype=torch.complex64, device=x.device)
+        got = C.c_int(0)
+        check(_lib.lib().aisx_pfb_process(self._h, x.data_ptr(), x.stride(0), n, out.data_ptr(), out.stride(0),
+                                          C.byref(got), _stream_ptr(stream)), "pfb_channelizer_ccf.work")
+        return out[:, : got.value]

@@ -283,3 +283,114 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     h->cur ^= 1;
     return AISX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// N3: polyphase channelizer front end (BASELINE config 5)
+// ---------------------------------------------------------------------------
+#include "k_pfb.h"
+
+__global__ __launch_bounds__(PFB_T) void k_pfb(PfbParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    pfb_body(cx, p);
+}
+
+struct aisx_pfb {
+    int nstreams = 0, D = 0, K = 0, Lh = 0, max_frames = 0;
+    float* d_taps = nullptr;
+    cf* d_wtab = nullptr;
+    cf* d_hist[2] = { nullptr, nullptr };
+    int cur = 0;
+    long frame0 = 0;
+};
+
+extern "C" int aisx_pfb_create(aisx_pfb** out, int nlanes, int decim, const float* taps, int ntaps, int nstreams,
+                               int max_frames)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (nlanes != PFB_M || (decim != PFB_M && decim != PFB_M / 2) || !taps || ntaps < 1 || nstreams < 1 || max_frames < 1) {
+        set_err("aisx_pfb_create: supported geometry is %d lanes, decimation %d or %d", PFB_M, PFB_M, PFB_M / 2);
+        return AISX_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_pfb* h = new aisx_pfb();
+    h->nstreams = nstreams;
+    h->D = decim;
+    h->K = (ntaps + PFB_M - 1) / PFB_M;
+    h->Lh = h->K * PFB_M;
+    h->max_frames = max_frames;
+    std::vector<float> pad((size_t)h->Lh, 0.f);
+    for (int i = 0; i < ntaps; i++)
+        pad[i] = taps[i];
+    std::vector<cf> w(PFB_M);
+    for (int k = 0; k < PFB_M; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)PFB_M;
+        w[k] = mk((float)cos(a), (float)sin(a));
+    }
+    if ((rc = dev_alloc(&h->d_taps, h->Lh)) != AISX_OK || (rc = dev_alloc(&h->d_wtab, PFB_M)) != AISX_OK ||
+        (rc = dev_alloc(&h->d_hist[0], (size_t)nstreams * h->Lh)) != AISX_OK ||
+        (rc = dev_alloc(&h->d_hist[1], (size_t)nstreams * h->Lh)) != AISX_OK) {
+        aisx_pfb_destroy(h);
+        return rc;
+    }
+    if (hipMemcpy(h->d_taps, pad.data(), sizeof(float) * h->Lh, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * PFB_M, hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("aisx_pfb_create: table upload failed");
+        aisx_pfb_destroy(h);
+        return AISX_ERR_HIP;
+    }
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_pfb_destroy(aisx_pfb* h)
+{
+    if (!h)
+        return AISX_OK;
+    dev_free(h->d_taps);
+    dev_free(h->d_wtab);
+    dev_free(h->d_hist[0]);
+    dev_free(h->d_hist[1]);
+    delete h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_pfb_process(aisx_pfb* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out,
+                                long out_stride, int* nframes, void* stream)
+{
+    if (!h || !d_in || !d_out || !nframes || n < 1 || (n % h->D) != 0 || in_stride < n) {
+        set_err("aisx_pfb_process: n must be a positive multiple of the decimation %d", h ? h->D : 0);
+        return AISX_ERR_INVALID;
+    }
+    const int nf = n / h->D;
+    if (nf > h->max_frames || out_stride < nf) {
+        set_err("aisx_pfb_process: %d frames exceed the capacity", nf);
+        return AISX_ERR_INVALID;
+    }
+    PfbParams p;
+    p.in = (const cf*)d_in;
+    p.in_stride = in_stride;
+    p.hist_in = h->d_hist[h->cur];
+    p.hist_out = h->d_hist[h->cur ^ 1];
+    p.taps = h->d_taps;
+    p.wtab = h->d_wtab;
+    p.out = (cf*)d_out;
+    p.out_stride = out_stride;
+    p.n = n;
+    p.D = h->D;
+    p.K = h->K;
+    p.Lh = h->Lh;
+    p.nframes = nf;
+    p.frame0 = h->frame0;
+    hipLaunchKernelGGL(k_pfb, dim3((nf + 3) / 4, h->nstreams), dim3(PFB_T), PFB_LDS_BYTES, (hipStream_t)stream, p);
+    AISX_HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    h->frame0 += nf;
+    *nframes = nf;
+    return AISX_OK;
+}

@@ -200,6 +200,23 @@ int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf
                      void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* wideband front end (BASELINE config 5; reference analogue: one             */
+/* freq_xlating_fir_filter_ccf(decim, low_pass(1, rate, 11e3, 1e3), f_off,    */
+/* rate) per channel, python/radio.py:49-54): a polyphase channelizer that    */
+/* computes all nlanes uniformly spaced channels f_m = m*fs/nlanes at once    */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_pfb aisx_pfb;
+/* nlanes = 1024; decim = 1024 (critically sampled) or 512 (2x oversampled);
+ * taps = the prototype low-pass (what firdes.low_pass returns), ntaps of them */
+int aisx_pfb_create(aisx_pfb** h, int nlanes, int decim, const float* taps, int ntaps, int nstreams, int max_frames);
+int aisx_pfb_destroy(aisx_pfb* h);
+/* d_in [nstreams][n] new wideband samples (n a multiple of decim); writes
+ * n/decim output items per lane: lane m of stream s is row s*nlanes + m of
+ * d_out[..][out_stride] (channel-major, ready for the demod stages) */
+int aisx_pfb_process(aisx_pfb* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out, long out_stride,
+                     int* nframes, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* host-side tail of the receive chain (python/radio.py:64-73): per-packet,   */
 /* bytes-per-second work, plain CPU code, HOST pointers                      */
 /* ------------------------------------------------------------------------ */

@@ -1179,3 +1179,58 @@ int orc_pdu_to_nmea(const char *designator, const unsigned char *p, int len, cha
     free(ascii);
     return o;
 }
+
+/* ------------------------------------------------------------------ */
+/* N3: [GR] freq_xlating_fir_filter_ccf(decim, taps, center_freq, fs)  */
+/* as python/radio.py:52-54 builds it per channel: band-pass taps      */
+/* h[n] e^{+j 2 pi f0 n / fs}, decimating FIR (output k uses x[kD],    */
+/* x[kD-1], ...; zeros before the stream start), then a rotator        */
+/* e^{-j 2 pi f0 D k / fs}.  Evaluated directly in double.             */
+/* ------------------------------------------------------------------ */
+void orc_freq_xlating_fir(const float *taps, int ntaps, int decim, double center_freq, double fs, const orc_cf *x,
+                          long nx, long k0, int nout, orc_cf *out)
+{
+    for (int i = 0; i < nout; i++) {
+        long k = k0 + i;
+        double ar = 0, ai = 0;
+        for (int n = 0; n < ntaps; n++) {
+            long idx = k * decim - n;
+            if (idx < 0 || idx >= nx)
+                continue;
+            double ph = 2.0 * M_PI * center_freq * (double)n / fs;
+            double hr = taps[n] * cos(ph), hi = taps[n] * sin(ph);
+            ar += hr * x[idx].re - hi * x[idx].im;
+            ai += hr * x[idx].im + hi * x[idx].re;
+        }
+        double rp = -2.0 * M_PI * center_freq * (double)decim * (double)k / fs;
+        double cr = cos(rp), ci = sin(rp);
+        out[i].re = (float)(ar * cr - ai * ci);
+        out[i].im = (float)(ar * ci + ai * cr);
+    }
+}
+
+/* [GR] firdes::low_pass(gain, fs, cutoff, transition, WIN_HAMMING) (python/radio.py:51) */
+int orc_firdes_low_pass(double gain, double fs, double cutoff, double transition, float *taps, int cap)
+{
+    int ntaps = (int)(53.0 * fs / (22.0 * transition));
+    if ((ntaps & 1) == 0)
+        ntaps++;
+    if (ntaps > cap)
+        return -ntaps;
+    int M = (ntaps - 1) / 2;
+    double fwT0 = 2 * M_PI * cutoff / fs;
+    for (int n = -M; n <= M; n++) {
+        double w = 0.54 - 0.46 * cos((2 * M_PI * (n + M)) / (ntaps - 1));
+        if (n == 0)
+            taps[n + M] = (float)(fwT0 / M_PI * w);
+        else
+            taps[n + M] = (float)(sin(n * fwT0) / (n * M_PI) * w);
+    }
+    double fmax = taps[0 + M];
+    for (int n = 1; n <= M; n++)
+        fmax += 2 * taps[n + M];
+    gain /= fmax;
+    for (int i = 0; i < ntaps; i++)
+        taps[i] = (float)(taps[i] * gain);
+    return ntaps;
+}

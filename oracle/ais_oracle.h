@@ -122,6 +122,11 @@ void orc_hdlc_init(orc_hdlc *h, int length_min, int length_max);
 int orc_hdlc_work(orc_hdlc *h, const unsigned char *in, int n, unsigned char *out, int out_cap, int *offs, int max_frames);
 int orc_pdu_to_nmea(const char *designator, const unsigned char *p, int len, char *out, int cap);
 
+/* ---- N3: freq_xlating_fir_filter_ccf + firdes.low_pass (python/radio.py:49-54) ---- */
+void orc_freq_xlating_fir(const float *taps, int ntaps, int decim, double center_freq, double fs, const orc_cf *x,
+                          long nx, long k0, int nout, orc_cf *out);
+int orc_firdes_low_pass(double gain, double fs, double cutoff, double transition, float *taps, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include "../../gr-ais_amd/csrc/k_corr.h"
 #include "../../gr-ais_amd/csrc/k_msk.h"
 #include "../../gr-ais_amd/csrc/aisx_plan.h"
+#include "../../gr-ais_amd/csrc/k_pfb.h"
 #if __has_include("../../gr-ais_amd/csrc/k_agc.h")
 #include "../../gr-ais_amd/csrc/k_agc.h"
 #define HAVE_AGC 1
@@ -298,6 +299,40 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
     return h->status[0];
 }
 
+void emu_pfb(const PfbParams* p, int nstreams)
+{
+    run_grid((p->nframes + 3) / 4, nstreams, PFB_T, PFB_LDS_BYTES, [&](EmuCtx& cx) { pfb_body(cx, *p); });
+}
+struct EmuPfb {
+    int nstreams, D, K, Lh;
+    std::vector<float> taps;
+    std::vector<cf> wtab, hist[2];
+    int cur = 0;
+    long frame0 = 0;
+};
+void* emu_pfb_create(int decim, const float* taps, int ntaps, int nstreams)
+{
+    EmuPfb* h = new EmuPfb();
+    h->nstreams = nstreams; h->D = decim; h->K = (ntaps + PFB_M - 1) / PFB_M; h->Lh = h->K * PFB_M;
+    h->taps.assign(h->Lh, 0.f);
+    for (int i = 0; i < ntaps; i++) h->taps[i] = taps[i];
+    h->wtab.resize(PFB_M);
+    for (int k = 0; k < PFB_M; k++) { double a = -2.0 * M_PI * k / PFB_M; h->wtab[k] = mk((float)cos(a), (float)sin(a)); }
+    h->hist[0].assign((size_t)nstreams * h->Lh, mk(0, 0)); h->hist[1] = h->hist[0];
+    return h;
+}
+void emu_pfb_destroy(void* hv) { delete (EmuPfb*)hv; }
+int emu_pfb_process(void* hv, const cf* in, long in_stride, int n, cf* out, long out_stride)
+{
+    EmuPfb* h = (EmuPfb*)hv;
+    PfbParams p;
+    p.in = in; p.in_stride = in_stride; p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
+    p.taps = h->taps.data(); p.wtab = h->wtab.data(); p.out = out; p.out_stride = out_stride;
+    p.n = n; p.D = h->D; p.K = h->K; p.Lh = h->Lh; p.nframes = n / h->D; p.frame0 = h->frame0;
+    emu_pfb(&p, h->nstreams);
+    h->cur ^= 1; h->frame0 += p.nframes;
+    return p.nframes;
+}
 float emu_fast_atan2f(float y, float x) { return fast_atan2f_tab(y, x, aisx_atan_table); }
 const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
 const float* emu_atan_table() { return aisx_atan_table; }

@@ -53,6 +53,11 @@ def lib():
         L.emu_fs_process.restype = i32
         L.emu_fs_process.argtypes = [vp, vp, lng, i32, vp, lng, vp, lng]
         L.emu_freqest_work.argtypes = [vp, vp, lng, vp, lng, i32]
+        L.emu_pfb_create.restype = vp
+        L.emu_pfb_create.argtypes = [i32, vp, i32, i32]
+        L.emu_pfb_destroy.argtypes = [vp]
+        L.emu_pfb_process.restype = i32
+        L.emu_pfb_process.argtypes = [vp, vp, lng, i32, vp, lng]
         _LIB = L
     return _LIB
 
@@ -179,3 +184,23 @@ class FreqSync:
         out = np.zeros((self.nchan, max(nvec, 1)), np.float32)
         lib().emu_freqest_work(self.h, _p(v), v.shape[1], _p(out), out.shape[1], nvec)
         return out[:, :nvec]
+
+
+class Pfb:
+    def __init__(self, taps, decim, nstreams=1):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        self.h = lib().emu_pfb_create(decim, _p(t), t.size, nstreams)
+        self.decim, self.nstreams = decim, nstreams
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().emu_pfb_destroy(self.h)
+            self.h = None
+
+    def work(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex64).reshape(self.nstreams, -1)
+        n = x.shape[1]
+        nf = n // self.decim
+        out = np.zeros((self.nstreams * 1024, nf), np.complex64)
+        lib().emu_pfb_process(self.h, _p(x), n, n, _p(out), nf)
+        return out

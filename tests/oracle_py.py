@@ -94,6 +94,9 @@ def lib():
         L.orc_hdlc_work.argtypes = [vp, vp, i32, vp, i32, vp, i32]
         L.orc_pdu_to_nmea.restype = i32
         L.orc_pdu_to_nmea.argtypes = [C.c_char_p, vp, i32, C.c_char_p, i32]
+        L.orc_freq_xlating_fir.argtypes = [vp, i32, i32, f64, f64, vp, C.c_long, C.c_long, i32, vp]
+        L.orc_firdes_low_pass.restype = i32
+        L.orc_firdes_low_pass.argtypes = [f64, f64, f64, f64, vp, i32]
         _LIB = L
     return _LIB
 
@@ -371,3 +374,18 @@ def pdu_to_nmea(designator, pdu):
     out = C.create_string_buffer(4096)
     n = lib().orc_pdu_to_nmea(designator.encode(), _ptr(p), p.size, out, 4096)
     return out.raw[:n].decode("latin-1")
+
+
+def firdes_low_pass(gain, fs, cutoff, transition):
+    cap = int(53.0 * fs / (22.0 * transition)) + 4
+    t = np.zeros(cap, dtype=np.float32)
+    n = lib().orc_firdes_low_pass(gain, fs, cutoff, transition, _ptr(t), cap)
+    return t[:n].copy()
+
+
+def freq_xlating_fir(taps, decim, center_freq, fs, x, k0, nout):
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    x = _c64(x)
+    out = np.zeros(nout, dtype=np.complex64)
+    lib().orc_freq_xlating_fir(_ptr(t), t.size, decim, center_freq, fs, _ptr(x), x.size, k0, nout, _ptr(out))
+    return out
