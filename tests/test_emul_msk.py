@@ -26,7 +26,8 @@ def _rand_tags(rng, n, count, chan=0):
 @pytest.mark.parametrize("sps,osps", [(4.0, 1), (4.0, 2), (5.2083, 1), (5.0, 1)])
 def test_emul_msk_stream_bit_exact(sps, osps):
     rng = np.random.default_rng(int(sps * 10) + osps)
-    nchan, lens = 3, [1500, 37, 900, 1, 700]
+    # > 64 channels so that both channels of a lane are live in the 2-channels-per-lane kernel
+    nchan, lens = (67 if (sps, osps) == (4.0, 1) else 3), [1500, 37, 900, 1, 700]
     total = sum(lens)
     xs = np.stack([_signal(50 + c, total, 4)[0] for c in range(nchan)])
     e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan)
