@@ -733,7 +733,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     int rc = msk_enable_big_lds();
     if (rc != AISX_OK)
         return rc;
-    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 64 * MSK_NCH - 1) / (64 * MSK_NCH)), dim3(MSK_T), MSK_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(MSK_T), MSK_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     return AISX_OK;

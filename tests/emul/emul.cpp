@@ -143,7 +143,7 @@ void emu_corr_resolve(const ResolveParams* p, int nchan)
 
 void emu_msk(const MskParams* p)
 {
-    run_grid((p->nchan + 64 * MSK_NCH - 1) / (64 * MSK_NCH), 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) { msk_body(cx, *p); });
+    run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) { msk_body(cx, *p); });
 }
 
 // ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
