@@ -56,6 +56,20 @@ __global__ __launch_bounds__(CF_T, 3) void k_corr_main(CorrParams p)
     corr_main_body(cx, p);
 }
 
+__global__ __launch_bounds__(CF4_T) void k_corr4_inith(CorrInitParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4_inith_body(cx, p);
+}
+
+__global__ __launch_bounds__(CF4_T, 2) void k_corr4_main(CorrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4_main_body(cx, p);
+}
+
 __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
     DevCtx cx{ nullptr };
@@ -84,6 +98,7 @@ static int msk_enable_big_lds()
 // ---------------------------------------------------------------------------
 struct aisx_corr {
     int nchan = 0, N = 0, max_items = 0, tag_cap = 0, L = 0, isps = 0, out_multiple = 0;
+    int F = CF_F; // FFT build serving this template length
     float sps = 0, thresh = 0;
     unsigned mark_delay = 0;
     std::vector<cf> symbols; // d_symbols
@@ -116,11 +131,14 @@ struct aisx_corr {
 static int corr_upload_taps(aisx_corr* h)
 {
     // taps/F, zero padded, then the forward transform in the kernel's own position order
-    std::vector<cf> pad = corr_padded_taps(h->symbols);
-    AISX_HIPCHK(hipMemcpy(h->d_tapspad, pad.data(), sizeof(cf) * CF_F, hipMemcpyHostToDevice));
+    std::vector<cf> pad = corr_padded_taps(h->symbols, h->F);
+    AISX_HIPCHK(hipMemcpy(h->d_tapspad, pad.data(), sizeof(cf) * h->F, hipMemcpyHostToDevice));
     AISX_HIPCHK(hipMemcpy(h->d_taps, h->symbols.data(), sizeof(cf) * h->N, hipMemcpyHostToDevice));
     CorrInitParams ip{ h->d_tapspad, h->d_wtab, h->d_Hpos };
-    hipLaunchKernelGGL(k_corr_inith, dim3(1), dim3(CF_T), CF_LDS_BYTES, 0, ip);
+    if (h->F == CF_F)
+        hipLaunchKernelGGL(k_corr_inith, dim3(1), dim3(CF_T), CF_LDS_BYTES, 0, ip);
+    else
+        hipLaunchKernelGGL(k_corr4_inith, dim3(1), dim3(CF4_T), CF4_LDS_BYTES, 0, ip);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipDeviceSynchronize());
     return AISX_OK;
@@ -136,9 +154,9 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
         set_err("aisx_corr_create: bad argument");
         return AISX_ERR_INVALID;
     }
-    if (nsym > CF_F / 2) {
-        set_err("aisx_corr_create: template of %d samples exceeds the %d supported by the F=%d kernel", nsym,
-                CF_F / 2, CF_F);
+    if (nsym > CORR_MAX_TEMPLATE) {
+        set_err("aisx_corr_create: template of %d samples exceeds the %d supported (F = %d build)", nsym,
+                CORR_MAX_TEMPLATE, CF4_F);
         return AISX_ERR_INVALID;
     }
     int rc = require_device();
@@ -150,7 +168,8 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->max_items = max_items;
     h->tag_cap = max_tags_per_chan;
     h->sps = sps;
-    h->L = CF_F - nsym;
+    h->F = corr_pick_fft(nsym);
+    h->L = h->F - nsym;
     // constructor maths of lib/corr_est_cc_impl.cc:58-85 (aisx_plan.h)
     CorrSetup cs = corr_setup((const cf*)symbols, nsym, sps, mark_delay, threshold);
     h->symbols = cs.symbols;
@@ -158,7 +177,7 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->thresh = cs.thresh;
     h->isps = cs.isps;
     h->out_multiple = cs.out_multiple;
-    std::vector<cf> w = corr_wtab();
+    std::vector<cf> w = corr_wtab(h->F);
     h->abits_stride = (max_items + 63) / 64 + 1;
     h->scratch_stride = max_items;
 #define CK(e)               \
@@ -170,9 +189,9 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
         }                   \
     } while (0)
     CK(dev_alloc(&h->d_taps, nsym));
-    CK(dev_alloc(&h->d_tapspad, CF_F));
-    CK(dev_alloc(&h->d_Hpos, CF_F));
-    CK(dev_alloc(&h->d_wtab, CF_F));
+    CK(dev_alloc(&h->d_tapspad, h->F));
+    CK(dev_alloc(&h->d_Hpos, h->F));
+    CK(dev_alloc(&h->d_wtab, h->F));
     CK(dev_alloc(&h->d_hist[0], (size_t)nchan * nsym));
     CK(dev_alloc(&h->d_hist[1], (size_t)nchan * nsym));
     CK(dev_alloc(&h->d_abits, (size_t)nchan * h->abits_stride));
@@ -184,7 +203,7 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->d_tags = h->d_tags2[0];
     h->d_tag_count = h->d_tag_count2[0];
     CK(dev_alloc(&h->d_atan, 257));
-    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * CF_F, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * h->F, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
         set_err("aisx_corr_create: table upload failed");
         aisx_corr_destroy(h);
@@ -277,7 +296,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     }
     hipStream_t st = (hipStream_t)stream;
     int nseg, tps;
-    corr_grid(h->nchan, n, h->L, &nseg, &tps);
+    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps);
 
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;
@@ -303,7 +322,10 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
-    hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
+    if (h->F == CF_F)
+        hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(k_corr4_main, dim3(nseg, h->nchan), dim3(CF4_T), CF4_LDS_BYTES, st, p);
     AISX_HIPCHK(hipGetLastError());
     if (h->prof) {
         AISX_HIPCHK(hipEventRecord(h->ev1[evi], st));

@@ -9,6 +9,7 @@
 
 #include "aisx_common.h"
 #include "k_corr.h"
+#include "k_corr4k.h"
 
 namespace aisx {
 
@@ -37,21 +38,26 @@ inline CorrSetup corr_setup(const cf* symbols, int nsym, float sps, unsigned mar
     return s;
 }
 
-inline std::vector<cf> corr_wtab()
+// which FFT build serves a template of nsym samples: F = 2048 up to 512 samples (more
+// valid outputs per flop than F = 4096 for short templates), F = 4096 up to 2048
+inline int corr_pick_fft(int nsym) { return nsym <= CF_F / 4 ? CF_F : CF4_F; }
+constexpr int CORR_MAX_TEMPLATE = CF4_F / 2;
+
+inline std::vector<cf> corr_wtab(int F)
 {
-    std::vector<cf> w(CF_F);
-    for (int k = 0; k < CF_F; k++) {
-        double a = -2.0 * M_PI * (double)k / (double)CF_F;
+    std::vector<cf> w(F);
+    for (int k = 0; k < F; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)F;
         w[k] = mk((float)cos(a), (float)sin(a));
     }
     return w;
 }
 
 // taps/F zero padded to F (fft_filter_ccc::set_taps scales the taps by 1/fftsize)
-inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored)
+inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored, int F)
 {
-    std::vector<cf> pad(CF_F, mk(0.f, 0.f));
-    const float scale = 1.0f / (float)CF_F;
+    std::vector<cf> pad(F, mk(0.f, 0.f));
+    const float scale = 1.0f / (float)F;
     for (size_t i = 0; i < stored.size(); i++)
         pad[i] = mk(stored[i].re * scale, stored[i].im * scale);
     return pad;
@@ -60,12 +66,12 @@ inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored)
 // grid of the main kernel: (nseg, nchan) workgroups, each walking tiles_per_seg
 // consecutive tiles of L outputs of one channel.  The segment count is chosen so
 // that the grid is close to a whole number of full-chip rounds (256 CUs x 6
-// resident workgroups at 154 VGPRs / 18 KB LDS): a ragged last round is pure loss
+// resident workgroups of the F = 2048 build at 154 VGPRs / 18 KB LDS, 2 of the F = 4096 build): a ragged last round is pure loss
 // for a kernel whose workgroups all take the same time.
-inline void corr_grid(int nchan, int n, int L, int* nseg, int* tiles_per_seg)
+inline void corr_grid(int nchan, int n, int L, int F, int* nseg, int* tiles_per_seg)
 {
     const int ntiles = (n + L - 1) / L;
-    const long slots = 256L * 6;
+    const long slots = 256L * (F == CF_F ? 6 : 2); // resident workgroups per CU of the two builds
     int best = 1;
     double best_cost = 1e30;
     for (int ns = 1; ns <= 16; ns++) {

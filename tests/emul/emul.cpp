@@ -124,16 +124,23 @@ static void run_independent(int gx, int nthreads, Body body)
 extern "C" {
 
 int emu_cf_sizes(int* F, int* T) { *F = CF_F; *T = CF_T; return CF_LDS_BYTES; }
+int emu_corr_max_template() { return CORR_MAX_TEMPLATE; }
 
-void emu_corr_inith(const cf* taps_scaled, const cf* wtab, cf* Hpos)
+void emu_corr_inith(const cf* taps_scaled, const cf* wtab, cf* Hpos, int F)
 {
     CorrInitParams p{ taps_scaled, wtab, Hpos };
-    run_grid(1, 1, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_inith_body(cx, p); });
+    if (F == CF_F)
+        run_grid(1, 1, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_inith_body(cx, p); });
+    else
+        run_grid(1, 1, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_inith_body(cx, p); });
 }
 
-void emu_corr_main(const CorrParams* p, int nchan)
+void emu_corr_main(const CorrParams* p, int nchan, int F)
 {
-    run_grid(p->nseg, nchan, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_main_body(cx, *p); });
+    if (F == CF_F)
+        run_grid(p->nseg, nchan, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_main_body(cx, *p); });
+    else
+        run_grid(p->nseg, nchan, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_main_body(cx, *p); });
 }
 
 void emu_corr_resolve(const ResolveParams* p, int nchan)
@@ -149,7 +156,7 @@ void emu_msk(const MskParams* p)
 // ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
 struct EmuCorr {
     CorrSetup cs;
-    int N, nchan, L;
+    int N, nchan, L, F;
     std::vector<cf> wtab, Hpos, hist[2], scratch;
     std::vector<unsigned long long> abits;
     int cur = 0;
@@ -162,11 +169,12 @@ void* emu_corr_create(const cf* symbols, int nsym, float sps, unsigned mark_dela
     h->cs = corr_setup(symbols, nsym, sps, mark_delay, threshold);
     h->N = nsym;
     h->nchan = nchan;
-    h->L = CF_F - nsym;
-    h->wtab = corr_wtab();
-    h->Hpos.resize(CF_F);
-    std::vector<cf> pad = corr_padded_taps(h->cs.symbols);
-    emu_corr_inith(pad.data(), h->wtab.data(), h->Hpos.data());
+    h->F = corr_pick_fft(nsym);
+    h->L = h->F - nsym;
+    h->wtab = corr_wtab(h->F);
+    h->Hpos.resize(h->F);
+    std::vector<cf> pad = corr_padded_taps(h->cs.symbols, h->F);
+    emu_corr_inith(pad.data(), h->wtab.data(), h->Hpos.data(), h->F);
     h->hist[0].assign((size_t)nchan * nsym, mk(0, 0));
     h->hist[1].assign((size_t)nchan * nsym, mk(0, 0));
     return h;
@@ -181,7 +189,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
 {
     EmuCorr* h = (EmuCorr*)hv;
     int nseg, tps;
-    corr_grid(h->nchan, n, h->L, &nseg, &tps);
+    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps);
     if (force_nseg > 0) {
         const int ntiles = (n + h->L - 1) / h->L;
         tps = (ntiles + force_nseg - 1) / force_nseg;
@@ -197,7 +205,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.Hpos = h->Hpos.data(); p.wtab = h->wtab.data();
     p.abits = h->abits.data(); p.abits_stride = astride;
     p.n = n; p.N = h->N; p.L = h->L; p.nseg = nseg; p.tiles_per_seg = tps; p.thresh = h->cs.thresh;
-    emu_corr_main(&p, h->nchan);
+    emu_corr_main(&p, h->nchan, h->F);
     ResolveParams r;
     r.abits = p.abits; r.abits_stride = astride; r.corr = p.corr; r.corr_stride = p.corr_stride; r.dense_corr = p.dense_corr;
     r.in = in; r.in_stride = in_stride; r.hist_in = p.hist_in; r.taps = h->cs.symbols.data();

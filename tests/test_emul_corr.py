@@ -21,7 +21,7 @@ def _oracle_run(tmpl, sps, chunks, mark_delay=1, thr=0.9, want_corr=True):
     return outs, corrs, tags, o
 
 
-@pytest.mark.parametrize("N", [1, 20, 112, 896, 1024])
+@pytest.mark.parametrize("N", [1, 20, 112, 512, 513, 896, 1024, 2048])
 def test_emul_corr_dense_matches_oracle(N):
     rng = np.random.default_rng(100 + N)
     tmpl = unit_template(rng, N)

@@ -41,7 +41,7 @@ def _p_template(sps=4):
     return synth.gmsk_waveform(np.array(lv, float), sps)[: len(lv) * sps].astype(np.complex64)
 
 
-@pytest.mark.parametrize("N", [1, 20, 112, 896, 1024])
+@pytest.mark.parametrize("N", [1, 20, 112, 512, 513, 896, 1024, 2048])
 def test_corr_dense_matches_oracle(ais, N):
     rng = np.random.default_rng(100 + N)
     tmpl = unit_template(rng, N)
@@ -123,7 +123,7 @@ def test_corr_dense_detections_overflow_and_quirks(ais):
     with pytest.raises(ValueError):
         blk.set_symbols(t2[:5])
     with pytest.raises(ValueError):
-        ais.corr_est_cc(unit_template(rng, 1500), 4.0, 1)
+        ais.corr_est_cc(unit_template(rng, 2500), 4.0, 1)
 
 
 def test_corr_work_host_gnuradio_path(ais):
