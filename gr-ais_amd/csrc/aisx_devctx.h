@@ -14,7 +14,7 @@ struct DevCtx {
     __device__ __forceinline__ int by() const { return blockIdx.y; }
     __device__ __forceinline__ char* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
-    __device__ __forceinline__ unsigned long long ballot(bool p) const { return __ballot(p); }
+    __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
     __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) const
     {
         return __shfl(v, src, 64);

@@ -83,6 +83,13 @@ __global__ __launch_bounds__(MSK_T) void k_msk(MskParams p)
     msk_body(cx, p);
 }
 
+__global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[260 * 4];
+    DevCtx cx{ smem };
+    bittail_body(cx, p);
+}
+
 static int msk_enable_big_lds()
 {
     static bool done = false;
@@ -507,8 +514,13 @@ struct aisx_msk {
     static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     float *d_mu = nullptr, *d_omega = nullptr;
     int* d_div = nullptr;
-    cf *d_dly1 = nullptr, *d_dly2 = nullptr, *d_diff1 = nullptr, *d_tprev = nullptr;
-    unsigned char* d_tbit = nullptr;
+    cf *d_dly1 = nullptr, *d_dly2 = nullptr, *d_diff1 = nullptr;
+    // bit tail state (previous symbol, previous sliced bit): read from [tcur], written to [tcur ^ 1]
+    cf* d_tprev[2] = { nullptr, nullptr };
+    unsigned char* d_tbit[2] = { nullptr, nullptr };
+    int tcur = 0;
+    cf* d_symscratch = nullptr; // symbols for the bit tail when the caller takes bits only
+    size_t symscratch_len = 0;
     unsigned long long* d_nread = nullptr;
     cf* d_carry[2] = { nullptr, nullptr };
     int* d_carry_len[2] = { nullptr, nullptr };
@@ -536,8 +548,11 @@ static int msk_init_state(aisx_msk* h)
     AISX_HIPCHK(hipMemset(h->d_dly1, 0, sizeof(cf) * nc));
     AISX_HIPCHK(hipMemset(h->d_dly2, 0, sizeof(cf) * nc));
     AISX_HIPCHK(hipMemset(h->d_diff1, 0, sizeof(cf) * nc));
-    AISX_HIPCHK(hipMemset(h->d_tprev, 0, sizeof(cf) * nc));
-    AISX_HIPCHK(hipMemset(h->d_tbit, 0, nc));
+    for (int k = 0; k < 2; k++) {
+        AISX_HIPCHK(hipMemset(h->d_tprev[k], 0, sizeof(cf) * nc));
+        AISX_HIPCHK(hipMemset(h->d_tbit[k], 0, nc));
+    }
+    h->tcur = 0;
     AISX_HIPCHK(hipMemset(h->d_nread, 0, sizeof(unsigned long long) * nc));
     for (int k = 0; k < 2; k++) {
         AISX_HIPCHK(hipMemset(h->d_carry[k], 0, sizeof(cf) * (size_t)nc * aisx_msk::carry_cap));
@@ -591,8 +606,10 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     CK(dev_alloc(&h->d_dly1, nchan));
     CK(dev_alloc(&h->d_dly2, nchan));
     CK(dev_alloc(&h->d_diff1, nchan));
-    CK(dev_alloc(&h->d_tprev, nchan));
-    CK(dev_alloc(&h->d_tbit, nchan));
+    for (int k = 0; k < 2; k++) {
+        CK(dev_alloc(&h->d_tprev[k], nchan));
+        CK(dev_alloc(&h->d_tbit[k], nchan));
+    }
     CK(dev_alloc(&h->d_nread, nchan));
     for (int k = 0; k < 2; k++) {
         CK(dev_alloc(&h->d_carry[k], (size_t)nchan * aisx_msk::carry_cap));
@@ -627,8 +644,11 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     dev_free(h->d_dly1);
     dev_free(h->d_dly2);
     dev_free(h->d_diff1);
-    dev_free(h->d_tprev);
-    dev_free(h->d_tbit);
+    for (int k = 0; k < 2; k++) {
+        dev_free(h->d_tprev[k]);
+        dev_free(h->d_tbit[k]);
+    }
+    dev_free(h->d_symscratch);
     dev_free(h->d_nread);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_carry[k]);
@@ -704,8 +724,6 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.dly1 = h->d_dly1;
     p.dly2 = h->d_dly2;
     p.diff1 = h->d_diff1;
-    p.tail_prev_sym = h->d_tprev;
-    p.tail_prev_bit = h->d_tbit;
     p.nread = h->d_nread;
     p.carry_in = h->d_carry[h->cur];
     p.carry_out = h->d_carry[h->cur ^ 1];
@@ -720,7 +738,29 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
-    p.atan_tab = h->d_atan;
+}
+
+// the NRZI bit tail over the symbols the timing-recovery kernel just wrote
+static int msk_launch_bittail(aisx_msk* h, const cf* syms, long sym_stride, const int* produced, uint8_t* bits,
+                              long bit_stride, int max_out, hipStream_t st)
+{
+    BitTailParams b;
+    b.nchan = h->nchan;
+    b.syms = syms;
+    b.sym_stride = sym_stride;
+    b.produced = produced;
+    b.bits = bits;
+    b.bit_stride = bit_stride;
+    b.prev_sym_in = h->d_tprev[h->tcur];
+    b.prev_bit_in = h->d_tbit[h->tcur];
+    b.prev_sym_out = h->d_tprev[h->tcur ^ 1];
+    b.prev_bit_out = h->d_tbit[h->tcur ^ 1];
+    b.atan_tab = h->d_atan;
+    const int nseg = std::max(1, (max_out + BT_SEG - 1) / BT_SEG);
+    hipLaunchKernelGGL(k_bittail, dim3(nseg, h->nchan), dim3(BT_T), 0, st, b);
+    AISX_HIPCHK(hipGetLastError());
+    h->tcur ^= 1;
+    return AISX_OK;
 }
 
 extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
@@ -745,19 +785,38 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.tags = (const tag_rec*)d_tags;
     p.tag_count = d_tag_counts;
     p.tag_cap = tag_cap;
-    p.syms = (cf*)d_syms;
+    int rc;
+    cf* syms = (cf*)d_syms;
+    if (d_bits && !syms) { // the bit tail reads the symbols back: give them a home
+        const size_t need = (size_t)h->nchan * (size_t)out_stride;
+        if (need > h->symscratch_len) {
+            AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            dev_free(h->d_symscratch);
+            h->d_symscratch = nullptr;
+            h->symscratch_len = 0;
+            if ((rc = dev_alloc(&h->d_symscratch, need)) != AISX_OK)
+                return rc;
+            h->symscratch_len = need;
+        }
+        syms = h->d_symscratch;
+    }
+    p.syms = syms;
     p.err = d_err;
     p.mu_out = d_mu;
-    p.bits = d_bits;
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : h->d_produced;
-    int rc = msk_enable_big_lds();
-    if (rc != AISX_OK)
+    if ((rc = msk_enable_big_lds()) != AISX_OK)
         return rc;
     hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(MSK_T), MSK_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
+    if (d_bits) {
+        // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
+        const int max_out = std::min<long>(p.out_cap, (long)((n + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * h->osps + 16);
+        if ((rc = msk_launch_bittail(h, syms, out_stride, p.produced, d_bits, out_stride, max_out, (hipStream_t)stream)) != AISX_OK)
+            return rc;
+    }
     return AISX_OK;
 }
 
@@ -842,7 +901,6 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     p.syms = h->d_st_sym;
     p.err = h->d_st_err;
     p.mu_out = h->d_st_mu;
-    p.bits = h->d_st_bits;
     p.out_stride = noutput_items;
     p.out_cap = noutput_items;
     p.produced = h->d_produced;
@@ -851,6 +909,9 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     hipLaunchKernelGGL(k_msk, dim3(1), dim3(MSK_T), MSK_LDS_BYTES, 0, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
+    if ((rc = msk_launch_bittail(h, h->d_st_sym, noutput_items, h->d_produced, h->d_st_bits, noutput_items,
+                                 noutput_items, 0)) != AISX_OK)
+        return rc;
     int st = 0;
     AISX_HIPCHK(hipMemcpy(produced, h->d_produced, sizeof(int), hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(consumed, h->d_consumed, sizeof(int), hipMemcpyDeviceToHost));

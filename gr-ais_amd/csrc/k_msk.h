@@ -1,6 +1,6 @@
 // k_msk.h -- msk_timing_recovery_cc (reference: lib/msk_timing_recovery_cc_impl.cc
-// :107-206) with the NRZI bit tail of python/ais_demod.py:48-52 + lib/invert_impl.cc
-// :62-64 fused into the epilogue.
+// :107-206), and the NRZI bit tail of python/ais_demod.py:48-52 + lib/invert_impl.cc
+// :62-64 as a second, fully parallel kernel over the symbols the first one wrote.
 //
 // The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
 // is across channels, so one lane owns one channel and a wave owns 64.  Every
@@ -12,9 +12,24 @@
 // 16-byte load per lane per two samples, each lane walking its own row, issued
 // BEFORE the iterations that consume chunk t-1 so the loads fly under the
 // recurrence) and landed afterwards; lanes then iterate, each at its own pace,
-// until none can go on without the next chunk.  Symbols and bits are stored
-// straight from the loop (fire and forget).  All arithmetic is the reference's
-// float/double sequence, unfused: bit-identical to the CPU restatement.
+// until none can go on without the next chunk.  Symbols are stored straight from
+// the loop (fire and forget).
+//
+// A lone wave issues one instruction every ~2.3 ns whatever the dependencies
+// (tools/ubench), so the loop is written for instruction count:
+//  * the reference's iteration comes in two kinds, d_div even (emit a symbol) and
+//    d_div odd (run the loop filter).  The body is unrolled into an even step and an
+//    odd step, each executed by the lanes of that parity: lanes fall into lock step
+//    after one pass and stay there (a time_est tag can shift a lane by one step, it
+//    rejoins on the next pass), so neither kind pays for the other;
+//  * every rare event of the reference's loop head (end of this general_work call,
+//    the next chunk not landed yet, a time_est tag coming into range) is folded into
+//    one per-lane bound fast_lim on iidx; only a lane that reaches it runs the
+//    event code, behind a wave-uniform branch;
+//  * the bit tail (quadrature demod, slicer, differential decoder, invert) has no
+//    feedback into the loop and runs afterwards over all symbols in parallel.
+// All arithmetic is the reference's float/double sequence, unfused: bit-identical
+// to the CPU restatement.
 #pragma once
 #include "aisx_common.h"
 
@@ -31,8 +46,9 @@ constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
 constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
 constexpr int MSK_LDS_MMSE = ((129 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
-constexpr int MSK_LDS_ATAN = 260 * 4;
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_ATAN;
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE;
+constexpr int BT_T = 256;          // bit tail: threads per workgroup
+constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
 struct MskParams {
     int nchan;
@@ -42,7 +58,6 @@ struct MskParams {
     // per-channel loop state
     float* mu; float* omega; int* div;
     cf* dly1; cf* dly2; cf* diff1;
-    cf* tail_prev_sym; unsigned char* tail_prev_bit;
     unsigned long long* nread; // nitems_read(0)
     // input: stream mode = carry (pre-item + pending items) followed by n new items
     const cf* in; long in_stride; int n;
@@ -53,9 +68,20 @@ struct MskParams {
     const tag_rec* tags; const int* tag_count; int tag_cap;
     const tag_rec* ctag_in; tag_rec* ctag_out; const int* ctag_n_in; int* ctag_n_out; int ctag_cap;
     // outputs
-    cf* syms; float* err; float* mu_out; unsigned char* bits; long out_stride; int out_cap;
+    cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
+};
+
+// quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
+// symbols of one msk call; the previous symbol / previous sliced bit are the only state
+struct BitTailParams {
+    int nchan;
+    const cf* syms; long sym_stride;
+    const int* produced;
+    unsigned char* bits; long bit_stride;
+    const cf* prev_sym_in; const unsigned char* prev_bit_in; // state before this call
+    cf* prev_sym_out; unsigned char* prev_bit_out;           // state after it (a different buffer)
     const float* atan_tab;
 };
 
@@ -76,21 +102,16 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     char* lds = cx.lds();
     cf* ring = (cf*)lds;                       // [MSK_SLOTS][64]
     float* mm = (float*)(lds + MSK_LDS_RING);
-    float* at = (float*)(lds + MSK_LDS_RING + MSK_LDS_MMSE);
     cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
 
     for (int i = l; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
-    for (int i = l; i < 257; i += 64)
-        at[i] = p.atan_tab[i];
 
     const float d_sps = p.d_sps;
     float d_mu = p.mu[cc], d_omega = p.omega[cc];
     int d_div = p.div[cc];
     cf d_dly_conj_1 = p.dly1[cc], d_dly_conj_2 = p.dly2[cc], d_dly_diff_1 = p.diff1[cc];
     cf prev_sq = cmul_exact(d_dly_conj_2, d_dly_conj_2);
-    cf tprev = p.tail_prev_sym[cc];
-    unsigned char tbit = p.tail_prev_bit[cc];
     const unsigned long long R = p.nread[cc];
     int status = 0;
     const int n = p.n;
@@ -120,8 +141,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int ntot = nct + nnt;
     int tpos = 0;
     auto tag_at = [&](int k) -> const tag_rec& { return (k < nct) ? ctg[k] : ntg[k - nct]; };
-    // the front of the tag queue is kept in registers: the loop below tests it on
-    // every iteration and must not pay a global load for that
+    // the front of the tag queue is kept in registers
     unsigned long long nt_off = ~0ull;
     float nt_val = 0.f;
     int nt_rel = 0x7fffffff; // offset of the front tag relative to this call's nitems_read, if in range
@@ -139,7 +159,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     float* oerr = p.err ? p.err + (long)cc * p.out_stride : nullptr;
     float* omu = p.mu_out ? p.mu_out + (long)cc * p.out_stride : nullptr;
     cf* osymg = p.syms ? p.syms + (long)cc * p.out_stride : nullptr;
-    unsigned char* obitg = p.bits ? p.bits + (long)cc * p.out_stride : nullptr;
 
     // ---- "scheduler": one general_work() call after another (stream mode) ----
     int base = 0, ototal = 0;     // items consumed / produced by finished calls
@@ -220,111 +239,151 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int landed = 1; // chunks in the rings
     cx.sync();
 
+    // spos = ring position of in[iidx] (new-sample index + MSK_OFF, unmasked); it moves
+    // with iidx and is untouched by the end of a general_work call (base += iidx, iidx = 0)
+    int spos = base + iidx - pending + MSK_OFF;
+    // iterations with iidx < fast_lim (and oidx < noutput) need none of the event code
+    int fast_lim = (int)0x80000000;
+    int tag_trig = (int)0x80000000; // first iidx at which the front tag can fire
+    bool parked = done;             // nothing more to do before the next chunk lands (or ever)
+    bool more = false;
+    int loaded_s = 0;
+
+    // the reference's loop head for one lane, in its order (:138-164); true = run the body now
+    auto events = [&](const int PAR) -> bool {
+        if (!(oidx < noutput && iidx < ninp)) { // this general_work() call is over (:138)
+            base += iidx;                       // consume_each(iidx)
+            ototal += oidx;
+            const bool progress = (iidx > 0) || (oidx > 0);
+            if (!p.stream_mode || !progress)
+                done = true;
+            else
+                setup_round();
+        }
+        if (done) {
+            parked = true;
+            return false;
+        }
+        if (more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s)) { // wait for the next chunk
+            parked = true;
+            return false;
+        }
+        // a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
+        if ((nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps))) {
+            const float center = nt_val;
+            if (center == center) { // not NaN (:144-147)
+                const int old = iidx;
+                d_mu = center;
+                iidx = nt_rel;
+                if (d_mu < 0) {
+                    d_mu++;
+                    iidx--;
+                }
+                spos += iidx - old;
+                d_div = 0;
+                d_omega = d_sps;
+                d_dly_conj_2 = d_dly_conj_1; // (prev_sq already is d_dly_conj_1^2)
+            }
+            tpos++;
+            skip_other_keys();
+            nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
+            tag_trig = (int)0x80000000;
+            fast_lim = iidx + 1; // the reference runs this iteration whatever comes next: one
+                                 // iteration, then back here (one tag per iteration, :140)
+            return (d_div & 1) == PAR;
+        }
+        // nothing pending: how far can this lane run before the next event?
+        tag_trig = 0x7fffffff;
+        if (nt_rel != 0x7fffffff && iidx <= nt_rel) { // (a tag the loop stepped over stays in front for good)
+            int i = nt_rel - jump_margin - 1;
+            while (!((float)nt_rel < ((float)i + d_sps)))
+                i++;
+            tag_trig = i;
+        }
+        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - (spos - iidx) + 1) : 0x7fffffff;
+        fast_lim = ninp < tag_trig ? ninp : tag_trig;
+        fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
+        return true;
+    };
+
+    // one reference iteration (:166-201) for the lanes whose d_div has parity PAR
+    auto step = [&](const int PAR) {
+        const bool mine = !parked && ((d_div & 1) == PAR);
+        bool go = mine && (iidx < fast_lim) && (oidx < noutput);
+        const bool ev = mine && !go;
+        if (cx.ballot(ev) != 0ull) {
+            if (ev)
+                go = events(PAR);
+        }
+        if (cx.ballot(go) == 0ull)
+            return;
+        if (go) {
+            // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
+            const int imu = (int)rintf(d_mu * 128.0f);
+            const bool bad = (unsigned)imu > 128u; // upstream throws std::runtime_error
+            const float* tp = mm + (bad ? 0 : imu) * MSK_TAPS_PITCH;
+            const cf* sp = myring + (spos & (MSK_RING - 1)) * 64;
+            cf acc = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
+                const float tk = tp[7 - k];
+                acc.re += s.re * tk;
+                acc.im += s.im * tk;
+            }
+            const cf in_interp = bad ? mk(0.f, 0.f) : acc;
+            status |= bad ? MSK_ST_INTERP_RANGE : 0;
+            const cf sq = cmul_exact(in_interp, in_interp);                    // :171
+            // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
+            // (:194-195, also after a tag reset :160), so its square is the previous sq
+            const cf dly_conj = cconj(prev_sq);
+            const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
+            float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
+            if (PAR) {                                                         // :179-184
+                err_out = branchless_clip(err_out, 3.0f);
+                d_omega += p.gain_omega * err_out;
+                d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+                d_mu += p.gain * err_out;
+            }
+            if (!PAR || p.osps == 2) { // :186-191
+                const int oo = ototal + oidx;
+                if (osymg)
+                    osymg[oo] = in_interp;
+                if (oerr)
+                    oerr[oo] = err_out;
+                if (omu)
+                    omu[oo] = d_mu;
+                oidx++;
+            }
+            d_div++;
+            d_dly_conj_1 = in_interp; // :194-196
+            d_dly_conj_2 = d_dly_conj_1;
+            prev_sq = sq;
+            d_dly_diff_1 = nlin_out;
+            d_mu += d_omega; // :199-201
+            const float fl = floorf(d_mu);
+            const int adv = (int)fl;
+            iidx += adv;
+            spos += adv;
+            d_mu = d_mu - fl;
+        }
+    };
+
     for (;;) {
         if (cx.ballot(!done) == 0ull)
             break;
-        const bool more = landed < nchunks;
+        more = landed < nchunks;
         if (more)
             issue_chunk(landed);
-        const int loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
-        // ---------------- the recurrence: every lane goes as far as its data allows ----------------
+        loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
+        parked = done;
+        fast_lim = (int)0x80000000;    // every lane recomputes its bound against the new horizon
+        // ------------- the recurrence: every lane goes as far as its data allows -------------
         for (;;) {
-            // (rare) this general_work() call is over (:138): consume, start the next one
-            const bool round_ev = !done && !(oidx < noutput && iidx < ninp);
-            if (cx.ballot(round_ev) != 0ull) {
-                if (round_ev) {
-                    base += iidx; // consume_each(iidx)
-                    ototal += oidx;
-                    const bool progress = (iidx > 0) || (oidx > 0);
-                    if (!p.stream_mode || !progress)
-                        done = true;
-                    else
-                        setup_round();
-                }
-            }
-            const int pos_s = base + iidx - pending;
-            const bool can = !done && (!more || (pos_s + 8 + jump_margin <= loaded_s));
-            if (cx.ballot(can) == 0ull)
+            step(0);
+            step(1);
+            if (cx.ballot(!parked) == 0ull)
                 break;
-            // (rare) a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
-            const bool tag_ev = can && (nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps));
-            if (cx.ballot(tag_ev) != 0ull) {
-                if (tag_ev) {
-                    const float center = nt_val;
-                    if (center == center) { // not NaN (:144-147)
-                        d_mu = center;
-                        iidx = nt_rel;
-                        if (d_mu < 0) {
-                            d_mu++;
-                            iidx--;
-                        }
-                        d_div = 0;
-                        d_omega = d_sps;
-                        d_dly_conj_2 = d_dly_conj_1; // (prev_sq already is d_dly_conj_1^2)
-                    }
-                    tpos++;
-                    skip_other_keys();
-                    nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
-                }
-            }
-            if (can) {
-                // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
-                const int imu = (int)rintf(d_mu * 128.0f);
-                cf in_interp = mk(0.f, 0.f);
-                if (imu < 0 || imu > 128) {
-                    status |= MSK_ST_INTERP_RANGE; // upstream throws std::runtime_error
-                } else {
-                    const float* tp = mm + imu * MSK_TAPS_PITCH;
-                    const cf* sp = myring + ((base + iidx - pending + MSK_OFF) & (MSK_RING - 1)) * 64;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
-                        const float tk = tp[7 - k];
-                        in_interp.re += s.re * tk;
-                        in_interp.im += s.im * tk;
-                    }
-                }
-                const cf sq = cmul_exact(in_interp, in_interp);                    // :171
-                // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
-                // (:194-195, also after a tag reset :160), so its square is the previous sq
-                const cf dly_conj = cconj(prev_sq);
-                const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
-                float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
-                if (d_div & 1) {                                                   // :179-184
-                    err_out = branchless_clip(err_out, 3.0f);
-                    d_omega += p.gain_omega * err_out;
-                    d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
-                    d_mu += p.gain * err_out;
-                }
-                if (!(d_div & 1) || p.osps == 2) { // :186-191
-                    const int oo = ototal + oidx;
-                    if (osymg)
-                        osymg[oo] = in_interp;
-                    if (oerr)
-                        oerr[oo] = err_out;
-                    if (omu)
-                        omu[oo] = d_mu;
-                    // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert
-                    const cf prod = cmul_exact(in_interp, cconj(tprev));
-                    const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, at);
-                    const unsigned char b = fm >= 0 ? 1 : 0;
-                    const unsigned char d = (unsigned char)(((unsigned)(b - tbit)) % 2u);
-                    if (obitg)
-                        obitg[oo] = (unsigned char)((d ^ 0x01) & 0x01);
-                    tprev = in_interp;
-                    tbit = b;
-                    oidx++;
-                }
-                d_div++;
-                d_dly_conj_1 = in_interp; // :194-196
-                d_dly_conj_2 = d_dly_conj_1;
-                prev_sq = sq;
-                d_dly_diff_1 = nlin_out;
-                d_mu += d_omega; // :199-201
-                const float fl = floorf(d_mu);
-                iidx += (int)fl;
-                d_mu = d_mu - fl;
-            }
         }
         // ---------------- land the prefetched chunk ----------------
         if (more) {
@@ -342,8 +401,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     p.dly1[c] = d_dly_conj_1;
     p.dly2[c] = d_dly_conj_2;
     p.diff1[c] = d_dly_diff_1;
-    p.tail_prev_sym[c] = tprev;
-    p.tail_prev_bit[c] = tbit;
     const unsigned long long Rn = R + (unsigned long long)base;
     p.nread[c] = Rn;
     p.produced[c] = ototal;
@@ -380,6 +437,54 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         p.ctag_n_out[c] = 0;
     }
     p.status[c] = status;
+}
+
+// Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)
+// turns symbols [seg * BT_SEG, +BT_SEG) of channel ch into bits.
+//   b[o]   = binary_slicer(quadrature_demod: pi/2 * fast_atan2f(sym[o] * conj(sym[o-1])))
+//   bit[o] = ((b[o] - b[o-1]) mod 2) ^ 1
+// with sym[-1] / b[-1] the state left by the previous call.
+template <class Ctx>
+AISX_DI void bittail_body(Ctx& cx, const BitTailParams& p)
+{
+    const int ch = cx.by();
+    const int t = cx.tid();
+    float* at = (float*)cx.lds();
+    for (int i = t; i < 257; i += BT_T)
+        at[i] = p.atan_tab[i];
+    cx.sync();
+    const int P = p.produced[ch];
+    const cf* sy = p.syms + (long)ch * p.sym_stride;
+    unsigned char* ob = p.bits + (long)ch * p.bit_stride;
+    const cf sym_m1 = p.prev_sym_in[ch];
+    const unsigned char bit_m1 = p.prev_bit_in[ch];
+    auto slice = [&](const cf& cur, const cf& prev) -> unsigned char {
+        const cf prod = cmul_exact(cur, cconj(prev));
+        const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, at);
+        return fm >= 0 ? 1 : 0;
+    };
+    if (cx.bx() == 0 && t == 0 && P == 0) { // nothing produced: the state carries over
+        p.prev_sym_out[ch] = sym_m1;
+        p.prev_bit_out[ch] = bit_m1;
+    }
+    const int o0 = cx.bx() * BT_SEG;
+    for (int k = 0; k < BT_SEG / BT_T; k++) {
+        const int o = o0 + k * BT_T + t;
+        if (o >= P)
+            break;
+        const cf s0 = sy[o];
+        const cf s1 = o >= 1 ? sy[o - 1] : sym_m1;
+        const unsigned char b = slice(s0, s1);
+        unsigned char bp = bit_m1;
+        if (o >= 1)
+            bp = slice(s1, o >= 2 ? sy[o - 2] : sym_m1);
+        const unsigned char d = (unsigned char)(((unsigned)(b - bp)) % 2u);
+        ob[o] = (unsigned char)((d ^ 0x01) & 0x01);
+        if (o == P - 1) {
+            p.prev_sym_out[ch] = s0;
+            p.prev_bit_out[ch] = b;
+        }
+    }
 }
 
 } // namespace aisx

@@ -148,6 +148,12 @@ void emu_corr_resolve(const ResolveParams* p, int nchan)
     run_grid(nchan, 1, 64, 0, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
 }
 
+void emu_bittail(const BitTailParams* p, int max_out)
+{
+    const int nseg = std::max(1, (max_out + BT_SEG - 1) / BT_SEG);
+    run_grid(nseg, p->nchan, BT_T, 260 * 4, [&](EmuCtx& cx) { bittail_body(cx, *p); });
+}
+
 void emu_msk(const MskParams* p)
 {
     run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) { msk_body(cx, *p); });
@@ -224,8 +230,9 @@ struct EmuMsk {
     static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     std::vector<float> mu, omega;
     std::vector<int> div, carry_len[2], ctag_n[2], produced, consumed, status;
-    std::vector<cf> dly1, dly2, diff1, tprev, carry[2];
-    std::vector<unsigned char> tbit;
+    std::vector<cf> dly1, dly2, diff1, tprev[2], carry[2], symscratch;
+    std::vector<unsigned char> tbit[2];
+    int tcur = 0;
     std::vector<unsigned long long> nread;
     std::vector<tag_rec> ctag[2];
     int cur = 0;
@@ -237,8 +244,9 @@ void* emu_msk_create(float sps, float gain, float limit, int osps, int nchan)
     MskSetup ms = msk_setup(sps, gain);
     h->nchan = nchan; h->osps = osps; h->d_sps = ms.d_sps; h->gain = gain; h->gain_omega = ms.gain_omega; h->limit = limit;
     h->mu.assign(nchan, 0.5f); h->omega.assign(nchan, ms.d_sps); h->div.assign(nchan, 0);
-    h->dly1.assign(nchan, mk(0, 0)); h->dly2 = h->dly1; h->diff1 = h->dly1; h->tprev = h->dly1;
-    h->tbit.assign(nchan, 0); h->nread.assign(nchan, 0ull);
+    h->dly1.assign(nchan, mk(0, 0)); h->dly2 = h->dly1; h->diff1 = h->dly1;
+    h->tprev[0] = h->dly1; h->tprev[1] = h->dly1;
+    h->tbit[0].assign(nchan, 0); h->tbit[1].assign(nchan, 0); h->nread.assign(nchan, 0ull);
     for (int k = 0; k < 2; k++) {
         h->carry[k].assign((size_t)nchan * EmuMsk::carry_cap, mk(0, 0));
         h->carry_len[k].assign(nchan, 0);
@@ -255,13 +263,26 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.nchan = h->nchan; p.d_sps = h->d_sps; p.gain = h->gain; p.gain_omega = h->gain_omega; p.limit = h->limit; p.osps = h->osps;
     p.mu = h->mu.data(); p.omega = h->omega.data(); p.div = h->div.data();
     p.dly1 = h->dly1.data(); p.dly2 = h->dly2.data(); p.diff1 = h->diff1.data();
-    p.tail_prev_sym = h->tprev.data(); p.tail_prev_bit = h->tbit.data(); p.nread = h->nread.data();
+    p.nread = h->nread.data();
     p.carry_in = h->carry[h->cur].data(); p.carry_out = h->carry[h->cur ^ 1].data();
     p.carry_len_in = h->carry_len[h->cur].data(); p.carry_len_out = h->carry_len[h->cur ^ 1].data(); p.carry_cap = EmuMsk::carry_cap;
     p.ctag_in = h->ctag[h->cur].data(); p.ctag_out = h->ctag[h->cur ^ 1].data();
     p.ctag_n_in = h->ctag_n[h->cur].data(); p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
-    p.mmse = &aisx_mmse_taps[0][0]; p.atan_tab = aisx_atan_table;
+    p.mmse = &aisx_mmse_taps[0][0];
+}
+
+static void emu_msk_bittail(EmuMsk* h, const cf* syms, long sym_stride, const int* produced, unsigned char* bits,
+                            long bit_stride, int max_out)
+{
+    BitTailParams b;
+    b.nchan = h->nchan; b.syms = syms; b.sym_stride = sym_stride; b.produced = produced;
+    b.bits = bits; b.bit_stride = bit_stride;
+    b.prev_sym_in = h->tprev[h->tcur].data(); b.prev_bit_in = h->tbit[h->tcur].data();
+    b.prev_sym_out = h->tprev[h->tcur ^ 1].data(); b.prev_bit_out = h->tbit[h->tcur ^ 1].data();
+    b.atan_tab = aisx_atan_table;
+    emu_bittail(&b, max_out);
+    h->tcur ^= 1;
 }
 
 int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const tag_rec* tags, const int* tag_counts,
@@ -273,10 +294,16 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
     emu_msk_fill(h, p);
     p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
     p.tags = tags; p.tag_count = tag_counts; p.tag_cap = tag_cap;
-    p.syms = syms; p.err = err; p.mu_out = mu; p.bits = bits; p.out_stride = out_stride; p.out_cap = (int)out_stride;
+    if (bits && !syms) {
+        h->symscratch.resize((size_t)h->nchan * out_stride);
+        syms = h->symscratch.data();
+    }
+    p.syms = syms; p.err = err; p.mu_out = mu; p.out_stride = out_stride; p.out_cap = (int)out_stride;
     p.produced = produced;
     emu_msk(&p);
     h->cur ^= 1;
+    if (bits)
+        emu_msk_bittail(h, syms, out_stride, produced, bits, out_stride, (int)out_stride);
     int st = 0;
     for (int c = 0; c < h->nchan; c++) {
         st |= h->status[c];
@@ -298,10 +325,12 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
     h->ctag_n[h->cur][0] = 0;
     p.in = in; p.in_stride = ninput + 1; p.n = ninput; p.stream_mode = 0; p.gr_ninput = ninput; p.gr_noutput = noutput;
     p.tags = tags; p.tag_count = &ntags; p.tag_cap = ntags + 1;
-    p.syms = out; p.err = err; p.mu_out = mu; p.bits = bits; p.out_stride = noutput; p.out_cap = noutput;
+    p.syms = out; p.err = err; p.mu_out = mu; p.out_stride = noutput; p.out_cap = noutput;
     p.produced = h->produced.data();
     emu_msk(&p);
     h->cur ^= 1;
+    if (bits)
+        emu_msk_bittail(h, out, noutput, h->produced.data(), bits, noutput, noutput);
     *consumed = h->consumed[0];
     *produced = h->produced[0];
     return h->status[0];
