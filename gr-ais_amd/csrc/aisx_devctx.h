@@ -15,6 +15,8 @@ struct DevCtx {
     __device__ __forceinline__ char* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
+    // per-lane predicate from a wave-uniform mask (the mask goes straight into exec / vcc)
+    __device__ __forceinline__ bool inv_ballot(unsigned long long m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
     __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) const
     {
         return __shfl(v, src, 64);

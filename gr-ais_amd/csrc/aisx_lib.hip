@@ -76,11 +76,12 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
     corr_resolve_body(cx, p);
 }
 
+template <bool AUX, bool OSPS2>
 __global__ __launch_bounds__(MSK_T) void k_msk(MskParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
-    msk_body(cx, p);
+    msk_body<DevCtx, AUX, OSPS2>(cx, p);
 }
 
 __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
@@ -90,13 +91,19 @@ __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
     bittail_body(cx, p);
 }
 
-static int msk_enable_big_lds()
+// launch the timing-recovery build for (err/mu ports connected, osps == 2)
+static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
 {
-    static bool done = false;
-    if (!done) {
-        AISX_HIPCHK(hipFuncSetAttribute((const void*)k_msk, hipFuncAttributeMaxDynamicSharedMemorySize, MSK_LDS_BYTES));
-        done = true;
+    typedef void (*kfn)(MskParams);
+    static const kfn fns[4] = { k_msk<false, false>, k_msk<false, true>, k_msk<true, false>, k_msk<true, true> };
+    static bool big_lds[4] = { false, false, false, false };
+    const int v = ((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0);
+    if (!big_lds[v]) {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, MSK_LDS_BYTES));
+        big_lds[v] = true;
     }
+    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(MSK_T), MSK_LDS_BYTES, st, p);
+    AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }
 
@@ -772,8 +779,10 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         set_err("aisx_msk_process_stream: bad argument");
         return AISX_ERR_INVALID;
     }
-    if ((d_syms || d_err || d_mu || d_bits) && out_stride < 1)
+    if (out_stride < 1) {
+        set_err("aisx_msk_process_stream: out_stride < 1");
         return AISX_ERR_INVALID;
+    }
     MskParams p;
     msk_fill_common(h, p);
     p.in = (const cf*)d_in;
@@ -787,7 +796,11 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.tag_cap = tag_cap;
     int rc;
     cf* syms = (cf*)d_syms;
-    if (d_bits && !syms) { // the bit tail reads the symbols back: give them a home
+    if (out_stride >= (1L << 23)) {
+        set_err("aisx_msk_process_stream: out_stride %ld too large (the 64 rows of a wave must lie within 4 GiB)", out_stride);
+        return AISX_ERR_INVALID;
+    }
+    if (!syms) { // the kernel always writes symbols (the bit tail reads them back): give them a home
         const size_t need = (size_t)h->nchan * (size_t)out_stride;
         if (need > h->symscratch_len) {
             AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -806,10 +819,8 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : h->d_produced;
-    if ((rc = msk_enable_big_lds()) != AISX_OK)
+    if ((rc = msk_launch(p, (h->nchan + 63) / 64, (hipStream_t)stream)) != AISX_OK)
         return rc;
-    hipLaunchKernelGGL(k_msk, dim3((h->nchan + 63) / 64), dim3(MSK_T), MSK_LDS_BYTES, (hipStream_t)stream, p);
-    AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     if (d_bits) {
         // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
@@ -904,10 +915,8 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     p.out_stride = noutput_items;
     p.out_cap = noutput_items;
     p.produced = h->d_produced;
-    if ((rc = msk_enable_big_lds()) != AISX_OK)
+    if ((rc = msk_launch(p, 1, 0)) != AISX_OK)
         return rc;
-    hipLaunchKernelGGL(k_msk, dim3(1), dim3(MSK_T), MSK_LDS_BYTES, 0, p);
-    AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     if ((rc = msk_launch_bittail(h, h->d_st_sym, noutput_items, h->d_produced, h->d_st_bits, noutput_items,
                                  noutput_items, 0)) != AISX_OK)

@@ -25,7 +25,9 @@
 //  * every rare event of the reference's loop head (end of this general_work call,
 //    the next chunk not landed yet, a time_est tag coming into range) is folded into
 //    one per-lane bound fast_lim on iidx; only a lane that reaches it runs the
-//    event code, behind a wave-uniform branch;
+//    event code, behind a wave-uniform branch.  Lane predicates (parked, parity)
+//    live as 64-bit wave masks in scalar registers: the per-step bookkeeping is a
+//    handful of scalar ops;
 //  * the bit tail (quadrature demod, slicer, differential decoder, invert) has no
 //    feedback into the loop and runs afterwards over all symbols in parallel.
 // All arithmetic is the reference's float/double sequence, unfused: bit-identical
@@ -45,10 +47,14 @@ constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_O
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
 constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
-constexpr int MSK_LDS_MMSE = ((129 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
+constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
+constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
 constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE;
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
+
+// two consecutive samples of a row; rows are only 8-byte aligned
+struct __attribute__((packed, aligned(8))) cf_pair { cf a, b; };
 
 struct MskParams {
     int nchan;
@@ -67,7 +73,7 @@ struct MskParams {
     // tags: new ones from this call + carried ones
     const tag_rec* tags; const int* tag_count; int tag_cap;
     const tag_rec* ctag_in; tag_rec* ctag_out; const int* ctag_n_in; int* ctag_n_out; int ctag_cap;
-    // outputs
+    // outputs (syms is mandatory; rows of one wave must lie within 4 GiB: out_stride < 2^23)
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
@@ -90,9 +96,11 @@ AISX_HD int msk_forecast(float d_sps, int noutput_items)
     return (int)ceil((noutput_items * d_sps * 2) + 3.0 * d_sps + 8u);
 }
 
-template <class Ctx>
+// AUX: the err / mu output ports are connected (:187-189).  OSPS2: osps == 2 (:186).
+template <class Ctx, bool AUX, bool OSPS2>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
+    typedef unsigned long long u64;
     const int l = cx.tid();
     const int cbase = cx.bx() * 64;
     const int c = cbase + l;
@@ -106,12 +114,17 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 
     for (int i = l; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
+    if (l < MSK_TAPS_PITCH)
+        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f;
 
     const float d_sps = p.d_sps;
     float d_mu = p.mu[cc], d_omega = p.omega[cc];
     int d_div = p.div[cc];
-    cf d_dly_conj_1 = p.dly1[cc], d_dly_conj_2 = p.dly2[cc], d_dly_diff_1 = p.diff1[cc];
-    cf prev_sq = cmul_exact(d_dly_conj_2, d_dly_conj_2);
+    // d_dly_conj_1 and d_dly_conj_2 both hold the previous interpolated sample (:194-195);
+    // the loop only ever uses the square of it
+    cf last_interp = p.dly1[cc];
+    cf d_dly_diff_1 = p.diff1[cc];
+    cf prev_sq = cmul_exact(p.dly2[cc], p.dly2[cc]);
     const unsigned long long R = p.nread[cc];
     int status = 0;
     const int n = p.n;
@@ -156,9 +169,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
     };
 
-    float* oerr = p.err ? p.err + (long)cc * p.out_stride : nullptr;
-    float* omu = p.mu_out ? p.mu_out + (long)cc * p.out_stride : nullptr;
-    cf* osymg = p.syms ? p.syms + (long)cc * p.out_stride : nullptr;
+    // output rows are addressed as (wave-uniform base) + (32-bit byte offset of this lane)
+    char* const osym0 = (char*)(p.syms + (long)cbase * p.out_stride);
+    char* const oerr0 = AUX && p.err ? (char*)(p.err + (long)cbase * p.out_stride) : nullptr;
+    char* const omu0 = AUX && p.mu_out ? (char*)(p.mu_out + (long)cbase * p.out_stride) : nullptr;
+    unsigned ob = (unsigned)((long)(cc - cbase) * p.out_stride) * 8u; // byte offset of the next symbol
 
     // ---- "scheduler": one general_work() call after another (stream mode) ----
     int base = 0, ototal = 0;     // items consumed / produced by finished calls
@@ -216,11 +231,21 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const cf* myin = p.in + (long)cc * p.in_stride;
     auto issue_chunk = [&](int t) {
         const int s0 = t * MSK_CHUNK;
+        if (s0 + MSK_CHUNK <= n) { // whole chunk inside the input: 16-byte loads, no predicates
+            const cf_pair* src = (const cf_pair*)(myin + s0); // (dead lanes re-read the last channel's row)
 #pragma unroll
-        for (int k = 0; k < MSK_CHUNK; k++) {
-            r[k] = mk(0.f, 0.f);
-            if (live && s0 + k < n)
-                r[k] = myin[s0 + k];
+            for (int k = 0; k < MSK_CHUNK / 2; k++) {
+                const cf_pair v = src[k];
+                r[2 * k] = v.a;
+                r[2 * k + 1] = v.b;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < MSK_CHUNK; k++) {
+                r[k] = mk(0.f, 0.f);
+                if (live && s0 + k < n)
+                    r[k] = myin[s0 + k];
+            }
         }
     };
     auto land_chunk = [&](int t) {
@@ -239,18 +264,19 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int landed = 1; // chunks in the rings
     cx.sync();
 
-    // spos = ring position of in[iidx] (new-sample index + MSK_OFF, unmasked); it moves
-    // with iidx and is untouched by the end of a general_work call (base += iidx, iidx = 0)
-    int spos = base + iidx - pending + MSK_OFF;
+    // sb = 512 * (ring position of in[iidx]) = 512 * (new-sample index + MSK_OFF), unmasked:
+    // the byte offset of that slot row; it moves with iidx and is untouched by the end of a
+    // general_work call (base += iidx, iidx = 0)
+    int sb = (base + iidx - pending + MSK_OFF) * 512;
     // iterations with iidx < fast_lim (and oidx < noutput) need none of the event code
     int fast_lim = (int)0x80000000;
-    int tag_trig = (int)0x80000000; // first iidx at which the front tag can fire
-    bool parked = done;             // nothing more to do before the next chunk lands (or ever)
+    unsigned worst_imu = 0; // max over iterations of min(imu, MSK_ZERO_ROW)
     bool more = false;
     int loaded_s = 0;
+    enum { EV_PARK = 0, EV_GO = 1, EV_OTHER_PARITY = 2 };
 
-    // the reference's loop head for one lane, in its order (:138-164); true = run the body now
-    auto events = [&](const int PAR) -> bool {
+    // the reference's loop head for one lane, in its order (:138-164)
+    auto events = [&](const int PAR) -> int {
         if (!(oidx < noutput && iidx < ninp)) { // this general_work() call is over (:138)
             base += iidx;                       // consume_each(iidx)
             ototal += oidx;
@@ -260,14 +286,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             else
                 setup_round();
         }
-        if (done) {
-            parked = true;
-            return false;
-        }
-        if (more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s)) { // wait for the next chunk
-            parked = true;
-            return false;
-        }
+        if (done)
+            return EV_PARK;
+        const int spos = sb >> 9;
+        if (more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s)) // wait for the next chunk
+            return EV_PARK;
         // a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
         if ((nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps))) {
             const float center = nt_val;
@@ -279,21 +302,20 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     d_mu++;
                     iidx--;
                 }
-                spos += iidx - old;
+                sb += (iidx - old) * 512;
                 d_div = 0;
                 d_omega = d_sps;
-                d_dly_conj_2 = d_dly_conj_1; // (prev_sq already is d_dly_conj_1^2)
+                // (:160 d_dly_conj_2 = d_dly_conj_1: prev_sq already is the square of it)
             }
             tpos++;
             skip_other_keys();
             nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
-            tag_trig = (int)0x80000000;
             fast_lim = iidx + 1; // the reference runs this iteration whatever comes next: one
                                  // iteration, then back here (one tag per iteration, :140)
-            return (d_div & 1) == PAR;
+            return ((d_div & 1) == PAR) ? EV_GO : EV_OTHER_PARITY;
         }
         // nothing pending: how far can this lane run before the next event?
-        tag_trig = 0x7fffffff;
+        int tag_trig = 0x7fffffff;
         if (nt_rel != 0x7fffffff && iidx <= nt_rel) { // (a tag the loop stepped over stays in front for good)
             int i = nt_rel - jump_margin - 1;
             while (!((float)nt_rel < ((float)i + d_sps)))
@@ -303,36 +325,52 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - (spos - iidx) + 1) : 0x7fffffff;
         fast_lim = ninp < tag_trig ? ninp : tag_trig;
         fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
-        return true;
+        return EV_GO;
     };
+
+    u64 P = 0; // parked lanes: nothing more to do before the next chunk lands (or ever)
+    u64 E = 0; // lanes whose next iteration has d_div even
 
     // one reference iteration (:166-201) for the lanes whose d_div has parity PAR
     auto step = [&](const int PAR) {
-        const bool mine = !parked && ((d_div & 1) == PAR);
-        bool go = mine && (iidx < fast_lim) && (oidx < noutput);
-        const bool ev = mine && !go;
-        if (cx.ballot(ev) != 0ull) {
-            if (ev)
-                go = events(PAR);
+        const u64 mine = ~P & (PAR ? ~E : E);
+        // oidx < noutput was checked on the odd step before an even one and cannot have
+        // changed since (osps == 1: odd iterations emit nothing)
+        const bool ok = (PAR || OSPS2) ? ((iidx < fast_lim) && (oidx < noutput)) : (iidx < fast_lim);
+        const u64 okM = cx.ballot(ok);
+        u64 goM = mine & okM;
+        const u64 evM = mine & ~okM;
+        if (evM != 0ull) {
+            int code = -1;
+            if (cx.inv_ballot(evM))
+                code = events(PAR);
+            goM |= cx.ballot(code == EV_GO);
+            P |= cx.ballot(code == EV_PARK);
+            E = cx.ballot((d_div & 1) == 0);
         }
-        if (cx.ballot(go) == 0ull)
+        if (goM == 0ull)
             return;
-        if (go) {
-            // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170)
-            const int imu = (int)rintf(d_mu * 128.0f);
-            const bool bad = (unsigned)imu > 128u; // upstream throws std::runtime_error
-            const float* tp = mm + (bad ? 0 : imu) * MSK_TAPS_PITCH;
-            const cf* sp = myring + (spos & (MSK_RING - 1)) * 64;
-            cf acc = mk(0.f, 0.f);
+        if (cx.inv_ballot(goM)) {
+            // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170); an imu outside
+            // [0, 128] (upstream throws std::runtime_error) reads the zero row and is reported
+            const unsigned imu = (unsigned)(int)rintf(d_mu * 128.0f);
+            const unsigned row = imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
+            worst_imu = worst_imu > row ? worst_imu : row;
+            const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
+            const cf* sp = (const cf*)((const char*)myring + (sb & ((MSK_RING - 1) * 512)));
+            cf in_interp = mk(0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
+#ifndef MSK_EXP_NOLDS
                 const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
                 const float tk = tp[7 - k];
-                acc.re += s.re * tk;
-                acc.im += s.im * tk;
+#else
+                const cf s = mk(d_mu + k, d_omega * k);
+                const float tk = d_mu * (7 - k);
+#endif
+                in_interp.re += s.re * tk;
+                in_interp.im += s.im * tk;
             }
-            const cf in_interp = bad ? mk(0.f, 0.f) : acc;
-            status |= bad ? MSK_ST_INTERP_RANGE : 0;
             const cf sq = cmul_exact(in_interp, in_interp);                    // :171
             // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
             // (:194-195, also after a tag reset :160), so its square is the previous sq
@@ -345,28 +383,33 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
                 d_mu += p.gain * err_out;
             }
-            if (!PAR || p.osps == 2) { // :186-191
-                const int oo = ototal + oidx;
-                if (osymg)
-                    osymg[oo] = in_interp;
-                if (oerr)
-                    oerr[oo] = err_out;
-                if (omu)
-                    omu[oo] = d_mu;
+            if (!PAR || OSPS2) { // :186-191
+#ifndef MSK_EXP_NOSTORE
+                *(cf*)(osym0 + ob) = in_interp;
+#else
+                if (in_interp.re == 1.2345f) *(cf*)(osym0 + ob) = in_interp;
+#endif
+                if (AUX) {
+                    if (oerr0)
+                        *(float*)(oerr0 + (ob >> 1)) = err_out;
+                    if (omu0)
+                        *(float*)(omu0 + (ob >> 1)) = d_mu;
+                }
+                ob += 8u;
                 oidx++;
             }
             d_div++;
-            d_dly_conj_1 = in_interp; // :194-196
-            d_dly_conj_2 = d_dly_conj_1;
+            last_interp = in_interp; // :194-196
             prev_sq = sq;
             d_dly_diff_1 = nlin_out;
             d_mu += d_omega; // :199-201
             const float fl = floorf(d_mu);
             const int adv = (int)fl;
             iidx += adv;
-            spos += adv;
+            sb += adv * 512;
             d_mu = d_mu - fl;
         }
+        E ^= goM;
     };
 
     for (;;) {
@@ -376,13 +419,14 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (more)
             issue_chunk(landed);
         loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
-        parked = done;
+        P = cx.ballot(done);
+        E = cx.ballot((d_div & 1) == 0);
         fast_lim = (int)0x80000000;    // every lane recomputes its bound against the new horizon
         // ------------- the recurrence: every lane goes as far as its data allows -------------
         for (;;) {
             step(0);
             step(1);
-            if (cx.ballot(!parked) == 0ull)
+            if (~P == 0ull)
                 break;
         }
         // ---------------- land the prefetched chunk ----------------
@@ -395,11 +439,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 
     if (!live)
         return;
+    if (worst_imu >= (unsigned)MSK_ZERO_ROW)
+        status |= MSK_ST_INTERP_RANGE;
     p.mu[c] = d_mu;
     p.omega[c] = d_omega;
     p.div[c] = d_div;
-    p.dly1[c] = d_dly_conj_1;
-    p.dly2[c] = d_dly_conj_2;
+    p.dly1[c] = last_interp;
+    p.dly2[c] = last_interp;
     p.diff1[c] = d_dly_diff_1;
     const unsigned long long Rn = R + (unsigned long long)base;
     p.nread[c] = Rn;

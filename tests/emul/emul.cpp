@@ -60,6 +60,7 @@ struct EmuCtx {
             m |= b[wave_base() + l] << l;
         return m;
     }
+    bool inv_ballot(unsigned long long m) const { return (m >> (tid_ & 63)) & 1ull; }
     template <class T>
     T xchg(T v, int src_lane) const
     {
@@ -156,7 +157,13 @@ void emu_bittail(const BitTailParams* p, int max_out)
 
 void emu_msk(const MskParams* p)
 {
-    run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) { msk_body(cx, *p); });
+    const bool aux = p->err || p->mu_out;
+    run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) {
+        if (p->osps == 2)
+            aux ? msk_body<EmuCtx, true, true>(cx, *p) : msk_body<EmuCtx, false, true>(cx, *p);
+        else
+            aux ? msk_body<EmuCtx, true, false>(cx, *p) : msk_body<EmuCtx, false, false>(cx, *p);
+    });
 }
 
 // ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
@@ -294,7 +301,7 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
     emu_msk_fill(h, p);
     p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
     p.tags = tags; p.tag_count = tag_counts; p.tag_cap = tag_cap;
-    if (bits && !syms) {
+    if (!syms) {
         h->symscratch.resize((size_t)h->nchan * out_stride);
         syms = h->symscratch.data();
     }
