@@ -96,6 +96,9 @@ AISX_HD int msk_forecast(float d_sps, int noutput_items)
     return (int)ceil((noutput_items * d_sps * 2) + 3.0 * d_sps + 8u);
 }
 
+#ifdef MSK_EMU_STATS
+extern long msk_stats[8];
+#endif
 // AUX: the err / mu output ports are connected (:187-189).  OSPS2: osps == 2 (:186).
 template <class Ctx, bool AUX, bool OSPS2>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
@@ -180,7 +183,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int iidx = 0, oidx = 0;       // of the call in progress
     int ninp = 0, noutput = 0;
     unsigned long long Rc = R, rend = R;
-    bool done = !live;
+    // dead lanes (c >= nchan) run as exact mirrors of the last channel, duplicate symbol stores
+    // included (same address, same value), so that a ragged last wave stays in lock step
+    bool done = false;
     auto setup_round = [&]() {
         int ninput;
         if (p.stream_mode) {
@@ -243,7 +248,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #pragma unroll
             for (int k = 0; k < MSK_CHUNK; k++) {
                 r[k] = mk(0.f, 0.f);
-                if (live && s0 + k < n)
+                if (s0 + k < n)
                     r[k] = myin[s0 + k];
             }
         }
@@ -270,10 +275,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int sb = (base + iidx - pending + MSK_OFF) * 512;
     // iterations with iidx < fast_lim (and oidx < noutput) need none of the event code
     int fast_lim = (int)0x80000000;
+    int tag_trig = (int)0x80000000; // first iidx at which the front tag can fire (set by events())
     unsigned worst_imu = 0; // max over iterations of min(imu, MSK_ZERO_ROW)
     bool more = false;
     int loaded_s = 0;
     enum { EV_PARK = 0, EV_GO = 1, EV_OTHER_PARITY = 2 };
+    const int TRIG_FORCED = (int)0x80000001;
 
     // the reference's loop head for one lane, in its order (:138-164)
     auto events = [&](const int PAR) -> int {
@@ -289,10 +296,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (done)
             return EV_PARK;
         const int spos = sb >> 9;
-        if (more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s)) // wait for the next chunk
-            return EV_PARK;
+        // the next chunk has to land before this lane can go on (a tag is left for later too:
+        // the iteration it resets must follow at once)
+        const bool waiting = more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s);
         // a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
-        if ((nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps))) {
+        if (!waiting && (nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps))) {
             const float center = nt_val;
             if (center == center) { // not NaN (:144-147)
                 const int old = iidx;
@@ -310,34 +318,91 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             tpos++;
             skip_other_keys();
             nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
+            tag_trig = TRIG_FORCED;
             fast_lim = iidx + 1; // the reference runs this iteration whatever comes next: one
                                  // iteration, then back here (one tag per iteration, :140)
             return ((d_div & 1) == PAR) ? EV_GO : EV_OTHER_PARITY;
         }
-        // nothing pending: how far can this lane run before the next event?
-        int tag_trig = 0x7fffffff;
+        // nothing to do now: how far can this lane run before the next event?
+        tag_trig = 0x7fffffff;
         if (nt_rel != 0x7fffffff && iidx <= nt_rel) { // (a tag the loop stepped over stays in front for good)
             int i = nt_rel - jump_margin - 1;
             while (!((float)nt_rel < ((float)i + d_sps)))
                 i++;
             tag_trig = i;
         }
+        if (waiting)
+            return EV_PARK; // (the bound is re-armed when the chunk lands)
         const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - (spos - iidx) + 1) : 0x7fffffff;
         fast_lim = ninp < tag_trig ? ninp : tag_trig;
         fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
         return EV_GO;
     };
 
+    // one reference iteration (:166-201), d_div of parity PAR, for the lanes exec covers
+    auto body = [&](const int PAR) {
+        // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170); an imu outside
+        // [0, 128] (upstream throws std::runtime_error) reads the zero row and is reported
+        const unsigned imu = (unsigned)(int)rintf(d_mu * 128.0f);
+        const unsigned row = imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
+        worst_imu = worst_imu > row ? worst_imu : row;
+        const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
+        const cf* sp = (const cf*)((const char*)myring + (sb & ((MSK_RING - 1) * 512)));
+        cf in_interp = mk(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
+            const float tk = tp[7 - k];
+            in_interp.re += s.re * tk;
+            in_interp.im += s.im * tk;
+        }
+        const cf sq = cmul_exact(in_interp, in_interp);                    // :171
+        // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
+        // (:194-195, also after a tag reset :160), so its square is the previous sq
+        const cf dly_conj = cconj(prev_sq);
+        const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
+        float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
+        if (PAR) {                                                         // :179-184
+            err_out = branchless_clip(err_out, 3.0f);
+            d_omega += p.gain_omega * err_out;
+            d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+            d_mu += p.gain * err_out;
+        }
+        if (!PAR || OSPS2) { // :186-191
+            *(cf*)(osym0 + ob) = in_interp;
+            if (AUX) {
+                if (oerr0)
+                    *(float*)(oerr0 + (ob >> 1)) = err_out;
+                if (omu0)
+                    *(float*)(omu0 + (ob >> 1)) = d_mu;
+            }
+            ob += 8u;
+            oidx++;
+        }
+        d_div++;
+        last_interp = in_interp; // :194-196
+        prev_sq = sq;
+        d_dly_diff_1 = nlin_out;
+        d_mu += d_omega; // :199-201
+        const float fl = floorf(d_mu);
+        const int adv = (int)fl;
+        iidx += adv;
+        sb += adv * 512;
+        d_mu = d_mu - fl;
+    };
+
     u64 P = 0; // parked lanes: nothing more to do before the next chunk lands (or ever)
     u64 E = 0; // lanes whose next iteration has d_div even
+    // oidx < noutput was checked on the odd step before an even one and cannot have changed
+    // since (osps == 1: odd iterations emit nothing), so an even step only looks at iidx
+    auto ok_for = [&](const int PAR) -> bool {
+        return (PAR || OSPS2) ? ((iidx < fast_lim) && (oidx < noutput)) : (iidx < fast_lim);
+    };
 
-    // one reference iteration (:166-201) for the lanes whose d_div has parity PAR
+    // general step: the lanes whose d_div has parity PAR and that are not parked
     auto step = [&](const int PAR) {
         const u64 mine = ~P & (PAR ? ~E : E);
-        // oidx < noutput was checked on the odd step before an even one and cannot have
-        // changed since (osps == 1: odd iterations emit nothing)
-        const bool ok = (PAR || OSPS2) ? ((iidx < fast_lim) && (oidx < noutput)) : (iidx < fast_lim);
-        const u64 okM = cx.ballot(ok);
+        const u64 okM = cx.ballot(ok_for(PAR));
         u64 goM = mine & okM;
         const u64 evM = mine & ~okM;
         if (evM != 0ull) {
@@ -348,93 +413,79 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             P |= cx.ballot(code == EV_PARK);
             E = cx.ballot((d_div & 1) == 0);
         }
-        if (goM == 0ull)
-            return;
-        if (cx.inv_ballot(goM)) {
-            // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170); an imu outside
-            // [0, 128] (upstream throws std::runtime_error) reads the zero row and is reported
-            const unsigned imu = (unsigned)(int)rintf(d_mu * 128.0f);
-            const unsigned row = imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
-            worst_imu = worst_imu > row ? worst_imu : row;
-            const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-            const cf* sp = (const cf*)((const char*)myring + (sb & ((MSK_RING - 1) * 512)));
-            cf in_interp = mk(0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-#ifndef MSK_EXP_NOLDS
-                const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
-                const float tk = tp[7 - k];
-#else
-                const cf s = mk(d_mu + k, d_omega * k);
-                const float tk = d_mu * (7 - k);
-#endif
-                in_interp.re += s.re * tk;
-                in_interp.im += s.im * tk;
-            }
-            const cf sq = cmul_exact(in_interp, in_interp);                    // :171
-            // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
-            // (:194-195, also after a tag reset :160), so its square is the previous sq
-            const cf dly_conj = cconj(prev_sq);
-            const cf nlin_out = cmul_exact(sq, dly_conj);                      // :174
-            float err_out = (nlin_out - d_dly_diff_1).re;                      // :178
-            if (PAR) {                                                         // :179-184
-                err_out = branchless_clip(err_out, 3.0f);
-                d_omega += p.gain_omega * err_out;
-                d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
-                d_mu += p.gain * err_out;
-            }
-            if (!PAR || OSPS2) { // :186-191
-#ifndef MSK_EXP_NOSTORE
-                *(cf*)(osym0 + ob) = in_interp;
-#else
-                if (in_interp.re == 1.2345f) *(cf*)(osym0 + ob) = in_interp;
-#endif
-                if (AUX) {
-                    if (oerr0)
-                        *(float*)(oerr0 + (ob >> 1)) = err_out;
-                    if (omu0)
-                        *(float*)(omu0 + (ob >> 1)) = d_mu;
-                }
-                ob += 8u;
-                oidx++;
-            }
-            d_div++;
-            last_interp = in_interp; // :194-196
-            prev_sq = sq;
-            d_dly_diff_1 = nlin_out;
-            d_mu += d_omega; // :199-201
-            const float fl = floorf(d_mu);
-            const int adv = (int)fl;
-            iidx += adv;
-            sb += adv * 512;
-            d_mu = d_mu - fl;
+        if (goM != 0ull) {
+            if (cx.inv_ballot(goM))
+                body(PAR);
+            E ^= goM;
         }
-        E ^= goM;
     };
 
+    const u64 ALL = cx.ballot(true);
+    // every lane re-arms its bound against the horizon (same formula as in events()); a lane
+    // that owes the iteration after a tag reset keeps its one-iteration bound
+    auto rearm = [&]() {
+        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - ((sb >> 9) - iidx) + 1) : 0x7fffffff;
+        int f = ninp < tag_trig ? ninp : tag_trig;
+        f = f < chunk_lim ? f : chunk_lim;
+        fast_lim = (tag_trig == TRIG_FORCED) ? fast_lim : f;
+    };
+    more = landed < nchunks;
+    if (more)
+        issue_chunk(landed);
+    loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
+    P = cx.ballot(done);
+    E = cx.ballot((d_div & 1) == 0);
+    rearm();
+    // ------------- the recurrence: every lane goes as far as its data allows -------------
     for (;;) {
-        if (cx.ballot(!done) == 0ull)
-            break;
-        more = landed < nchunks;
-        if (more)
-            issue_chunk(landed);
-        loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
-        P = cx.ballot(done);
-        E = cx.ballot((d_div & 1) == 0);
-        fast_lim = (int)0x80000000;    // every lane recomputes its bound against the new horizon
-        // ------------- the recurrence: every lane goes as far as its data allows -------------
-        for (;;) {
-            step(0);
-            step(1);
-            if (~P == 0ull)
-                break;
+        // lock step: nobody parked, every lane about to run an even iteration, none at its
+        // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
+        // their own (so that the values the loop carries stay in place)
+        if (P == 0ull && E == ALL) {
+            for (;;) {
+                if (cx.ballot(ok_for(0)) != ALL)
+                    break;
+#ifdef MSK_EMU_STATS
+                if (l == 0) msk_stats[0]++;
+#endif
+                body(0);
+                if (cx.ballot(ok_for(1)) != ALL) {
+                    E = 0ull; // every lane is about to run an odd iteration
+                    break;
+                }
+                body(1);
+            }
         }
-        // ---------------- land the prefetched chunk ----------------
+        // (some lane needs attention.)  The next chunk lands as soon as no lane still reads
+        // the slots it overwrites: samples [64t - 256, 64t - 192) for chunk t (a lane may step
+        // back one item on a tag, :151-154) -- usually before any lane has to wait for it.
+        // Lanes that do wait satisfy the condition themselves, so when everybody waits the
+        // chunk does land.
         if (more) {
-            land_chunk(landed);
-            landed++;
+            const bool clear = done || ((sb >> 9) - MSK_OFF >= landed * MSK_CHUNK - (MSK_RING - MSK_CHUNK) + 2);
+            if (cx.ballot(clear) == ALL) {
+#ifdef MSK_EMU_STATS
+                if (l == 0) msk_stats[4]++;
+#endif
+                land_chunk(landed);
+                landed++;
+                more = landed < nchunks;
+                if (more)
+                    issue_chunk(landed);
+                loaded_s = landed * MSK_CHUNK;
+                P = cx.ballot(done); // whoever waited goes on
+                rearm();
+                if (P == 0ull && E == ALL)
+                    continue;
+            }
         }
-        cx.sync();
+#ifdef MSK_EMU_STATS
+        if (l == 0) { msk_stats[1]++; if (P != 0ull) msk_stats[2]++; if (E != ALL && E != 0ull) msk_stats[3]++; }
+#endif
+        step(0);
+        step(1);
+        if (P == ALL && (!more || cx.ballot(done) == ALL))
+            break; // all parked and nothing they could wait for: all done
     }
 
     if (!live)

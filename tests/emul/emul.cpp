@@ -14,6 +14,9 @@
 #include "../../gr-ais_amd/csrc/aisx_tables.h"
 #include "../../gr-ais_amd/csrc/k_corr.h"
 #include "../../gr-ais_amd/csrc/k_msk.h"
+#ifdef MSK_EMU_STATS
+namespace aisx { long msk_stats[8]; }
+#endif
 #include "../../gr-ais_amd/csrc/aisx_plan.h"
 #include "../../gr-ais_amd/csrc/k_pfb.h"
 #if __has_include("../../gr-ais_amd/csrc/k_agc.h")
@@ -149,6 +152,9 @@ void emu_corr_resolve(const ResolveParams* p, int nchan)
     run_grid(nchan, 1, 64, 0, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
 }
 
+#ifdef MSK_EMU_STATS
+long* emu_msk_stats() { return aisx::msk_stats; }
+#endif
 void emu_bittail(const BitTailParams* p, int max_out)
 {
     const int nseg = std::max(1, (max_out + BT_SEG - 1) / BT_SEG);
