@@ -17,6 +17,11 @@ struct DevCtx {
     __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
     // per-lane predicate from a wave-uniform mask (the mask goes straight into exec / vcc)
     __device__ __forceinline__ bool inv_ballot(unsigned long long m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    // scheduling fences: the value is materialised here, in program order with the other pins
+    // (keeps speculated arithmetic above the branch that may discard it)
+    __device__ __forceinline__ void pin(float& v) const { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ void pin(int& v) const { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ void pin_mask(unsigned long long& m) const { asm volatile("" : "+s"(m)); }
     __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) const
     {
         return __shfl(v, src, 64);

@@ -48,7 +48,7 @@ constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
 constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
-constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 15) / 16) * 16;
+constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 511) / 512) * 512; // whole slot rows: folds into ds offsets
 constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE;
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
@@ -111,8 +111,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
     char* lds = cx.lds();
-    cf* ring = (cf*)lds;                       // [MSK_SLOTS][64]
-    float* mm = (float*)(lds + MSK_LDS_RING);
+    float* mm = (float*)lds;                   // [130][MSK_TAPS_PITCH], at LDS offset 0: a row address is one multiply
+    cf* ring = (cf*)(lds + MSK_LDS_MMSE);      // [MSK_SLOTS][64]
     cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
 
     for (int i = l; i < 129 * 8; i += 64)
@@ -339,23 +339,31 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         return EV_GO;
     };
 
-    // one reference iteration (:166-201), d_div of parity PAR, for the lanes exec covers
-    auto body = [&](const int PAR) {
-        // mmse_fir_interpolator_cc::interpolate(&in[iidx], d_mu) (:170); an imu outside
-        // [0, 128] (upstream throws std::runtime_error) reads the zero row and is reported
-        const unsigned imu = (unsigned)(int)rintf(d_mu * 128.0f);
-        const unsigned row = imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
-        worst_imu = worst_imu > row ? worst_imu : row;
+    // mmse_fir_interpolator_cc::interpolate(&in[..], mu) (:170) at ring byte position sbpos; an
+    // imu outside [0, 128] (upstream throws std::runtime_error) reads the all-zero row
+    auto tap_row = [&](float mu) -> unsigned {
+        const unsigned imu = (unsigned)(int)rintf(mu * 128.0f);
+        return imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
+    };
+    auto fir = [&](unsigned row, int sbpos) -> cf {
         const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-        const cf* sp = (const cf*)((const char*)myring + (sb & ((MSK_RING - 1) * 512)));
-        cf in_interp = mk(0.f, 0.f);
+        const cf* sp = (const cf*)((const char*)myring + (sbpos & ((MSK_RING - 1) * 512)));
+        cf acc = mk(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
             const float tk = tp[7 - k];
-            in_interp.re += s.re * tk;
-            in_interp.im += s.im * tk;
+            acc.re += s.re * tk;
+            acc.im += s.im * tk;
         }
+        return acc;
+    };
+
+    // one reference iteration (:166-201), d_div of parity PAR, for the lanes exec covers
+    auto body = [&](const int PAR) {
+        const unsigned row = tap_row(d_mu);
+        worst_imu = worst_imu > row ? worst_imu : row; // (out-of-range mu is reported)
+        const cf in_interp = fir(row, sb);
         const cf sq = cmul_exact(in_interp, in_interp);                    // :171
         // :173 conj(d_dly_conj_2^2): d_dly_conj_2 is always the previous in_interp
         // (:194-195, also after a tag reset :160), so its square is the previous sq
@@ -421,6 +429,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
 
     const u64 ALL = cx.ballot(true);
+    // an even iteration advances iidx by floor(mu + omega) <= 1 + d_sps + |limit|: a lane that far
+    // below its bound can run the pair's odd iteration too without another look
+    const int pair_margin = (int)ceilf(1.0f + d_sps + fabsf(p.limit)) + 1;
     // every lane re-arms its bound against the horizon (same formula as in events()); a lane
     // that owes the iteration after a tag reset keeps its one-iteration bound
     auto rearm = [&]() {
@@ -442,18 +453,80 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
         // their own (so that the values the loop carries stay in place)
         if (P == 0ull && E == ALL) {
+            // A pair of iterations (even, odd) per trip, one check per pair, taken early and
+            // branched on late: the even iteration's arithmetic is done under it and dropped
+            // if some lane turns out to be within one iteration of its bound.
+            const int sb_entry = sb;
+            const long long tl = (long long)sb + ((long long)fast_lim - (long long)iidx - (long long)pair_margin) * 512ll;
+            const int fast_sb = tl > 0x7fffffffll ? 0x7fffffff : (tl < -0x80000000ll ? (int)0x80000000 : (int)tl);
+            const int orem = noutput - oidx; // outputs this general_work call may still emit
+            int kk = 1;                      // outputs the coming pair needs room for, less one
+            cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
+            float nl_prev = d_dly_diff_1.re;
             for (;;) {
-                if (cx.ballot(ok_for(0)) != ALL)
+                u64 okM = cx.ballot((sb < fast_sb) && (orem > kk));
+                cx.pin_mask(okM);
+                // ---- even iteration (:166-201 with d_div even): nothing is committed yet
+                cf accE = fir(tap_row(d_mu), sb);
+                const cf sE = cmul_exact(accE, accE);                          // :171
+                float nlE = sE.re * sqO.re + sE.im * sqO.im;                   // :173-174, real part
+                const float m1 = d_mu + d_omega;                               // :199-201
+                const float fl1 = floorf(m1);
+                float muO = m1 - fl1;
+                int sb1 = sb + (int)fl1 * 512;
+                cx.pin(accE.re); cx.pin(accE.im); cx.pin(nlE); cx.pin(muO); cx.pin(sb1);
+                if (okM != ALL)
                     break;
 #ifdef MSK_EMU_STATS
                 if (l == 0) msk_stats[0]++;
 #endif
-                body(0);
-                if (cx.ballot(ok_for(1)) != ALL) {
-                    E = 0ull; // every lane is about to run an odd iteration
-                    break;
+                *(cf*)(osym0 + ob) = accE;                                     // :186-191
+                if (AUX) {
+                    if (oerr0)
+                        *(float*)(oerr0 + (ob >> 1)) = nlE - nl_prev;
+                    if (omu0)
+                        *(float*)(omu0 + (ob >> 1)) = d_mu;
                 }
-                body(1);
+                ob += 8u;
+                // ---- odd iteration: loop filter (:179-184)
+                const cf acc1 = fir(tap_row(muO), sb1);
+                const cf s1 = cmul_exact(acc1, acc1);
+                const float nlO = s1.re * sE.re + s1.im * sE.im;
+                const float err = branchless_clip(nlO - nlE, 3.0f);
+                d_omega += p.gain_omega * err;
+                d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+                const float mu2 = muO + p.gain * err;
+                if (OSPS2) {
+                    *(cf*)(osym0 + ob) = acc1;
+                    if (AUX) {
+                        if (oerr0)
+                            *(float*)(oerr0 + (ob >> 1)) = err;
+                        if (omu0)
+                            *(float*)(omu0 + (ob >> 1)) = mu2;
+                    }
+                    ob += 8u;
+                }
+                const float m2 = mu2 + d_omega;
+                const float fl2 = floorf(m2);
+                d_mu = m2 - fl2;
+                sb = sb1 + (int)fl2 * 512;
+                sqE = sE;
+                sqO = s1;
+                accO = acc1;
+                nl_prev = nlO;
+                kk += OSPS2 ? 2 : 1;
+            }
+            const int npairs = OSPS2 ? (kk - 1) / 2 : (kk - 1);
+            if (npairs > 0) { // hand the state back to the per-lane variables
+                d_div += 2 * npairs;
+                oidx += OSPS2 ? 2 * npairs : npairs;
+                iidx += (sb - sb_entry) >> 9;
+                prev_sq = sqO;
+                last_interp = accO;
+                // :174 imaginary part of the last nlin_out: only ever read back as state
+                d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
+                if (!(d_mu >= 0.f && d_mu <= 1.f)) // (non-finite input: upstream would have thrown)
+                    status |= MSK_ST_INTERP_RANGE;
             }
         }
         // (some lane needs attention.)  The next chunk lands as soon as no lane still reads

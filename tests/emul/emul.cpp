@@ -63,6 +63,9 @@ struct EmuCtx {
             m |= b[wave_base() + l] << l;
         return m;
     }
+    void pin(float&) const {}
+    void pin(int&) const {}
+    void pin_mask(unsigned long long&) const {}
     bool inv_ballot(unsigned long long m) const { return (m >> (tid_ & 63)) & 1ull; }
     template <class T>
     T xchg(T v, int src_lane) const
