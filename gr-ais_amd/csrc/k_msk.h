@@ -45,6 +45,7 @@ constexpr int MSK_SLOTS = MSK_RING + 8; // + 8 mirror slots: an 8-tap read never
 constexpr int MSK_CHUNK = 64;   // samples per chunk
 constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_OFF) & 255
 constexpr int MSK_CARRY_MAX = 128;
+constexpr int MSK_PAIRS_MAX = 16; // pairs of iterations per check-free run (a power of two)
 constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
 constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
@@ -359,6 +360,26 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         return acc;
     };
 
+    // the same in two halves, so that the loads can be issued well before the sum
+    auto fir_load = [&](unsigned row, int sbpos, cf* sv, float* tv) {
+        const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
+        const cf* sp = (const cf*)((const char*)myring + (sbpos & ((MSK_RING - 1) * 512)));
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sv[k] = sp[k * 64];
+            tv[k] = tp[7 - k];
+        }
+    };
+    auto fir_sum = [&](const cf* sv, const float* tv) -> cf {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            acc.re += sv[k].re * tv[k];
+            acc.im += sv[k].im * tv[k];
+        }
+        return acc;
+    };
+
     // one reference iteration (:166-201), d_div of parity PAR, for the lanes exec covers
     auto body = [&](const int PAR) {
         const unsigned row = tap_row(d_mu);
@@ -429,9 +450,15 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
 
     const u64 ALL = cx.ballot(true);
-    // an even iteration advances iidx by floor(mu + omega) <= 1 + d_sps + |limit|: a lane that far
-    // below its bound can run the pair's odd iteration too without another look
-    const int pair_margin = (int)ceilf(1.0f + d_sps + fabsf(p.limit)) + 1;
+    // Bounds for the check-free pair loop.  iidx after any number of iterations is iidx0 +
+    // (mu0 + the sum of the omega and gain * err terms) - (the current mu), and mu stays in
+    // [0, 1]: the fraction carries over, so a run of c pairs moves iidx by less than
+    // 1 + c * pair_adv, with pair_adv = 2 wmax + 3 |gain| (wmax = d_sps + |limit| bounds omega,
+    // :183; |err| <= 3, :180).  The last iteration of the run starts below that.
+    const float wmax = d_sps + fabsf(p.limit);
+    const float pair_adv = 2.0f * wmax + 3.0f * fabsf(p.gain);
+    const float pair_adv_inv = 0.9999f / pair_adv;
+    const int pair_margin = 2;
     // every lane re-arms its bound against the horizon (same formula as in events()); a lane
     // that owes the iteration after a tag reset keeps its one-iteration bound
     auto rearm = [&]() {
@@ -453,71 +480,81 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
         // their own (so that the values the loop carries stay in place)
         if (P == 0ull && E == ALL) {
-            // A pair of iterations (even, odd) per trip, one check per pair, taken early and
-            // branched on late: the even iteration's arithmetic is done under it and dropped
-            // if some lane turns out to be within one iteration of its bound.
-            const int sb_entry = sb;
-            const long long tl = (long long)sb + ((long long)fast_lim - (long long)iidx - (long long)pair_margin) * 512ll;
-            const int fast_sb = tl > 0x7fffffffll ? 0x7fffffff : (tl < -0x80000000ll ? (int)0x80000000 : (int)tl);
-            const int orem = noutput - oidx; // outputs this general_work call may still emit
-            int kk = 1;                      // outputs the coming pair needs room for, less one
-            cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
-            float nl_prev = d_dly_diff_1.re;
-            for (;;) {
-                u64 okM = cx.ballot((sb < fast_sb) && (orem > kk));
-                cx.pin_mask(okM);
-                // ---- even iteration (:166-201 with d_div even): nothing is committed yet
-                cf accE = fir(tap_row(d_mu), sb);
-                const cf sE = cmul_exact(accE, accE);                          // :171
-                float nlE = sE.re * sqO.re + sE.im * sqO.im;                   // :173-174, real part
-                const float m1 = d_mu + d_omega;                               // :199-201
-                const float fl1 = floorf(m1);
-                float muO = m1 - fl1;
-                int sb1 = sb + (int)fl1 * 512;
-                cx.pin(accE.re); cx.pin(accE.im); cx.pin(nlE); cx.pin(muO); cx.pin(sb1);
-                if (okM != ALL)
-                    break;
+            // How many (even, odd) pairs can EVERY lane run without looking up?  A pair moves
+            // iidx by about pair_adv and emits one output (two if osps == 2), so a lane
+            // with `room` items below its bound is good for room / pair_adv pairs (see pair_adv); the wave
+            // takes what the slowest lane can do (at most MSK_PAIRS_MAX: one chunk's worth, the
+            // next chunk is then due).  The trips run with no test at all.
+            const long long room = (long long)fast_lim - (long long)iidx - (long long)pair_margin;
+            int can = room <= 0 ? 0 : (room >= 1000000 ? MSK_PAIRS_MAX : (int)((float)room * pair_adv_inv));
+            const int ocan = OSPS2 ? (noutput - oidx) / 2 : (noutput - oidx) - 1;
+            can = can < ocan ? can : ocan;
+            can = can < MSK_PAIRS_MAX ? can : MSK_PAIRS_MAX;
+            int npairs = MSK_PAIRS_MAX; // = min over the lanes of `can`
+            if (cx.ballot(can >= MSK_PAIRS_MAX) != ALL) {
+                npairs = 0;
+                for (int bit = MSK_PAIRS_MAX / 2; bit; bit >>= 1)
+                    if (cx.ballot(can >= npairs + bit) == ALL)
+                        npairs += bit;
+            }
+            if (npairs > 0) {
+                const int sb_entry = sb;
+                cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
+                float nl_prev = d_dly_diff_1.re;
+                for (int k = 0; k < npairs; k++) {
 #ifdef MSK_EMU_STATS
-                if (l == 0) msk_stats[0]++;
+                    if (l == 0) msk_stats[0]++;
 #endif
-                *(cf*)(osym0 + ob) = accE;                                     // :186-191
-                if (AUX) {
-                    if (oerr0)
-                        *(float*)(oerr0 + (ob >> 1)) = nlE - nl_prev;
-                    if (omu0)
-                        *(float*)(omu0 + (ob >> 1)) = d_mu;
-                }
-                ob += 8u;
-                // ---- odd iteration: loop filter (:179-184)
-                const cf acc1 = fir(tap_row(muO), sb1);
-                const cf s1 = cmul_exact(acc1, acc1);
-                const float nlO = s1.re * sE.re + s1.im * sE.im;
-                const float err = branchless_clip(nlO - nlE, 3.0f);
-                d_omega += p.gain_omega * err;
-                d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
-                const float mu2 = muO + p.gain * err;
-                if (OSPS2) {
-                    *(cf*)(osym0 + ob) = acc1;
+                    // ---- even iteration (:166-201 with d_div even).  It has no feedback into
+                    // mu (:179), so where the odd iteration will read is known now: both sets of
+                    // loads go out together, the odd one's latency hides behind the even sum.
+                    cf svE[8], svO[8];
+                    float tvE[8], tvO[8];
+                    fir_load(tap_row(d_mu), sb, svE, tvE);
+                    const float m1 = d_mu + d_omega;                               // :199-201
+                    const float fl1 = floorf(m1);
+                    const float muO = m1 - fl1;
+                    const int sb1 = sb + (int)fl1 * 512;
+                    fir_load(tap_row(muO), sb1, svO, tvO);
+                    const cf accE = fir_sum(svE, tvE);
+                    const cf sE = cmul_exact(accE, accE);                          // :171
+                    const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
+                    *(cf*)(osym0 + ob) = accE;                                     // :186-191
                     if (AUX) {
                         if (oerr0)
-                            *(float*)(oerr0 + (ob >> 1)) = err;
+                            *(float*)(oerr0 + (ob >> 1)) = nlE - nl_prev;
                         if (omu0)
-                            *(float*)(omu0 + (ob >> 1)) = mu2;
+                            *(float*)(omu0 + (ob >> 1)) = d_mu;
                     }
                     ob += 8u;
+                    // ---- odd iteration: loop filter (:179-184)
+                    const cf acc1 = fir_sum(svO, tvO);
+                    const cf s1 = cmul_exact(acc1, acc1);
+                    const float nlO = s1.re * sE.re + s1.im * sE.im;
+                    const float err = branchless_clip(nlO - nlE, 3.0f);
+                    d_omega += p.gain_omega * err;
+                    d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+                    const float mu2 = muO + p.gain * err;
+                    if (OSPS2) {
+                        *(cf*)(osym0 + ob) = acc1;
+                        if (AUX) {
+                            if (oerr0)
+                                *(float*)(oerr0 + (ob >> 1)) = err;
+                            if (omu0)
+                                *(float*)(omu0 + (ob >> 1)) = mu2;
+                        }
+                        ob += 8u;
+                    }
+                    const float m2 = mu2 + d_omega;
+                    const float fl2 = floorf(m2);
+                    d_mu = m2 - fl2;
+                    sb = sb1 + (int)fl2 * 512;
+                    sqE = sE;
+                    sqO = s1;
+                    accO = acc1;
+                    nl_prev = nlO;
                 }
-                const float m2 = mu2 + d_omega;
-                const float fl2 = floorf(m2);
-                d_mu = m2 - fl2;
-                sb = sb1 + (int)fl2 * 512;
-                sqE = sE;
-                sqO = s1;
-                accO = acc1;
-                nl_prev = nlO;
-                kk += OSPS2 ? 2 : 1;
-            }
-            const int npairs = OSPS2 ? (kk - 1) / 2 : (kk - 1);
-            if (npairs > 0) { // hand the state back to the per-lane variables
+                // hand the state back to the per-lane variables
                 d_div += 2 * npairs;
                 oidx += OSPS2 ? 2 * npairs : npairs;
                 iidx += (sb - sb_entry) >> 9;
