@@ -17,6 +17,8 @@ struct DevCtx {
     __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
     // per-lane predicate from a wave-uniform mask (the mask goes straight into exec / vcc)
     __device__ __forceinline__ bool inv_ballot(unsigned long long m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
+    __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // scheduling fences: the value is materialised here, in program order with the other pins
     // (keeps speculated arithmetic above the branch that may discard it)
     __device__ __forceinline__ void pin(float& v) const { asm volatile("" : "+v"(v)); }

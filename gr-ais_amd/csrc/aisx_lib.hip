@@ -745,6 +745,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
+    p.lds_tab_off = MSK_LDS_RING;
 }
 
 // the NRZI bit tail over the symbols the timing-recovery kernel just wrote

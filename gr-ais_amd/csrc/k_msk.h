@@ -46,11 +46,13 @@ constexpr int MSK_CHUNK = 64;   // samples per chunk
 constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_OFF) & 255
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_PAIRS_MAX = 16; // pairs of iterations per check-free run (a power of two)
-constexpr int MSK_TAPS_PITCH = 9; // floats per table row in LDS (8 taps + 1: spreads rows over banks)
+constexpr int MSK_TAPS_PITCH = 12; // floats per table row in LDS: 16-byte aligned rows, two 128-bit reads per FIR
 constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
 constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 511) / 512) * 512; // whole slot rows: folds into ds offsets
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE;
+constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
+constexpr int MSK_LDS_TAGQ = MSK_TAGQ * 64 * 8;
+constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_TAGQ;
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
@@ -78,6 +80,7 @@ struct MskParams {
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
+    int lds_tab_off;   // = MSK_LDS_RING
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -112,8 +115,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
     char* lds = cx.lds();
-    float* mm = (float*)lds;                   // [130][MSK_TAPS_PITCH], at LDS offset 0: a row address is one multiply
-    cf* ring = (cf*)(lds + MSK_LDS_MMSE);      // [MSK_SLOTS][64]
+    cf* ring = (cf*)lds;                       // [MSK_SLOTS][64] at LDS offset 0: a slot address is one and-or
+    // [130][MSK_TAPS_PITCH] behind the rings; the offset comes in as a kernel argument so that
+    // it sits in a scalar register and a row address is one multiply-add
+    float* mm = (float*)(lds + p.lds_tab_off);
     cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
 
     for (int i = l; i < 129 * 8; i += 64)
@@ -156,22 +161,63 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     if (nnt > p.tag_cap)
         nnt = p.tag_cap;
     const int ntot = nct + nnt;
-    int tpos = 0;
     auto tag_at = [&](int k) -> const tag_rec& { return (k < nct) ? ctg[k] : ntg[k - nct]; };
-    // the front of the tag queue is kept in registers
-    unsigned long long nt_off = ~0ull;
-    float nt_val = 0.f;
-    int nt_rel = 0x7fffffff; // offset of the front tag relative to this call's nitems_read, if in range
-    auto skip_other_keys = [&]() {
-        while (tpos < ntot && tag_at(tpos).key != KEY_TIME_EST)
-            tpos++;
-        if (tpos < ntot) {
-            nt_off = tag_at(tpos).offset;
-            nt_val = (float)tag_at(tpos).value;
-        } else {
-            nt_off = ~0ull;
+    // The time_est tags of that list are queued in LDS, as (offset - R, (float)value), at the
+    // start: the loop must not pay global-memory latency when a tag fires.  MSK_TAGQ entries
+    // per lane, entry k of lane l at tq[k * 64 + l]; a longer list is queued in instalments.
+    struct tq_ent { int rel; float val; };
+    tq_ent* const tq = (tq_ent*)(lds + MSK_LDS_RING + MSK_LDS_MMSE) + l;
+    const int TQ_NONE = 0x7fffffff;
+    int gq = 0;            // tags of the list looked at so far
+    int qhead = 0, qn = 0; // queue: entries [0, qn), front at qhead
+    auto tq_fill = [&]() {
+        // (keeps the entry popped last: its offset may still be >= nitems_read at the end)
+        if (qn > 0) {
+            tq[0] = tq[(qn - 1) * 64];
+            qn = 1;
+        }
+        qhead = qn;
+        while (qn < MSK_TAGQ && gq < ntot) {
+            tag_rec t[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                t[j] = tag_at(gq + j < ntot ? gq + j : ntot - 1); // four loads in flight
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (qn < MSK_TAGQ && gq < ntot) {
+                    gq++;
+                    if (t[j].key == KEY_TIME_EST && t[j].offset >= R) {
+                        const unsigned long long d = t[j].offset - R;
+                        tq_ent e;
+                        e.rel = d > 0x7ffffff0ull ? 0x7ffffff0 : (int)d;
+                        e.val = (float)t[j].value;
+                        tq[qn * 64] = e;
+                        qn++;
+                    }
+                }
+            }
         }
     };
+    // the front of the queue is kept in registers
+    int fr_rel = TQ_NONE; // offset of the front tag relative to R
+    float nt_val = 0.f;
+    int nt_rel = 0x7fffffff; // ... relative to this general_work call's nitems_read, if in its range
+    auto tq_front = [&]() {
+        if (qhead >= qn && gq < ntot)
+            tq_fill();
+        if (qhead < qn) {
+            const tq_ent e = tq[qhead * 64];
+            fr_rel = e.rel;
+            nt_val = e.val;
+        } else {
+            fr_rel = TQ_NONE;
+        }
+    };
+    auto tq_pop = [&]() {
+        qhead++;
+        tq_front();
+    };
+    tq_fill();
 
     // output rows are addressed as (wave-uniform base) + (32-bit byte offset of this lane)
     char* const osym0 = (char*)(p.syms + (long)cbase * p.out_stride);
@@ -183,7 +229,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int base = 0, ototal = 0;     // items consumed / produced by finished calls
     int iidx = 0, oidx = 0;       // of the call in progress
     int ninp = 0, noutput = 0;
-    unsigned long long Rc = R, rend = R;
     // dead lanes (c >= nchan) run as exact mirrors of the last channel, duplicate symbol stores
     // included (same address, same value), so that a ragged last wave stays in lock step
     bool done = false;
@@ -213,15 +258,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             return;
         }
         // get_tags_in_range(nitems_read, nitems_read + ninp, "time_est") (:125-130)
-        Rc = R + (unsigned long long)base;
-        rend = Rc + (unsigned long long)ninp;
-        tpos = 0;
-        skip_other_keys();
-        while (nt_off < Rc) {
-            tpos++;
-            skip_other_keys();
-        }
-        nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
+        // (from the start of the queue: a tag an earlier call consumed is delivered again if
+        // its offset is still >= nitems_read)
+        qhead = 0;
+        tq_front();
+        while (fr_rel < base)
+            tq_pop();
+        nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
     };
     if (!done)
         setup_round();
@@ -316,9 +359,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_omega = d_sps;
                 // (:160 d_dly_conj_2 = d_dly_conj_1: prev_sq already is the square of it)
             }
-            tpos++;
-            skip_other_keys();
-            nt_rel = (nt_off < rend) ? (int)(nt_off - Rc) : 0x7fffffff;
+            tq_pop();
+            nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
             tag_trig = TRIG_FORCED;
             fast_lim = iidx + 1; // the reference runs this iteration whatever comes next: one
                                  // iteration, then back here (one tag per iteration, :140)
@@ -348,7 +390,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
     auto fir = [&](unsigned row, int sbpos) -> cf {
         const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-        const cf* sp = (const cf*)((const char*)myring + (sbpos & ((MSK_RING - 1) * 512)));
+        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * 512)) | (unsigned)(l * 8)));
         cf acc = mk(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -362,8 +404,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 
     // the same in two halves, so that the loads can be issued well before the sum
     auto fir_load = [&](unsigned row, int sbpos, cf* sv, float* tv) {
-        const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-        const cf* sp = (const cf*)((const char*)myring + (sbpos & ((MSK_RING - 1) * 512)));
+        typedef float tap4 __attribute__((vector_size(16)));
+        const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4)); // 16-byte aligned rows
+        const tap4 tlo = tp4[0], thi = tp4[1];
+        const float tp[8] = { tlo[0], tlo[1], tlo[2], tlo[3], thi[0], thi[1], thi[2], thi[3] };
+        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * 512)) | (unsigned)(l * 8)));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             sv[k] = sp[k * 64];
@@ -450,6 +495,14 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
 
     const u64 ALL = cx.ballot(true);
+#ifdef MSK_PROF
+    long long pf_t0 = __builtin_readcyclecounter(), pf_lock = 0, pf_land = 0, pf_gen = 0, pf_n[4] = {0, 0, 0, 0};
+#define PF_BEGIN long long pf_a = __builtin_readcyclecounter();
+#define PF_END(acc) acc += __builtin_readcyclecounter() - pf_a;
+#else
+#define PF_BEGIN
+#define PF_END(acc)
+#endif
     // Bounds for the check-free pair loop.  iidx after any number of iterations is iidx0 +
     // (mu0 + the sum of the omega and gain * err terms) - (the current mu), and mu stays in
     // [0, 1]: the fraction carries over, so a run of c pairs moves iidx by less than
@@ -459,6 +512,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const float pair_adv = 2.0f * wmax + 3.0f * fabsf(p.gain);
     const float pair_adv_inv = 0.9999f / pair_adv;
     const int pair_margin = 2;
+    // mu + omega stays positive there (so that floor is a truncation and mu - floor(mu) the
+    // hardware's fract) as long as the loop filter cannot pull mu below -omega:
+    const bool lock_ok = 3.0f * fabsf(p.gain) + fabsf(p.limit) + 0.01f < d_sps;
     // every lane re-arms its bound against the horizon (same formula as in events()); a lane
     // that owes the iteration after a tag reset keeps its one-iteration bound
     auto rearm = [&]() {
@@ -479,6 +535,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // lock step: nobody parked, every lane about to run an even iteration, none at its
         // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
         // their own (so that the values the loop carries stay in place)
+        { PF_BEGIN
         if (P == 0ull && E == ALL) {
             // How many (even, odd) pairs can EVERY lane run without looking up?  A pair moves
             // iidx by about pair_adv and emits one output (two if osps == 2), so a lane
@@ -489,6 +546,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             int can = room <= 0 ? 0 : (room >= 1000000 ? MSK_PAIRS_MAX : (int)((float)room * pair_adv_inv));
             const int ocan = OSPS2 ? (noutput - oidx) / 2 : (noutput - oidx) - 1;
             can = can < ocan ? can : ocan;
+            if (!lock_ok || !(d_mu >= 0.f && d_mu <= 1.f)) // (the loop below takes mu in [0, 1] for granted)
+                can = 0;
             can = can < MSK_PAIRS_MAX ? can : MSK_PAIRS_MAX;
             int npairs = MSK_PAIRS_MAX; // = min over the lanes of `can`
             if (cx.ballot(can >= MSK_PAIRS_MAX) != ALL) {
@@ -510,12 +569,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     // loads go out together, the odd one's latency hides behind the even sum.
                     cf svE[8], svO[8];
                     float tvE[8], tvO[8];
-                    fir_load(tap_row(d_mu), sb, svE, tvE);
-                    const float m1 = d_mu + d_omega;                               // :199-201
-                    const float fl1 = floorf(m1);
-                    const float muO = m1 - fl1;
-                    const int sb1 = sb + (int)fl1 * 512;
-                    fir_load(tap_row(muO), sb1, svO, tvO);
+                    fir_load((unsigned)(int)rintf(d_mu * 128.0f), sb, svE, tvE);
+                    const float m1 = d_mu + d_omega;                               // :199-201, m1 > 0:
+                    const float muO = cx.fract(m1);                                // m1 - floorf(m1)
+                    const int sb1 = sb + (int)m1 * 512;                            // (int)floorf(m1)
+                    fir_load((unsigned)(int)rintf(muO * 128.0f), sb1, svO, tvO);
                     const cf accE = fir_sum(svE, tvE);
                     const cf sE = cmul_exact(accE, accE);                          // :171
                     const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
@@ -545,10 +603,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                         }
                         ob += 8u;
                     }
-                    const float m2 = mu2 + d_omega;
-                    const float fl2 = floorf(m2);
-                    d_mu = m2 - fl2;
-                    sb = sb1 + (int)fl2 * 512;
+                    const float m2 = mu2 + d_omega;                                // > 0 (lock_ok)
+                    d_mu = cx.fract(m2);
+                    sb = sb1 + (int)m2 * 512;
                     sqE = sE;
                     sqO = s1;
                     accO = acc1;
@@ -564,13 +621,18 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
                 if (!(d_mu >= 0.f && d_mu <= 1.f)) // (non-finite input: upstream would have thrown)
                     status |= MSK_ST_INTERP_RANGE;
+#ifdef MSK_PROF
+                pf_n[0] += npairs; pf_n[1]++;
+#endif
             }
         }
+        PF_END(pf_lock) }
         // (some lane needs attention.)  The next chunk lands as soon as no lane still reads
         // the slots it overwrites: samples [64t - 256, 64t - 192) for chunk t (a lane may step
         // back one item on a tag, :151-154) -- usually before any lane has to wait for it.
         // Lanes that do wait satisfy the condition themselves, so when everybody waits the
         // chunk does land.
+        { PF_BEGIN
         if (more) {
             const bool clear = done || ((sb >> 9) - MSK_OFF >= landed * MSK_CHUNK - (MSK_RING - MSK_CHUNK) + 2);
             if (cx.ballot(clear) == ALL) {
@@ -585,19 +647,33 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 loaded_s = landed * MSK_CHUNK;
                 P = cx.ballot(done); // whoever waited goes on
                 rearm();
-                if (P == 0ull && E == ALL)
+                if (P == 0ull && E == ALL) {
+                    PF_END(pf_land)
                     continue;
+                }
             }
         }
+        PF_END(pf_land) }
 #ifdef MSK_EMU_STATS
         if (l == 0) { msk_stats[1]++; if (P != 0ull) msk_stats[2]++; if (E != ALL && E != 0ull) msk_stats[3]++; }
 #endif
+        { PF_BEGIN
         step(0);
         step(1);
+#ifdef MSK_PROF
+        pf_n[2]++;
+#endif
+        PF_END(pf_gen) }
         if (P == ALL && (!more || cx.ballot(done) == ALL))
             break; // all parked and nothing they could wait for: all done
     }
 
+#ifdef MSK_PROF
+    if (c == 0) {
+        long long pf_t1 = __builtin_readcyclecounter();
+        printf("msk prof: total %lld lock %lld land %lld gen %lld | pairs %lld runs %lld genpasses %lld\n", pf_t1 - pf_t0, pf_lock, pf_land, pf_gen, pf_n[0], pf_n[1], pf_n[2]);
+    }
+#endif
     if (!live)
         return;
     if (worst_imu >= (unsigned)MSK_ZERO_ROW)
@@ -627,7 +703,23 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
         int w = 0;
-        for (int k = 0; k < ntot; k++) {
+        for (int k = 0; k < qn; k++) { // queued ones (value already narrowed to the float the loop uses)
+            const tq_ent e = tq[k * 64];
+            if (e.rel < base)
+                continue;
+            if (w < p.ctag_cap) {
+                tag_rec tg;
+                tg.offset = R + (unsigned long long)e.rel;
+                tg.value = (double)e.val;
+                tg.key = KEY_TIME_EST;
+                tg.chan = c;
+                cto[w] = tg;
+            } else {
+                status |= MSK_ST_TAGCARRY_OVERFLOW;
+            }
+            w++;
+        }
+        for (int k = gq; k < ntot; k++) { // and the ones never queued
             const tag_rec& tg = tag_at(k);
             if (tg.key != KEY_TIME_EST || tg.offset < Rn)
                 continue;

@@ -63,6 +63,7 @@ struct EmuCtx {
             m |= b[wave_base() + l] << l;
         return m;
     }
+    float fract(float x) const { return x - floorf(x); }
     void pin(float&) const {}
     void pin(int&) const {}
     void pin_mask(unsigned long long&) const {}
@@ -286,6 +287,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.ctag_n_in = h->ctag_n[h->cur].data(); p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
+    p.lds_tab_off = MSK_LDS_RING;
 }
 
 static void emu_msk_bittail(EmuMsk* h, const cf* syms, long sym_stride, const int* produced, unsigned char* bits,
