@@ -97,3 +97,56 @@ def test_emul_msk_general_work_gr_mode():
         assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
         read += a[4]
     assert read > 3000
+
+
+def test_emul_msk_many_tags_queue_refill():
+    # more time_est tags in one call than the kernel's LDS queue holds (MSK_TAGQ = 36), mixed
+    # with other keys: the queue is refilled in instalments and the result stays bit-exact
+    rng = np.random.default_rng(11)
+    nchan, lens = 2, [2600, 1400]
+    total = sum(lens)
+    xs = np.stack([_signal(90 + c, total, 4)[0] for c in range(nchan)])
+    e = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=nchan)
+    o = [orc.MskStream(4.0, 0.04, 0.01, 1) for _ in range(nchan)]
+    all_tags = []
+    for c in range(nchan):
+        t = _rand_tags(rng, total, 150, c)
+        t["key"][rng.choice(150, 30, replace=False)] = 3
+        all_tags.append(t)
+    k = 0
+    for L in lens:
+        cap = 160
+        tg = np.zeros((nchan, cap), dtype=emu.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        new = []
+        for c in range(nchan):
+            sel = all_tags[c][(all_tags[c]["offset"] >= k) & (all_tags[c]["offset"] < k + L)]
+            tg[c, : len(sel)] = sel
+            cnt[c] = len(sel)
+            new.append(sel)
+        assert (cnt > 40).any()
+        r = e.step(xs[:, k:k + L], tg, cnt, want_aux=True)
+        assert r["status"] == 0
+        for c in range(nchan):
+            ot = np.zeros(len(new[c]), dtype=orc.TAG_DTYPE)
+            ot["offset"], ot["value"], ot["key"] = new[c]["offset"], new[c]["value"], new[c]["key"]
+            out, o2, o3, cons = o[c].step(xs[c, k:k + L], ot, want_aux=True)
+            p = r["produced"][c]
+            assert p == len(out) and r["consumed"][c] == cons
+            assert np.array_equal(r["syms"][c, :p].view(np.uint32), out.view(np.uint32))
+            assert np.array_equal(r["mu"][c, :p].view(np.uint32), o3.view(np.uint32))
+        k += L
+
+
+def test_emul_msk_interp_range_is_reported():
+    # a time_est tag whose value is outside the interpolator's range: upstream throws
+    # std::runtime_error("mmse_fir_interpolator_cc: imu out of bounds."); here the status says so
+    x, _ = _signal(5, 800)
+    e = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=1)
+    tg = np.zeros((1, 4), dtype=emu.TAG_DTYPE)
+    tg[0, 0] = (300, 5.25, 2, 0)
+    r = e.step(x[None, :], tg, np.array([1], np.int32))
+    assert r["status"] & 1  # MSK_ST_INTERP_RANGE
+    e2 = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=1)
+    tg[0, 0] = (300, 0.25, 2, 0)
+    assert e2.step(x[None, :], tg, np.array([1], np.int32))["status"] == 0

@@ -233,6 +233,55 @@ def test_msk_general_work_host_gnuradio_path(ais):
     assert read > 10000
 
 
+def test_msk_interp_range_raises_like_upstream(ais):
+    # a time_est tag whose value puts mu outside the interpolator's table: upstream throws
+    # std::runtime_error("mmse_fir_interpolator_cc: imu out of bounds.")
+    from ais_amd import synth
+
+    x, _ = synth.make_channel(5, 4000, "P", 4, amp=1.0, cfo_max=50.0)
+    buf = np.concatenate([np.zeros(1, np.complex64), x])
+    tags = np.zeros(1, dtype=ais.TAG_DTYPE)
+    tags["offset"], tags["value"], tags["key"] = 300, 5.25, 2
+    blk = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1)
+    with pytest.raises(RuntimeError, match="imu out of bounds"):
+        blk.general_work_host(256, 1100, buf, 1, tags, 0)
+
+
+def test_msk_many_tags_per_call(ais):
+    # more time_est tags in one call than the kernel's LDS tag queue holds: refilled in instalments
+    from ais_amd import synth
+
+    rng = np.random.default_rng(12)
+    nchan, total = 66, 7000
+    xs = np.stack([synth.make_channel(300 + c, total, "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
+    blk = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=total)
+    cap = 128
+    tg = np.zeros((nchan, cap), dtype=ais.TAG_DTYPE)
+    cnt = np.full(nchan, 100, np.int32)
+    for c in range(nchan):
+        keys = np.full(100, 2, np.int32)
+        keys[rng.choice(100, 15, replace=False)] = 1
+        tg["key"][c, :100] = keys
+        tg["offset"][c, :100] = np.sort(rng.choice(np.arange(10, total - 10), size=100, replace=False))
+        tg["value"][c, :100] = rng.uniform(-0.9, 0.9, 100)
+        tg["chan"][c, :100] = c
+    import torch
+    # the tag hand-over API takes device pointers: reuse corr_est's layout
+    d_tags = torch.as_tensor(tg.view(np.uint8).reshape(nchan, -1).copy()).cuda()
+    d_cnt = torch.as_tensor(cnt).cuda()
+    r = blk.work(_dev(xs), tags_ptrs=(d_tags.data_ptr(), d_cnt.data_ptr(), cap), want_aux=True)
+    assert blk.last_status() == 0
+    prod = r["produced"].cpu().numpy()
+    syms = r["syms"].cpu().numpy()
+    for c in range(0, nchan, 5):
+        o = orc.MskStream(4.0, 0.04, 0.01, 1)
+        ot = np.zeros(100, dtype=orc.TAG_DTYPE)
+        ot["offset"], ot["value"], ot["key"] = tg["offset"][c, :100], tg["value"][c, :100], tg["key"][c, :100]
+        out, _, _, _ = o.step(xs[c], ot, want_aux=True)
+        assert prod[c] == len(out)
+        assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
+
+
 @pytest.mark.parametrize("family", ["P", "S"])
 def test_core_chain_corr_to_msk_bits_identical(ais, family):
     # corr_est -> msk -> NRZI bits with the tags handed over on the device, vs
