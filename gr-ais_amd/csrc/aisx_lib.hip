@@ -12,6 +12,7 @@
 #include "aisx_tables.h"
 #include "k_corr.h"
 #include "k_msk.h"
+#include <cstdlib>
 
 using namespace aisx;
 
@@ -89,6 +90,12 @@ __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
     __shared__ __attribute__((aligned(16))) char smem[260 * 4];
     DevCtx cx{ smem };
     bittail_body(cx, p);
+}
+
+__global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
+{
+    DevCtx cx{ nullptr };
+    tagprep_body(cx, p);
 }
 
 // launch the timing-recovery build for (err/mu ports connected, osps == 2)
@@ -517,6 +524,7 @@ extern "C" int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32*
 // ---------------------------------------------------------------------------
 struct aisx_msk {
     int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
+    int lpw = 64; // channels per wave of the timing-recovery kernel
     float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
     static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     float *d_mu = nullptr, *d_omega = nullptr;
@@ -533,6 +541,9 @@ struct aisx_msk {
     int* d_carry_len[2] = { nullptr, nullptr };
     tag_rec* d_ctag[2] = { nullptr, nullptr };
     int* d_ctag_n[2] = { nullptr, nullptr };
+    msk_ctag* d_ct = nullptr; // this call's time_est tags, compacted (k_msk_tagprep)
+    int* d_ct_n = nullptr;
+    int ct_cap = 0;
     int cur = 0;
     int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
     float *d_mmse = nullptr, *d_atan = nullptr;
@@ -599,6 +610,23 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->gain = gain;
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
     h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
+    {
+        // one wave per CU (the kernel takes a CU's whole LDS): as few channels per wave as
+        // still puts all channels on the chip at once
+        hipDeviceProp_t prop;
+        int dev = 0;
+        int ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+        h->lpw = 16;
+        while (h->lpw < 64 && (long)h->lpw * ncu < nchan)
+            h->lpw *= 2;
+        if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
+            const int v = atoi(e);
+            if (v == 16 || v == 32 || v == 64)
+                h->lpw = v;
+        }
+    }
 #define CK(e)               \
     do {                    \
         rc = (e);           \
@@ -636,6 +664,14 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         return AISX_ERR_HIP;
     }
     CK(msk_init_state(h));
+    // the compacted tag list for the usual hand-over capacity; grown on demand
+    h->ct_cap = aisx_msk::ctag_cap + 1024;
+    CK(dev_alloc(&h->d_ct, (size_t)nchan * (size_t)h->ct_cap));
+    CK(dev_alloc(&h->d_ct_n, nchan));
+    if (hipDeviceSynchronize() != hipSuccess) {
+        aisx_msk_destroy(h);
+        return AISX_ERR_HIP;
+    }
 #undef CK
     *out = h;
     return AISX_OK;
@@ -656,6 +692,8 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
         dev_free(h->d_tbit[k]);
     }
     dev_free(h->d_symscratch);
+    dev_free(h->d_ct);
+    dev_free(h->d_ct_n);
     dev_free(h->d_nread);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_carry[k]);
@@ -737,15 +775,52 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.carry_len_in = h->d_carry_len[h->cur];
     p.carry_len_out = h->d_carry_len[h->cur ^ 1];
     p.carry_cap = aisx_msk::carry_cap;
-    p.ctag_in = h->d_ctag[h->cur];
     p.ctag_out = h->d_ctag[h->cur ^ 1];
-    p.ctag_n_in = h->d_ctag_n[h->cur];
     p.ctag_n_out = h->d_ctag_n[h->cur ^ 1];
     p.ctag_cap = aisx_msk::ctag_cap;
+    p.ct = h->d_ct;
+    p.ct_n = h->d_ct_n;
+    p.ct_cap = h->ct_cap;
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
     p.lds_tab_off = MSK_LDS_RING;
+    p.lpw = h->lpw;
+}
+
+// compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows
+static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_tag_counts, int tag_cap, hipStream_t st)
+{
+    const int need = aisx_msk::ctag_cap + (d_tags ? tag_cap : 0);
+    int rc;
+    if (need > h->ct_cap || !h->d_ct) {
+        AISX_HIPCHK(hipStreamSynchronize(st));
+        dev_free(h->d_ct);
+        h->d_ct = nullptr;
+        h->ct_cap = 0;
+        if ((rc = dev_alloc(&h->d_ct, (size_t)h->nchan * (size_t)need)) != AISX_OK)
+            return rc;
+        h->ct_cap = need;
+        if (!h->d_ct_n && (rc = dev_alloc(&h->d_ct_n, h->nchan)) != AISX_OK)
+            return rc;
+        // dev_alloc's zero fill runs on the null stream: it must not trail into the kernels on `st`
+        AISX_HIPCHK(hipDeviceSynchronize());
+    }
+    TagPrepParams t;
+    t.nchan = h->nchan;
+    t.ctag_in = h->d_ctag[h->cur];
+    t.ctag_n_in = h->d_ctag_n[h->cur];
+    t.ctag_cap = aisx_msk::ctag_cap;
+    t.tags = d_tags;
+    t.tag_count = d_tag_counts;
+    t.tag_cap = tag_cap;
+    t.nread = h->d_nread;
+    t.ct = h->d_ct;
+    t.ct_n = h->d_ct_n;
+    t.ct_cap = h->ct_cap;
+    hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 255) / 256), dim3(256), 0, st, t);
+    AISX_HIPCHK(hipGetLastError());
+    return AISX_OK;
 }
 
 // the NRZI bit tail over the symbols the timing-recovery kernel just wrote
@@ -784,6 +859,9 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         set_err("aisx_msk_process_stream: out_stride < 1");
         return AISX_ERR_INVALID;
     }
+    int rc;
+    if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, (hipStream_t)stream)) != AISX_OK)
+        return rc;
     MskParams p;
     msk_fill_common(h, p);
     p.in = (const cf*)d_in;
@@ -792,10 +870,6 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.stream_mode = 1;
     p.gr_ninput = 0;
     p.gr_noutput = 0;
-    p.tags = (const tag_rec*)d_tags;
-    p.tag_count = d_tag_counts;
-    p.tag_cap = tag_cap;
-    int rc;
     cf* syms = (cf*)d_syms;
     if (out_stride >= (1L << 23)) {
         set_err("aisx_msk_process_stream: out_stride %ld too large (the 64 rows of a wave must lie within 4 GiB)", out_stride);
@@ -810,6 +884,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
             h->symscratch_len = 0;
             if ((rc = dev_alloc(&h->d_symscratch, need)) != AISX_OK)
                 return rc;
+            AISX_HIPCHK(hipDeviceSynchronize()); // (the zero fill runs on the null stream)
             h->symscratch_len = need;
         }
         syms = h->d_symscratch;
@@ -820,7 +895,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : h->d_produced;
-    if ((rc = msk_launch(p, (h->nchan + 63) / 64, (hipStream_t)stream)) != AISX_OK)
+    if ((rc = msk_launch(p, (h->nchan + h->lpw - 1) / h->lpw, (hipStream_t)stream)) != AISX_OK)
         return rc;
     h->cur ^= 1;
     if (d_bits) {
@@ -899,6 +974,8 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     const int zero = 0;
     AISX_HIPCHK(hipMemcpy(h->d_carry_len[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
     AISX_HIPCHK(hipMemcpy(h->d_ctag_n[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
+    if ((rc = msk_launch_tagprep(h, h->d_st_tags, h->d_st_tagn, ntags + 1, 0)) != AISX_OK)
+        return rc;
     MskParams p;
     msk_fill_common(h, p);
     p.in = h->d_st_in;
@@ -907,9 +984,6 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     p.stream_mode = 0;
     p.gr_ninput = ninput_items;
     p.gr_noutput = noutput_items;
-    p.tags = h->d_st_tags;
-    p.tag_count = h->d_st_tagn;
-    p.tag_cap = ntags + 1;
     p.syms = h->d_st_sym;
     p.err = h->d_st_err;
     p.mu_out = h->d_st_mu;

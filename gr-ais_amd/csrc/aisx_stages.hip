@@ -173,7 +173,7 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
     m.nvec = nvec;
     m.binsize = h->binsize;
     m.sensitivity = h->sensitivity;
-    hipLaunchKernelGGL(k_fs_mix, dim3((h->nchan + 63) / 64), dim3(FSM_T), FSM_LDS_BYTES, st, m);
+    hipLaunchKernelGGL(k_fs_mix, dim3((h->nchan + FSM_CPW - 1) / FSM_CPW), dim3(FSM_T), FSM_LDS_BYTES, st, m);
     AISX_HIPCHK(hipGetLastError());
     h->npend = h->npend + n - nvec * h->fftlen;
     h->cur ^= 1;

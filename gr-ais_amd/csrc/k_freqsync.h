@@ -9,7 +9,7 @@
 //                 |X[j]| + |X[j+offset]|) with a wave arg-max.  Emits maxpos, or
 //                 -1 when no bin pair had positive energy (the reference then
 //                 re-uses the previous vector's maxpos, :68 vs :74).
-//   fs_mix_body : per 64 channels: resolves the stale-maxpos rule in sequence,
+//   fs_mix_body : per 16 channels: resolves the stale-maxpos rule in sequence,
 //                 f = (float(maxpos) - fftlen/2) * binsize / 2 (:84), then
 //                 repeat -> frequency_modulator_fc -> multiply_cc
 //                 (gmsk_sync.py:26-28,33).  The NCO phase is GNU Radio's float
@@ -205,12 +205,14 @@ AISX_HD float nco_wrap(float ph)
 }
 
 // ---------------------------------------------------------------------------
-constexpr int FSM_T = 512;             // wave 0 walks the NCO phases, waves 1..7 mix
+constexpr int FSM_T = 256;             // wave 0 walks the NCO phases, waves 1..3 mix
+constexpr int FSM_CPW = 16;            // channels per workgroup (256 workgroups at 4096 channels: one per CU)
 constexpr int FSM_MIXW = FSM_T / 64 - 1;
-constexpr int FSM_CH = 64;             // samples per chunk
+constexpr int FSM_CH = 128;            // samples per chunk
 constexpr int FSM_PITCH = FSM_CH + 1;  // floats per channel row in LDS
-constexpr int FSM_ROWS = (64 + FSM_MIXW - 1) / FSM_MIXW; // channel rows per mixing wave
-constexpr int FSM_LDS_BYTES = 2 * 64 * FSM_PITCH * 4;    // two phase buffers
+constexpr int FSM_UNITS = FSM_CPW * (FSM_CH / 64);            // (channel, 64-sample half) units per chunk
+constexpr int FSM_UPW = (FSM_UNITS + FSM_MIXW - 1) / FSM_MIXW; // units per mixing wave
+constexpr int FSM_LDS_BYTES = 2 * FSM_CPW * FSM_PITCH * 4;    // two phase buffers
 
 struct FsMixParams {
     int nchan;
@@ -230,22 +232,22 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
 {
     const int t = cx.tid();
     const int wave = t >> 6, l = t & 63;
-    const int cbase = cx.bx() * 64;
-    float* PH = (float*)cx.lds(); // [2][64][FSM_PITCH]
-    // wave 0: lane = channel cbase + l
+    const int cbase = cx.bx() * FSM_CPW;
+    float* PH = (float*)cx.lds(); // [2][FSM_CPW][FSM_PITCH]
+    // wave 0: lane l < FSM_CPW walks channel cbase + l
     const int myc = cbase + l;
-    const bool mylive = (wave == 0) && (myc < p.nchan);
+    const bool mylive = (wave == 0) && (l < FSM_CPW) && (myc < p.nchan);
     float ph = mylive ? p.phase[myc] : 0.f;
     unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
     float d = 0.f;
     const int total = p.nvec * FS_F;
     const int nchunks = total / FSM_CH;
-    // software pipeline: wave 0 produces the phases of chunk k while waves 1..7 mix chunk k-1
+    // software pipeline: wave 0 produces the phases of chunk k while waves 1..3 mix chunk k-1
     for (int k = 0; k <= nchunks; k++) {
         if (wave == 0) {
             if (mylive && k < nchunks) {
                 const int k0 = k * FSM_CH;
-                float* dst = PH + (k & 1) * 64 * FSM_PITCH + l * FSM_PITCH;
+                float* dst = PH + (k & 1) * FSM_CPW * FSM_PITCH + l * FSM_PITCH;
                 if ((k0 & (FS_F - 1)) == 0) { // a new vector starts
                     const int v = k0 / FS_F;
                     const int mp = p.maxpos[(long)myc * p.maxpos_stride + v];
@@ -267,25 +269,26 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
             }
         } else if (k > 0) {
             const long k0 = (long)(k - 1) * FSM_CH;
-            const float* src = PH + ((k - 1) & 1) * 64 * FSM_PITCH;
-            const long idx = k0 + l;
-            cf s[FSM_ROWS];
+            const float* src = PH + ((k - 1) & 1) * FSM_CPW * FSM_PITCH;
+            cf s[FSM_UPW];
 #pragma unroll
-            for (int q = 0; q < FSM_ROWS; q++) {
-                const int r = (wave - 1) + FSM_MIXW * q;
-                const int c = cbase + r;
+            for (int q = 0; q < FSM_UPW; q++) {
+                const int u = (wave - 1) + FSM_MIXW * q;
+                const int r = u % FSM_CPW, c = cbase + r;
+                const long idx = k0 + (u / FSM_CPW) * 64 + l;
                 s[q] = mk(0.f, 0.f);
-                if (r < 64 && c < p.nchan)
+                if (u < FSM_UNITS && c < p.nchan)
                     s[q] = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
             }
 #pragma unroll
-            for (int q = 0; q < FSM_ROWS; q++) {
-                const int r = (wave - 1) + FSM_MIXW * q;
-                const int c = cbase + r;
-                if (r < 64 && c < p.nchan) {
+            for (int q = 0; q < FSM_UPW; q++) {
+                const int u = (wave - 1) + FSM_MIXW * q;
+                const int r = u % FSM_CPW, c = cbase + r;
+                const int h = u / FSM_CPW;
+                if (u < FSM_UNITS && c < p.nchan) {
                     float sn, cs;
-                    det_sincos(src[r * FSM_PITCH + l], &sn, &cs);
-                    p.out[(long)c * p.out_stride + idx] = cmul_exact(s[q], mk(cs, sn));
+                    det_sincos(src[r * FSM_PITCH + h * 64 + l], &sn, &cs);
+                    p.out[(long)c * p.out_stride + k0 + h * 64 + l] = cmul_exact(s[q], mk(cs, sn));
                 }
             }
         }
@@ -295,7 +298,7 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
         p.phase[myc] = ph;
     // keep the trailing partial vector (stream_to_vector's pending items)
     const int rem = p.npend + p.n - total;
-    for (int r = wave; r < 64; r += FSM_T / 64) {
+    for (int r = wave; r < FSM_CPW; r += FSM_T / 64) {
         const int c = cbase + r;
         if (c < p.nchan)
             for (int i = l; i < rem; i += 64) {

@@ -56,6 +56,10 @@ constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_TAGQ;
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
+// a time_est tag as the timing-recovery kernel wants it: offset relative to the channel's
+// nitems_read at the start of the call, value narrowed to the float the loop uses
+struct msk_ctag { int rel; float val; };
+
 // two consecutive samples of a row; rows are only 8-byte aligned
 struct __attribute__((packed, aligned(8))) cf_pair { cf a, b; };
 
@@ -73,14 +77,16 @@ struct MskParams {
     const cf* carry_in; cf* carry_out; const int* carry_len_in; int* carry_len_out; int carry_cap;
     // GNU Radio mode (stream_mode == 0): explicit ninput/noutput, nothing carried but the pre-item
     int stream_mode; int gr_ninput; int gr_noutput;
-    // tags: new ones from this call + carried ones
-    const tag_rec* tags; const int* tag_count; int tag_cap;
-    const tag_rec* ctag_in; tag_rec* ctag_out; const int* ctag_n_in; int* ctag_n_out; int ctag_cap;
+    // tags: the time_est tags of (carried ones + this call's), compacted by tagprep_body
+    const msk_ctag* ct; const int* ct_n; int ct_cap;
+    // tags still pending at the end of the call, for the next one
+    tag_rec* ctag_out; int* ctag_n_out; int ctag_cap;
     // outputs (syms is mandatory; rows of one wave must lie within 4 GiB: out_stride < 2^23)
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
     int lds_tab_off;   // = MSK_LDS_RING
+    int lpw;           // channels (active lanes) per wave: 16, 32 or 64
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -109,7 +115,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
     typedef unsigned long long u64;
     const int l = cx.tid();
-    const int cbase = cx.bx() * 64;
+    // p.lpw lanes of the wave carry channels (16, 32 or 64).  Few channels per wave when
+    // the chip has CUs to spare: events of different lanes stall each other less, LDS
+    // returns fewer bytes per instruction, a chunk load touches fewer lines.
+    if (l >= p.lpw)
+        return;
+    const int cbase = cx.bx() * p.lpw;
     const int c = cbase + l;
     const bool live = c < p.nchan;
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
@@ -121,7 +132,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     float* mm = (float*)(lds + p.lds_tab_off);
     cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
 
-    for (int i = l; i < 129 * 8; i += 64)
+    for (int i = l; i < 129 * 8; i += p.lpw)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
     if (l < MSK_TAPS_PITCH)
         mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f;
@@ -153,19 +164,15 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             myring[(MSK_RING + slot) * 64] = cin[q + 1];
     }
 
-    // logical tag list = carried tags, then this call's tags
-    const tag_rec* ctg = p.ctag_in + (long)cc * p.ctag_cap;
-    const int nct = p.ctag_n_in[cc];
-    const tag_rec* ntg = p.tags ? p.tags + (long)cc * p.tag_cap : nullptr;
-    int nnt = p.tags ? p.tag_count[cc] : 0;
-    if (nnt > p.tag_cap)
-        nnt = p.tag_cap;
-    const int ntot = nct + nnt;
-    auto tag_at = [&](int k) -> const tag_rec& { return (k < nct) ? ctg[k] : ntg[k - nct]; };
-    // The time_est tags of that list are queued in LDS, as (offset - R, (float)value), at the
-    // start: the loop must not pay global-memory latency when a tag fires.  MSK_TAGQ entries
-    // per lane, entry k of lane l at tq[k * 64 + l]; a longer list is queued in instalments.
-    struct tq_ent { int rel; float val; };
+    // the time_est tags visible to this call (carried ones first), already compacted
+    const msk_ctag* ctl = p.ct + (long)cc * p.ct_cap;
+    int ntot = p.ct_n[cc];
+    if (ntot > p.ct_cap)
+        ntot = p.ct_cap;
+    // They are queued in LDS: the loop must not pay global-memory latency when a tag fires.
+    // MSK_TAGQ entries per lane, entry k of lane l at tq[k * 64 + l]; a longer list is queued
+    // in instalments.
+    typedef msk_ctag tq_ent;
     tq_ent* const tq = (tq_ent*)(lds + MSK_LDS_RING + MSK_LDS_MMSE) + l;
     const int TQ_NONE = 0x7fffffff;
     int gq = 0;            // tags of the list looked at so far
@@ -178,22 +185,16 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         qhead = qn;
         while (qn < MSK_TAGQ && gq < ntot) {
-            tag_rec t[4];
+            tq_ent t[4];
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                t[j] = tag_at(gq + j < ntot ? gq + j : ntot - 1); // four loads in flight
+                t[j] = ctl[gq + j < ntot ? gq + j : ntot - 1]; // four loads in flight
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (qn < MSK_TAGQ && gq < ntot) {
                     gq++;
-                    if (t[j].key == KEY_TIME_EST && t[j].offset >= R) {
-                        const unsigned long long d = t[j].offset - R;
-                        tq_ent e;
-                        e.rel = d > 0x7ffffff0ull ? 0x7ffffff0 : (int)d;
-                        e.val = (float)t[j].value;
-                        tq[qn * 64] = e;
-                        qn++;
-                    }
+                    tq[qn * 64] = t[j];
+                    qn++;
                 }
             }
         }
@@ -720,13 +721,19 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             w++;
         }
         for (int k = gq; k < ntot; k++) { // and the ones never queued
-            const tag_rec& tg = tag_at(k);
-            if (tg.key != KEY_TIME_EST || tg.offset < Rn)
+            const tq_ent e = ctl[k];
+            if (e.rel < base)
                 continue;
-            if (w < p.ctag_cap)
+            if (w < p.ctag_cap) {
+                tag_rec tg;
+                tg.offset = R + (unsigned long long)e.rel;
+                tg.value = (double)e.val;
+                tg.key = KEY_TIME_EST;
+                tg.chan = c;
                 cto[w] = tg;
-            else
+            } else {
                 status |= MSK_ST_TAGCARRY_OVERFLOW;
+            }
             w++;
         }
         p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
@@ -736,6 +743,57 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         p.ctag_n_out[c] = 0;
     }
     p.status[c] = status;
+}
+
+// Tag prepass: one lane per channel merges the tags carried over from the previous call with
+// this call's, keeps the time_est ones at or after nitems_read (:125-130 asks for that key
+// only) and writes them as msk_ctag.  Runs before msk_body on the same stream.
+struct TagPrepParams {
+    int nchan;
+    const tag_rec* ctag_in; const int* ctag_n_in; int ctag_cap; // carried (already time_est only)
+    const tag_rec* tags; const int* tag_count; int tag_cap;     // this call's, any keys (may be null)
+    const unsigned long long* nread;
+    msk_ctag* ct; int* ct_n; int ct_cap;
+};
+
+template <class Ctx>
+AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
+{
+    const int c = cx.bx() * cx.nthreads() + cx.tid();
+    if (c >= p.nchan)
+        return;
+    const unsigned long long R = p.nread[c];
+    msk_ctag* out = p.ct + (long)c * p.ct_cap;
+    int w = 0;
+    auto scan = [&](const tag_rec* list, int n) {
+        for (int k0 = 0; k0 < n; k0 += 8) {
+            tag_rec t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                t[j] = list[k0 + j < n ? k0 + j : n - 1]; // eight loads in flight
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (k0 + j < n && t[j].key == KEY_TIME_EST && t[j].offset >= R && w < p.ct_cap) {
+                    const unsigned long long d = t[j].offset - R;
+                    msk_ctag e;
+                    e.rel = d > 0x7ffffff0ull ? 0x7ffffff0 : (int)d;
+                    e.val = (float)t[j].value;
+                    out[w++] = e;
+                }
+            }
+        }
+    };
+    int nc = p.ctag_n_in[c];
+    if (nc > p.ctag_cap)
+        nc = p.ctag_cap;
+    scan(p.ctag_in + (long)c * p.ctag_cap, nc);
+    if (p.tags) {
+        int nn = p.tag_count[c];
+        if (nn > p.tag_cap)
+            nn = p.tag_cap;
+        scan(p.tags + (long)c * p.tag_cap, nn);
+    }
+    p.ct_n[c] = w;
 }
 
 // Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)

@@ -168,7 +168,7 @@ void emu_bittail(const BitTailParams* p, int max_out)
 void emu_msk(const MskParams* p)
 {
     const bool aux = p->err || p->mu_out;
-    run_grid((p->nchan + 63) / 64, 1, MSK_T, MSK_LDS_BYTES, [&](EmuCtx& cx) {
+    run_grid((p->nchan + p->lpw - 1) / p->lpw, 1, p->lpw, MSK_LDS_BYTES, [&](EmuCtx& cx) {
         if (p->osps == 2)
             aux ? msk_body<EmuCtx, true, true>(cx, *p) : msk_body<EmuCtx, false, true>(cx, *p);
         else
@@ -243,6 +243,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
 // ---- msk_timing_recovery_cc handle mirroring aisx_msk_* ----
 struct EmuMsk {
     int nchan, osps;
+    int lpw = 64;
     float d_sps, gain, gain_omega, limit;
     static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     std::vector<float> mu, omega;
@@ -252,6 +253,9 @@ struct EmuMsk {
     int tcur = 0;
     std::vector<unsigned long long> nread;
     std::vector<tag_rec> ctag[2];
+    std::vector<msk_ctag> ct;
+    std::vector<int> ct_n;
+    int ct_cap = 0;
     int cur = 0;
 };
 
@@ -274,6 +278,7 @@ void* emu_msk_create(float sps, float gain, float limit, int osps, int nchan)
     return h;
 }
 void emu_msk_destroy(void* hv) { delete (EmuMsk*)hv; }
+void emu_msk_set_lpw(void* hv, int lpw) { ((EmuMsk*)hv)->lpw = lpw; }
 
 static void emu_msk_fill(EmuMsk* h, MskParams& p)
 {
@@ -283,11 +288,27 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.nread = h->nread.data();
     p.carry_in = h->carry[h->cur].data(); p.carry_out = h->carry[h->cur ^ 1].data();
     p.carry_len_in = h->carry_len[h->cur].data(); p.carry_len_out = h->carry_len[h->cur ^ 1].data(); p.carry_cap = EmuMsk::carry_cap;
-    p.ctag_in = h->ctag[h->cur].data(); p.ctag_out = h->ctag[h->cur ^ 1].data();
-    p.ctag_n_in = h->ctag_n[h->cur].data(); p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
+    p.ctag_out = h->ctag[h->cur ^ 1].data();
+    p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
+    p.ct = h->ct.data(); p.ct_n = h->ct_n.data(); p.ct_cap = h->ct_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
     p.lds_tab_off = MSK_LDS_RING;
+    p.lpw = h->lpw;
+}
+
+static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap)
+{
+    h->ct_cap = EmuMsk::ctag_cap + (tags ? tag_cap : 0);
+    h->ct.assign((size_t)h->nchan * h->ct_cap, msk_ctag{ 0, 0.f });
+    h->ct_n.assign(h->nchan, 0);
+    TagPrepParams t;
+    t.nchan = h->nchan;
+    t.ctag_in = h->ctag[h->cur].data(); t.ctag_n_in = h->ctag_n[h->cur].data(); t.ctag_cap = EmuMsk::ctag_cap;
+    t.tags = tags; t.tag_count = tag_counts; t.tag_cap = tag_cap;
+    t.nread = h->nread.data();
+    t.ct = h->ct.data(); t.ct_n = h->ct_n.data(); t.ct_cap = h->ct_cap;
+    run_grid((h->nchan + 63) / 64, 1, 64, 64, [&](EmuCtx& cx) { tagprep_body(cx, t); });
 }
 
 static void emu_msk_bittail(EmuMsk* h, const cf* syms, long sym_stride, const int* produced, unsigned char* bits,
@@ -308,10 +329,10 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
                            int* produced, int* consumed_out)
 {
     EmuMsk* h = (EmuMsk*)hv;
+    emu_msk_tagprep(h, tags, tag_counts, tag_cap);
     MskParams p;
     emu_msk_fill(h, p);
     p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
-    p.tags = tags; p.tag_count = tag_counts; p.tag_cap = tag_cap;
     if (!syms) {
         h->symscratch.resize((size_t)h->nchan * out_stride);
         syms = h->symscratch.data();
@@ -336,13 +357,13 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
                          unsigned long long nitems_read, int* consumed, int* produced)
 {
     EmuMsk* h = (EmuMsk*)hv;
-    MskParams p;
-    emu_msk_fill(h, p);
     h->nread[0] = nitems_read;
     h->carry_len[h->cur][0] = 0;
     h->ctag_n[h->cur][0] = 0;
+    emu_msk_tagprep(h, tags, &ntags, ntags + 1);
+    MskParams p;
+    emu_msk_fill(h, p);
     p.in = in; p.in_stride = ninput + 1; p.n = ninput; p.stream_mode = 0; p.gr_ninput = ninput; p.gr_noutput = noutput;
-    p.tags = tags; p.tag_count = &ntags; p.tag_cap = ntags + 1;
     p.syms = out; p.err = err; p.mu_out = mu; p.out_stride = noutput; p.out_cap = noutput;
     p.produced = h->produced.data();
     emu_msk(&p);
@@ -466,7 +487,7 @@ int emu_fs_process(void* hv, const cf* in, long in_stride, int n, cf* out, long 
     m.nchan = h->nchan; m.in = in; m.in_stride = in_stride; m.pend_in = h->pend[h->cur].data(); m.pend_out = h->pend[h->cur ^ 1].data();
     m.npend = h->npend; m.n = n; m.out = out; m.out_stride = out_stride; m.maxpos = h->maxpos.data(); m.maxpos_stride = h->max_vec;
     m.fhat = fhat; m.fhat_stride = fhat_stride; m.phase = h->phase.data(); m.nvec = nvec; m.binsize = h->binsize; m.sensitivity = h->sens;
-    run_grid((h->nchan + 63) / 64, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, m); });
+    run_grid((h->nchan + FSM_CPW - 1) / FSM_CPW, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, m); });
     h->npend = h->npend + n - nvec * FS_F;
     h->cur ^= 1;
     return nvec * FS_F;

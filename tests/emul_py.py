@@ -38,6 +38,7 @@ def lib():
         L.emu_msk_create.restype = vp
         L.emu_msk_create.argtypes = [f32, f32, f32, i32, i32]
         L.emu_msk_destroy.argtypes = [vp]
+        L.emu_msk_set_lpw.argtypes = [vp, i32]
         L.emu_msk_process_stream.restype = i32
         L.emu_msk_process_stream.argtypes = [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp]
         L.emu_msk_general_work.restype = i32
@@ -98,9 +99,10 @@ class CorrEst:
 
 
 class MskStream:
-    def __init__(self, sps, gain, limit, osps=1, nchan=1):
+    def __init__(self, sps, gain, limit, osps=1, nchan=1, lpw=64):
         self.h = lib().emu_msk_create(sps, gain, limit, osps, nchan)
         self.nchan = nchan
+        lib().emu_msk_set_lpw(self.h, lpw)  # channels per wave: 16, 32 or 64
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -30,7 +30,7 @@ def test_emul_msk_stream_bit_exact(sps, osps):
     nchan, lens = (67 if (sps, osps) == (4.0, 1) else 3), [1500, 37, 900, 1, 700]
     total = sum(lens)
     xs = np.stack([_signal(50 + c, total, 4)[0] for c in range(nchan)])
-    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan)
+    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan, lpw=(16 if sps == 5.0 else 64))
     o = [orc.MskStream(sps, 0.04, 0.01, osps) for _ in range(nchan)]
     bt = [orc.BitTail() for _ in range(nchan)]
     # tags: a mix of plausible time_est tags, NaN, other keys, clustered offsets
@@ -103,10 +103,10 @@ def test_emul_msk_many_tags_queue_refill():
     # more time_est tags in one call than the kernel's LDS queue holds (MSK_TAGQ = 36), mixed
     # with other keys: the queue is refilled in instalments and the result stays bit-exact
     rng = np.random.default_rng(11)
-    nchan, lens = 2, [2600, 1400]
+    nchan, lens = 19, [2600, 1400]
     total = sum(lens)
     xs = np.stack([_signal(90 + c, total, 4)[0] for c in range(nchan)])
-    e = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=nchan)
+    e = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=nchan, lpw=16)  # 16 channels per wave: two waves, one ragged
     o = [orc.MskStream(4.0, 0.04, 0.01, 1) for _ in range(nchan)]
     all_tags = []
     for c in range(nchan):
