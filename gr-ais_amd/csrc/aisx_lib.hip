@@ -77,12 +77,12 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
     corr_resolve_body(cx, p);
 }
 
-template <bool AUX, bool OSPS2>
+template <bool AUX, bool OSPS2, int LPW>
 __global__ __launch_bounds__(MSK_T) void k_msk(MskParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
-    msk_body<DevCtx, AUX, OSPS2>(cx, p);
+    msk_body<DevCtx, AUX, OSPS2, LPW>(cx, p);
 }
 
 __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
@@ -98,18 +98,24 @@ __global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
     tagprep_body(cx, p);
 }
 
-// launch the timing-recovery build for (err/mu ports connected, osps == 2)
+// launch the timing-recovery build for (err/mu ports connected, osps == 2, channels per wave)
 static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
 {
     typedef void (*kfn)(MskParams);
-    static const kfn fns[4] = { k_msk<false, false>, k_msk<false, true>, k_msk<true, false>, k_msk<true, true> };
-    static bool big_lds[4] = { false, false, false, false };
-    const int v = ((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0);
-    if (!big_lds[v]) {
-        AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, MSK_LDS_BYTES));
+    static const kfn fns[12] = {
+        k_msk<false, false, 16>, k_msk<false, true, 16>, k_msk<true, false, 16>, k_msk<true, true, 16>,
+        k_msk<false, false, 32>, k_msk<false, true, 32>, k_msk<true, false, 32>, k_msk<true, true, 32>,
+        k_msk<false, false, 64>, k_msk<false, true, 64>, k_msk<true, false, 64>, k_msk<true, true, 64>,
+    };
+    static bool big_lds[12] = { false };
+    const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : 2);
+    const int v = li * 4 + (((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0));
+    const int lds = msk_lds_bytes(p.lpw);
+    if (!big_lds[v] && lds > 64 * 1024) {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         big_lds[v] = true;
     }
-    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(MSK_T), MSK_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(MSK_T), lds, st, p);
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }
@@ -611,8 +617,9 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
     h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
     {
-        // one wave per CU (the kernel takes a CU's whole LDS): as few channels per wave as
-        // still puts all channels on the chip at once
+        // as few channels per wave as still puts all channels on the chip at once, one wave
+        // per CU (fewer lanes per wave = fewer events of other lanes to wait for, and the LDS
+        // footprint of a wave shrinks with it, leaving the rest of the CU to other kernels)
         hipDeviceProp_t prop;
         int dev = 0;
         int ncu = 256;
@@ -784,7 +791,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
-    p.lds_tab_off = MSK_LDS_RING;
+    p.lds_tab_off = msk_lds_ring(h->lpw);
     p.lpw = h->lpw;
 }
 

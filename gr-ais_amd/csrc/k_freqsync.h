@@ -204,8 +204,19 @@ AISX_HD float nco_wrap(float ph)
     return r - F_PI;
 }
 
+// the same for |ph + pi| < 4 pi: u, or u -/+ 2 pi -- as selects
+AISX_HD float nco_wrap_small(float ph)
+{
+    const float F_PI = 3.14159265358979323846f;
+    const float TWO_PI = 2.0f * F_PI;
+    const float u = ph + F_PI;
+    const float w = u - copysignf(TWO_PI, u);
+    const float r = (fabsf(u) < TWO_PI) ? u : w;
+    return r - F_PI;
+}
+
 // ---------------------------------------------------------------------------
-constexpr int FSM_T = 256;             // wave 0 walks the NCO phases, waves 1..3 mix
+constexpr int FSM_T = 512;             // wave 0 walks the NCO phases, waves 1..7 mix
 constexpr int FSM_CPW = 16;            // channels per workgroup (256 workgroups at 4096 channels: one per CU)
 constexpr int FSM_MIXW = FSM_T / 64 - 1;
 constexpr int FSM_CH = 128;            // samples per chunk
@@ -242,7 +253,7 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
     float d = 0.f;
     const int total = p.nvec * FS_F;
     const int nchunks = total / FSM_CH;
-    // software pipeline: wave 0 produces the phases of chunk k while waves 1..3 mix chunk k-1
+    // software pipeline: wave 0 produces the phases of chunk k while waves 1..7 mix chunk k-1
     for (int k = 0; k <= nchunks; k++) {
         if (wave == 0) {
             if (mylive && k < nchunks) {
@@ -259,12 +270,20 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
                         p.fhat[(long)myc * p.fhat_stride + v] = f;
                     d = p.sensitivity * f;
                 }
+                // [GR] frequency_modulator_fc_impl::work: d_phase += sensitivity * in[i], then
+                // the fmod wrap.  With |d| < 2 pi the argument of the wrap stays below 4 pi in
+                // magnitude and fmod is a select (nco_wrap_small): no branch in the recurrence.
+                if (fabsf(d) < 6.0f) {
 #pragma unroll 8
-                for (int i = 0; i < FSM_CH; i++) {
-                    // [GR] frequency_modulator_fc_impl::work
-                    ph = ph + d;
-                    ph = nco_wrap(ph);
-                    dst[i] = ph;
+                    for (int i = 0; i < FSM_CH; i++) {
+                        ph = nco_wrap_small(ph + d);
+                        dst[i] = ph;
+                    }
+                } else {
+                    for (int i = 0; i < FSM_CH; i++) {
+                        ph = nco_wrap(ph + d);
+                        dst[i] = ph;
+                    }
                 }
             }
         } else if (k > 0) {

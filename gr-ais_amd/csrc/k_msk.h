@@ -47,12 +47,12 @@ constexpr int MSK_OFF = 192;    // ring slot of new-sample index s is (s + MSK_O
 constexpr int MSK_CARRY_MAX = 128;
 constexpr int MSK_PAIRS_MAX = 16; // pairs of iterations per check-free run (a power of two)
 constexpr int MSK_TAPS_PITCH = 12; // floats per table row in LDS: 16-byte aligned rows, two 128-bit reads per FIR
-constexpr int MSK_LDS_RING = MSK_SLOTS * 64 * 8;
+constexpr int msk_lds_ring(int lpw) { return MSK_SLOTS * lpw * 8; } // rings: [MSK_SLOTS][lpw] samples
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
 constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 511) / 512) * 512; // whole slot rows: folds into ds offsets
 constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
-constexpr int MSK_LDS_TAGQ = MSK_TAGQ * 64 * 8;
-constexpr int MSK_LDS_BYTES = MSK_LDS_RING + MSK_LDS_MMSE + MSK_LDS_TAGQ;
+constexpr int msk_lds_bytes(int lpw) { return msk_lds_ring(lpw) + MSK_LDS_MMSE + MSK_TAGQ * lpw * 8; }
+constexpr int MSK_LDS_BYTES = msk_lds_bytes(64); // the largest build
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
@@ -85,8 +85,8 @@ struct MskParams {
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
-    int lds_tab_off;   // = MSK_LDS_RING
-    int lpw;           // channels (active lanes) per wave: 16, 32 or 64
+    int lds_tab_off;   // = msk_lds_ring(lpw)
+    int lpw;           // channels (active lanes) per wave, = the build's LPW: 16, 32 or 64
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -110,17 +110,22 @@ AISX_HD int msk_forecast(float d_sps, int noutput_items)
 extern long msk_stats[8];
 #endif
 // AUX: the err / mu output ports are connected (:187-189).  OSPS2: osps == 2 (:186).
-template <class Ctx, bool AUX, bool OSPS2>
+// LPW: channels (active lanes) per wave; the LDS layouts are [.][LPW], so a build with few
+// channels per wave leaves most of the CU's LDS to whatever else runs there.
+template <class Ctx, bool AUX, bool OSPS2, int LPW>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
+    constexpr int SLOT_B = LPW * 8;                                   // bytes per ring slot row
+    constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : 7);      // log2(SLOT_B)
+    static_assert(LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
     typedef unsigned long long u64;
     const int l = cx.tid();
     // p.lpw lanes of the wave carry channels (16, 32 or 64).  Few channels per wave when
     // the chip has CUs to spare: events of different lanes stall each other less, LDS
     // returns fewer bytes per instruction, a chunk load touches fewer lines.
-    if (l >= p.lpw)
+    if (l >= LPW)
         return;
-    const int cbase = cx.bx() * p.lpw;
+    const int cbase = cx.bx() * LPW;
     const int c = cbase + l;
     const bool live = c < p.nchan;
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
@@ -130,9 +135,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // [130][MSK_TAPS_PITCH] behind the rings; the offset comes in as a kernel argument so that
     // it sits in a scalar register and a row address is one multiply-add
     float* mm = (float*)(lds + p.lds_tab_off);
-    cf* myring = ring + l;                     // slot k of this lane: myring[k * 64]
+    cf* myring = ring + l;                     // slot k of this lane: myring[k * LPW]
 
-    for (int i = l; i < 129 * 8; i += p.lpw)
+    for (int i = l; i < 129 * 8; i += LPW)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
     if (l < MSK_TAPS_PITCH)
         mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f;
@@ -159,9 +164,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int navail = pending + n;
     for (int q = -1; q < pending; q++) {
         const int slot = (q - pending + MSK_OFF) & (MSK_RING - 1);
-        myring[slot * 64] = cin[q + 1];
+        myring[slot * LPW] = cin[q + 1];
         if (slot < 8)
-            myring[(MSK_RING + slot) * 64] = cin[q + 1];
+            myring[(MSK_RING + slot) * LPW] = cin[q + 1];
     }
 
     // the time_est tags visible to this call (carried ones first), already compacted
@@ -170,17 +175,17 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     if (ntot > p.ct_cap)
         ntot = p.ct_cap;
     // They are queued in LDS: the loop must not pay global-memory latency when a tag fires.
-    // MSK_TAGQ entries per lane, entry k of lane l at tq[k * 64 + l]; a longer list is queued
+    // MSK_TAGQ entries per lane, entry k of lane l at tq[k * LPW + l]; a longer list is queued
     // in instalments.
     typedef msk_ctag tq_ent;
-    tq_ent* const tq = (tq_ent*)(lds + MSK_LDS_RING + MSK_LDS_MMSE) + l;
+    tq_ent* const tq = (tq_ent*)(lds + msk_lds_ring(LPW) + MSK_LDS_MMSE) + l;
     const int TQ_NONE = 0x7fffffff;
     int gq = 0;            // tags of the list looked at so far
     int qhead = 0, qn = 0; // queue: entries [0, qn), front at qhead
     auto tq_fill = [&]() {
         // (keeps the entry popped last: its offset may still be >= nitems_read at the end)
         if (qn > 0) {
-            tq[0] = tq[(qn - 1) * 64];
+            tq[0] = tq[(qn - 1) * LPW];
             qn = 1;
         }
         qhead = qn;
@@ -193,7 +198,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             for (int j = 0; j < 4; j++) {
                 if (qn < MSK_TAGQ && gq < ntot) {
                     gq++;
-                    tq[qn * 64] = t[j];
+                    tq[qn * LPW] = t[j];
                     qn++;
                 }
             }
@@ -207,7 +212,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (qhead >= qn && gq < ntot)
             tq_fill();
         if (qhead < qn) {
-            const tq_ent e = tq[qhead * 64];
+            const tq_ent e = tq[qhead * LPW];
             fr_rel = e.rel;
             nt_val = e.val;
         } else {
@@ -302,11 +307,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const int slot0 = (t * MSK_CHUNK + MSK_OFF) & (MSK_RING - 1); // multiple of 64
 #pragma unroll
         for (int k = 0; k < MSK_CHUNK; k++)
-            myring[(slot0 + k) * 64] = r[k];
+            myring[(slot0 + k) * LPW] = r[k];
         if (slot0 == 0) { // mirror the first 8 slots behind slot 255
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                myring[(MSK_RING + k) * 64] = r[k];
+                myring[(MSK_RING + k) * LPW] = r[k];
         }
     };
     issue_chunk(0);
@@ -314,10 +319,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     int landed = 1; // chunks in the rings
     cx.sync();
 
-    // sb = 512 * (ring position of in[iidx]) = 512 * (new-sample index + MSK_OFF), unmasked:
+    // sb = SLOT_B * (ring position of in[iidx]) = SLOT_B * (new-sample index + MSK_OFF), unmasked:
     // the byte offset of that slot row; it moves with iidx and is untouched by the end of a
     // general_work call (base += iidx, iidx = 0)
-    int sb = (base + iidx - pending + MSK_OFF) * 512;
+    int sb = (base + iidx - pending + MSK_OFF) * SLOT_B;
     // iterations with iidx < fast_lim (and oidx < noutput) need none of the event code
     int fast_lim = (int)0x80000000;
     int tag_trig = (int)0x80000000; // first iidx at which the front tag can fire (set by events())
@@ -340,7 +345,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         if (done)
             return EV_PARK;
-        const int spos = sb >> 9;
+        const int spos = sb >> SLOT_SH;
         // the next chunk has to land before this lane can go on (a tag is left for later too:
         // the iteration it resets must follow at once)
         const bool waiting = more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s);
@@ -355,7 +360,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     d_mu++;
                     iidx--;
                 }
-                sb += (iidx - old) * 512;
+                sb += (iidx - old) * SLOT_B;
                 d_div = 0;
                 d_omega = d_sps;
                 // (:160 d_dly_conj_2 = d_dly_conj_1: prev_sq already is the square of it)
@@ -391,11 +396,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
     auto fir = [&](unsigned row, int sbpos) -> cf {
         const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * 512)) | (unsigned)(l * 8)));
+        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * SLOT_B)) | (unsigned)(l * 8)));
         cf acc = mk(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const cf s = sp[k * 64]; // mirror slots: no wrap inside the 8 taps
+            const cf s = sp[k * LPW]; // mirror slots: no wrap inside the 8 taps
             const float tk = tp[7 - k];
             acc.re += s.re * tk;
             acc.im += s.im * tk;
@@ -409,10 +414,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4)); // 16-byte aligned rows
         const tap4 tlo = tp4[0], thi = tp4[1];
         const float tp[8] = { tlo[0], tlo[1], tlo[2], tlo[3], thi[0], thi[1], thi[2], thi[3] };
-        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * 512)) | (unsigned)(l * 8)));
+        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * SLOT_B)) | (unsigned)(l * 8)));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            sv[k] = sp[k * 64];
+            sv[k] = sp[k * LPW];
             tv[k] = tp[7 - k];
         }
     };
@@ -462,7 +467,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const float fl = floorf(d_mu);
         const int adv = (int)fl;
         iidx += adv;
-        sb += adv * 512;
+        sb += adv * SLOT_B;
         d_mu = d_mu - fl;
     };
 
@@ -519,7 +524,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // every lane re-arms its bound against the horizon (same formula as in events()); a lane
     // that owes the iteration after a tag reset keeps its one-iteration bound
     auto rearm = [&]() {
-        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - ((sb >> 9) - iidx) + 1) : 0x7fffffff;
+        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - ((sb >> SLOT_SH) - iidx) + 1) : 0x7fffffff;
         int f = ninp < tag_trig ? ninp : tag_trig;
         f = f < chunk_lim ? f : chunk_lim;
         fast_lim = (tag_trig == TRIG_FORCED) ? fast_lim : f;
@@ -573,7 +578,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     fir_load((unsigned)(int)rintf(d_mu * 128.0f), sb, svE, tvE);
                     const float m1 = d_mu + d_omega;                               // :199-201, m1 > 0:
                     const float muO = cx.fract(m1);                                // m1 - floorf(m1)
-                    const int sb1 = sb + (int)m1 * 512;                            // (int)floorf(m1)
+                    const int sb1 = sb + (int)m1 * SLOT_B;                            // (int)floorf(m1)
                     fir_load((unsigned)(int)rintf(muO * 128.0f), sb1, svO, tvO);
                     const cf accE = fir_sum(svE, tvE);
                     const cf sE = cmul_exact(accE, accE);                          // :171
@@ -606,7 +611,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     }
                     const float m2 = mu2 + d_omega;                                // > 0 (lock_ok)
                     d_mu = cx.fract(m2);
-                    sb = sb1 + (int)m2 * 512;
+                    sb = sb1 + (int)m2 * SLOT_B;
                     sqE = sE;
                     sqO = s1;
                     accO = acc1;
@@ -615,7 +620,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 // hand the state back to the per-lane variables
                 d_div += 2 * npairs;
                 oidx += OSPS2 ? 2 * npairs : npairs;
-                iidx += (sb - sb_entry) >> 9;
+                iidx += (sb - sb_entry) >> SLOT_SH;
                 prev_sq = sqO;
                 last_interp = accO;
                 // :174 imaginary part of the last nlin_out: only ever read back as state
@@ -635,7 +640,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // chunk does land.
         { PF_BEGIN
         if (more) {
-            const bool clear = done || ((sb >> 9) - MSK_OFF >= landed * MSK_CHUNK - (MSK_RING - MSK_CHUNK) + 2);
+            const bool clear = done || ((sb >> SLOT_SH) - MSK_OFF >= landed * MSK_CHUNK - (MSK_RING - MSK_CHUNK) + 2);
             if (cx.ballot(clear) == ALL) {
 #ifdef MSK_EMU_STATS
                 if (l == 0) msk_stats[4]++;
@@ -699,13 +704,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             left = cap - 1;
         }
         for (int k = 0; k <= left; k++)
-            cout[k] = myring[((base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)) * 64];
+            cout[k] = myring[((base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)) * LPW];
         p.carry_len_out[c] = left;
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
         int w = 0;
         for (int k = 0; k < qn; k++) { // queued ones (value already narrowed to the float the loop uses)
-            const tq_ent e = tq[k * 64];
+            const tq_ent e = tq[k * LPW];
             if (e.rel < base)
                 continue;
             if (w < p.ctag_cap) {
@@ -738,7 +743,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         }
         p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
     } else {
-        cout[0] = myring[((base - 1 - pending + MSK_OFF) & (MSK_RING - 1)) * 64];
+        cout[0] = myring[((base - 1 - pending + MSK_OFF) & (MSK_RING - 1)) * LPW];
         p.carry_len_out[c] = 0;
         p.ctag_n_out[c] = 0;
     }

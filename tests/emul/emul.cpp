@@ -168,12 +168,21 @@ void emu_bittail(const BitTailParams* p, int max_out)
 void emu_msk(const MskParams* p)
 {
     const bool aux = p->err || p->mu_out;
-    run_grid((p->nchan + p->lpw - 1) / p->lpw, 1, p->lpw, MSK_LDS_BYTES, [&](EmuCtx& cx) {
-        if (p->osps == 2)
-            aux ? msk_body<EmuCtx, true, true>(cx, *p) : msk_body<EmuCtx, false, true>(cx, *p);
-        else
-            aux ? msk_body<EmuCtx, true, false>(cx, *p) : msk_body<EmuCtx, false, false>(cx, *p);
-    });
+    auto go = [&](auto lpw_tag) {
+        constexpr int L = decltype(lpw_tag)::value;
+        run_grid((p->nchan + L - 1) / L, 1, L, msk_lds_bytes(L), [&](EmuCtx& cx) {
+            if (p->osps == 2)
+                aux ? msk_body<EmuCtx, true, true, L>(cx, *p) : msk_body<EmuCtx, false, true, L>(cx, *p);
+            else
+                aux ? msk_body<EmuCtx, true, false, L>(cx, *p) : msk_body<EmuCtx, false, false, L>(cx, *p);
+        });
+    };
+    if (p->lpw == 16)
+        go(std::integral_constant<int, 16>{});
+    else if (p->lpw == 32)
+        go(std::integral_constant<int, 32>{});
+    else
+        go(std::integral_constant<int, 64>{});
 }
 
 // ---- corr_est_cc handle mirroring aisx_corr_* (host orchestration of aisx_lib.hip) ----
@@ -293,7 +302,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.ct = h->ct.data(); p.ct_n = h->ct_n.data(); p.ct_cap = h->ct_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
-    p.lds_tab_off = MSK_LDS_RING;
+    p.lds_tab_off = msk_lds_ring(h->lpw);
     p.lpw = h->lpw;
 }
 

@@ -30,7 +30,7 @@ def test_emul_msk_stream_bit_exact(sps, osps):
     nchan, lens = (67 if (sps, osps) == (4.0, 1) else 3), [1500, 37, 900, 1, 700]
     total = sum(lens)
     xs = np.stack([_signal(50 + c, total, 4)[0] for c in range(nchan)])
-    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan, lpw=(16 if sps == 5.0 else 64))
+    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan, lpw=(16 if sps == 5.0 else (32 if sps == 5.2083 else 64)))
     o = [orc.MskStream(sps, 0.04, 0.01, osps) for _ in range(nchan)]
     bt = [orc.BitTail() for _ in range(nchan)]
     # tags: a mix of plausible time_est tags, NaN, other keys, clustered offsets
