@@ -29,6 +29,13 @@ __global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
     DevCtx cx{ nullptr };
     fs_freqest_body(cx, p);
 }
+__global__ __launch_bounds__(AGC_T) void k_agc8(AgcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    agc8_body(cx, p);
+}
+
 __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,7 +285,10 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.W = h->W;
     p.reference = h->reference;
     p.ntiles = (n + AGC_TL - 1) / AGC_TL;
-    hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
+    if (agc8_applies(p.W))
+        hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     return AISX_OK;

@@ -17,6 +17,9 @@ constexpr int AGC_MAXW = 2048;   // largest supported window
 constexpr int AGC_E = AGC_TL + AGC_MAXW; // envelope slots per buffer
 constexpr int AGC_LDS_BYTES = 2 * AGC_E * 4;
 
+// two consecutive items; rows are only 8-byte aligned
+struct __attribute__((packed, aligned(8))) cf_pair_agc { cf a, b; };
+
 struct AgcParams {
     const cf* in; long in_stride;   // [nchan][n] new items
     cf* out; long out_stride;       // [nchan][n]
@@ -108,6 +111,160 @@ AISX_DI void agc_body(Ctx& cx, const AgcParams& p)
         cf* ho = p.hist_out + (long)c * H;
         for (int j = t; j < H; j += AGC_T) {
             const int s = n + j; // combined index of the j-th kept item
+            ho[j] = (s < H) ? hist[s] : xin[s - H];
+        }
+    }
+}
+
+// The same for windows that are a multiple of 8 (the stock 512 is): each thread owns 8
+// consecutive items.  The window of item i = 8a + k is the tail of its own group (a running
+// maximum the thread keeps in registers), the Q - 1 = W/8 - 1 whole groups after it (a
+// sliding maximum over GROUP maxima: 1/8 of the elements, log2(Q) doubling passes) and the
+// first k items of group a + Q (that group's prefix maxima, exchanged through LDS).  About
+// three LDS operations per item instead of three per item and doubling pass.
+constexpr int AGC8_G = 8;
+constexpr int AGC8_NG = AGC_TL / AGC8_G;               // groups with outputs per tile (= AGC_T)
+constexpr int AGC8_MAXQ = AGC_MAXW / AGC8_G;           // halo groups at most
+constexpr int AGC8_GROUPS = AGC8_NG + AGC8_MAXQ;       // group maxima per buffer
+constexpr int AGC8_LDS_BYTES = (2 * AGC8_GROUPS + AGC8_GROUPS * AGC8_G) * 4;
+static_assert(AGC8_NG == AGC_T, "one output group per thread");
+static_assert(AGC8_MAXQ <= AGC_T, "at most one halo group per thread");
+
+AISX_HD bool agc8_applies(int W) { return W % AGC8_G == 0 && W >= 2 * AGC8_G && W <= AGC_MAXW; }
+
+template <class Ctx>
+AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
+{
+    const int t = cx.tid();
+    const int c = cx.by();
+    const int tile = cx.bx();
+    float* GA = (float*)cx.lds();            // group maxima, ping
+    float* GB = GA + AGC8_GROUPS;            // ... pong
+    float* PF = GB + AGC8_GROUPS;            // prefix maxima of every group: PF[g * 8 + k] = max(e[8g .. 8g+k])
+    const int H = p.W - 1;
+    const int Q = p.W / AGC8_G;
+    const int n = p.n;
+    const cf* xin = p.in + (long)c * p.in_stride;
+    const cf* hist = p.hist_in + (long)c * H;
+    cf* xout = p.out + (long)c * p.out_stride;
+
+    const int base = tile * AGC_TL;
+    const int nout = (n - base) < AGC_TL ? (n - base) : AGC_TL;
+    const int E = nout + H;                         // items of the combined stream this tile looks at
+    const int ngroups = (E + AGC8_G - 1) / AGC8_G;  // <= AGC8_NG + Q
+
+    // one group: load (zero past the end), envelopes, prefix maxima to LDS, group maximum
+    cf own[AGC8_G];
+    float sfx[AGC8_G]; // suffix maxima of the thread's output group: max(e[k .. 7])
+    auto do_group = [&](int g, bool keep) {
+        cf v[AGC8_G];
+        const int s0 = base + g * AGC8_G;
+        if (s0 >= H && g * AGC8_G + AGC8_G <= E) { // wholly inside the new items: 16-byte loads
+            const cf_pair_agc* src = (const cf_pair_agc*)(xin + (s0 - H));
+#pragma unroll
+            for (int k = 0; k < AGC8_G / 2; k++) {
+                const cf_pair_agc q = src[k];
+                v[2 * k] = q.a;
+                v[2 * k + 1] = q.b;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < AGC8_G; k++) {
+                const int j = g * AGC8_G + k, s = base + j;
+                v[k] = mk(0.f, 0.f);
+                if (j < E)
+                    v[k] = (s < H) ? hist[s] : xin[s - H];
+            }
+        }
+        float e[AGC8_G];
+#pragma unroll
+        for (int k = 0; k < AGC8_G; k++)
+            e[k] = (g * AGC8_G + k < E) ? agc_envelope(v[k]) : 0.f; // (0 never wins: floor 1e-12)
+        float run = e[0];
+        PF[g * AGC8_G] = run;
+#pragma unroll
+        for (int k = 1; k < AGC8_G; k++) {
+            run = run < e[k] ? e[k] : run;
+            PF[g * AGC8_G + k] = run;
+        }
+        GA[g] = run;
+        if (keep) {
+            float r2 = e[AGC8_G - 1];
+            sfx[AGC8_G - 1] = r2;
+#pragma unroll
+            for (int k = AGC8_G - 2; k >= 0; k--) {
+                r2 = r2 < e[k] ? e[k] : r2;
+                sfx[k] = r2;
+            }
+#pragma unroll
+            for (int k = 0; k < AGC8_G; k++)
+                own[k] = v[k];
+        }
+    };
+    if (t < ngroups)
+        do_group(t, true);
+    if (AGC8_NG + t < ngroups)
+        do_group(AGC8_NG + t, false);
+    for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC_T)
+        GA[g] = 0.f; // groups past the data: neutral
+    cx.sync();
+    // sliding maximum over Q - 1 group maxima by doubling: 2^K <= Q - 1
+    int K = 0;
+    while ((2 << K) <= Q - 1)
+        K++;
+    float* src = GA;
+    float* dst = GB;
+    for (int k = 0; k < K; k++) {
+        const int step = 1 << k;
+        for (int g = t; g < AGC8_GROUPS; g += AGC_T) {
+            const float a = src[g];
+            const float b = (g + step < AGC8_GROUPS) ? src[g + step] : a;
+            dst[g] = a < b ? b : a;
+        }
+        cx.sync();
+        float* tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    if (t * AGC8_G < nout) {
+        // whole groups t+1 .. t+Q-1
+        const float w1 = src[t + 1], w2 = src[t + Q - (1 << K)];
+        const float gw = w1 < w2 ? w2 : w1;
+        const float* pf = PF + (t + Q) * AGC8_G; // prefix maxima of the group the window ends in
+        cf o[AGC8_G];
+#pragma unroll
+        for (int k = 0; k < AGC8_G; k++) {
+            float mx = sfx[k] < gw ? gw : sfx[k];
+            if (k > 0) {
+                const float pe = pf[k - 1];
+                mx = mx < pe ? pe : mx;
+            }
+            mx = (1e-12f < mx) ? mx : 1e-12f;
+            const float gain = fdiv_rn(p.reference, mx);
+            o[k] = mk(gain * own[k].re, gain * own[k].im);
+        }
+        const int i0 = t * AGC8_G;
+        if (i0 + AGC8_G <= nout) {
+            cf_pair_agc* dstp = (cf_pair_agc*)(xout + base + i0);
+#pragma unroll
+            for (int k = 0; k < AGC8_G / 2; k++) {
+                cf_pair_agc q;
+                q.a = o[2 * k];
+                q.b = o[2 * k + 1];
+                dstp[k] = q;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < AGC8_G; k++)
+                if (i0 + k < nout)
+                    xout[base + i0 + k] = o[k];
+        }
+    }
+    // set_history(nsamples): keep the last W-1 items of the combined stream
+    if (tile == p.ntiles - 1) {
+        cf* ho = p.hist_out + (long)c * H;
+        for (int j = t; j < H; j += AGC_T) {
+            const int s = n + j;
             ho[j] = (s < H) ? hist[s] : xin[s - H];
         }
     }

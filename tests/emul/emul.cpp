@@ -445,7 +445,10 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.n = n; p.W = h->W; p.reference = h->ref; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
-    run_grid(p.ntiles, h->nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, p); });
+    if (agc8_applies(p.W))
+        run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
+    else
+        run_grid(p.ntiles, h->nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, p); });
     h->cur ^= 1;
 }
 #endif

@@ -17,7 +17,7 @@ def test_emul_agc_bit_exact():
     x[0, 1000:3000] = 0          # floor 1e-12 path
     x[1, 200] = np.nan           # NaN envelopes are ignored by std::max
     x[2] *= np.linspace(0.01, 30, total).astype(np.float32)
-    for W in (512, 1, 37, 2048):
+    for W in (512, 1, 37, 2048, 16, 24):
         e = emu.Agc(W, 2.0, nchan)
         o = [orc.Agc(W, 2.0) for _ in range(nchan)]
         k = 0

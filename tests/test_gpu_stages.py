@@ -34,7 +34,7 @@ def test_agc_bit_exact(ais):
     x[0, 1000:3000] = 0
     x[1, 200] = np.nan
     x[2] *= np.linspace(0.01, 30, total).astype(np.float32)
-    for W in (512, 1, 37, 2048):
+    for W in (512, 1, 37, 2048, 16, 24):
         blk = ais.feedforward_agc_cc(W, 2.0, nchan=nchan, max_items=max(lens))
         o = [orc.Agc(W, 2.0) for _ in range(nchan)]
         k = 0
