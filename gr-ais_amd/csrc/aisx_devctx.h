@@ -14,6 +14,9 @@ struct DevCtx {
     __device__ __forceinline__ int by() const { return blockIdx.y; }
     __device__ __forceinline__ char* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // a lane that leaves the kernel for good before its workgroup's barriers (nothing to do
+    // on the device: the hardware counts waves, not lanes)
+    __device__ __forceinline__ void retire() const {}
     __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
     // per-lane predicate from a wave-uniform mask (the mask goes straight into exec / vcc)
     __device__ __forceinline__ bool inv_ballot(unsigned long long m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 }
 
 template <bool AUX, bool OSPS2, int LPW>
-__global__ __launch_bounds__(MSK_T) void k_msk(MskParams p)
+__global__ __launch_bounds__(64 * (64 / LPW)) void k_msk(MskParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
@@ -110,12 +110,13 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
     static bool big_lds[12] = { false };
     const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : 2);
     const int v = li * 4 + (((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0));
-    const int lds = msk_lds_bytes(p.lpw);
-    if (!big_lds[v] && lds > 64 * 1024) {
+    const int lds = MSK_LDS_BYTES;
+    if (!big_lds[v]) {
         AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         big_lds[v] = true;
     }
-    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(MSK_T), lds, st, p);
+    // a workgroup = 64 channels = 64 / lpw waves with lpw lanes at work each
+    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(64 * (64 / p.lpw)), lds, st, p);
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }
@@ -617,17 +618,10 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
     h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
     {
-        // as few channels per wave as still puts all channels on the chip at once, one wave
-        // per CU (fewer lanes per wave = fewer events of other lanes to wait for, and the LDS
-        // footprint of a wave shrinks with it, leaving the rest of the CU to other kernels)
-        hipDeviceProp_t prop;
-        int dev = 0;
-        int ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
+        // 16 channels per wave, four waves (one per SIMD) and 64 channels per workgroup: fewer
+        // lanes per wave = fewer events of other lanes to wait for, and the kernel still keeps
+        // to nchan / 64 CUs, which leaves the rest of the chip to the stages that run beside it
         h->lpw = 16;
-        while (h->lpw < 64 && (long)h->lpw * ncu < nchan)
-            h->lpw *= 2;
         if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
             if (v == 16 || v == 32 || v == 64)
@@ -791,7 +785,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
-    p.lds_tab_off = msk_lds_ring(h->lpw);
+    p.lds_tab_off = MSK_LDS_TABOFF;
     p.lpw = h->lpw;
 }
 
@@ -902,7 +896,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : h->d_produced;
-    if ((rc = msk_launch(p, (h->nchan + h->lpw - 1) / h->lpw, (hipStream_t)stream)) != AISX_OK)
+    if ((rc = msk_launch(p, (h->nchan + 63) / 64, (hipStream_t)stream)) != AISX_OK)
         return rc;
     h->cur ^= 1;
     if (d_bits) {

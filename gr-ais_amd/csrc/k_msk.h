@@ -51,8 +51,11 @@ constexpr int msk_lds_ring(int lpw) { return MSK_SLOTS * lpw * 8; } // rings: [M
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
 constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 511) / 512) * 512; // whole slot rows: folds into ds offsets
 constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
-constexpr int msk_lds_bytes(int lpw) { return msk_lds_ring(lpw) + MSK_LDS_MMSE + MSK_TAGQ * lpw * 8; }
-constexpr int MSK_LDS_BYTES = msk_lds_bytes(64); // the largest build
+// a workgroup always carries 64 channels, as 64 / lpw waves of lpw lanes; every wave has its own
+// rings and tag queue, the tap table behind them is shared
+constexpr int msk_lds_wave(int lpw) { return msk_lds_ring(lpw) + MSK_TAGQ * lpw * 8; }
+constexpr int MSK_LDS_TABOFF = msk_lds_wave(64);          // = (64 / lpw) * msk_lds_wave(lpw) for every lpw
+constexpr int MSK_LDS_BYTES = MSK_LDS_TABOFF + MSK_LDS_MMSE;
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
@@ -85,7 +88,7 @@ struct MskParams {
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
-    int lds_tab_off;   // = msk_lds_ring(lpw)
+    int lds_tab_off;   // = MSK_LDS_TABOFF
     int lpw;           // channels (active lanes) per wave, = the build's LPW: 16, 32 or 64
 };
 
@@ -119,28 +122,38 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : 7);      // log2(SLOT_B)
     static_assert(LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
     typedef unsigned long long u64;
-    const int l = cx.tid();
-    // p.lpw lanes of the wave carry channels (16, 32 or 64).  Few channels per wave when
-    // the chip has CUs to spare: events of different lanes stall each other less, LDS
-    // returns fewer bytes per instruction, a chunk load touches fewer lines.
-    if (l >= LPW)
+    // A workgroup carries 64 channels as 64 / LPW waves, LPW lanes of each at work, every
+    // wave on its own (its own SIMD, rings, tag queue, pace).  Few channels per wave: events of
+    // other lanes stall a lane less, LDS returns fewer bytes per instruction, a chunk load
+    // touches fewer lines -- and the 64 channels still sit on one CU, leaving the others alone.
+    static_assert(64 % LPW == 0, "whole waves");
+    const int wv = cx.tid() >> 6, l = cx.tid() & 63;
+    if (l >= LPW) {
+        cx.retire();
         return;
-    const int cbase = cx.bx() * LPW;
+    }
+    const int cbase = cx.bx() * 64 + wv * LPW;
     const int c = cbase + l;
     const bool live = c < p.nchan;
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
-    char* lds = cx.lds();
-    cf* ring = (cf*)lds;                       // [MSK_SLOTS][64] at LDS offset 0: a slot address is one and-or
-    // [130][MSK_TAPS_PITCH] behind the rings; the offset comes in as a kernel argument so that
-    // it sits in a scalar register and a row address is one multiply-add
-    float* mm = (float*)(lds + p.lds_tab_off);
+    char* const lds0 = cx.lds();
+    char* const lds = lds0 + wv * msk_lds_wave(LPW); // this wave's rings [MSK_SLOTS][LPW] and tag queue
+    cf* ring = (cf*)lds;
+    // [130][MSK_TAPS_PITCH], one per workgroup, behind the waves' regions; the offset comes in
+    // as a kernel argument so that it sits in a scalar register and a row address is one
+    // multiply-add
+    float* mm = (float*)(lds0 + p.lds_tab_off);
     cf* myring = ring + l;                     // slot k of this lane: myring[k * LPW]
 
-    for (int i = l; i < 129 * 8; i += LPW)
+    for (int i = wv * LPW + l; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
-    if (l < MSK_TAPS_PITCH)
+    if (wv == 0 && l < MSK_TAPS_PITCH)
         mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f;
+    if (cbase >= p.nchan) { // a wave with no channel at all (ragged last workgroup)
+        cx.sync();
+        return;
+    }
 
     const float d_sps = p.d_sps;
     float d_mu = p.mu[cc], d_omega = p.omega[cc];
@@ -178,7 +191,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // MSK_TAGQ entries per lane, entry k of lane l at tq[k * LPW + l]; a longer list is queued
     // in instalments.
     typedef msk_ctag tq_ent;
-    tq_ent* const tq = (tq_ent*)(lds + msk_lds_ring(LPW) + MSK_LDS_MMSE) + l;
+    tq_ent* const tq = (tq_ent*)(lds + msk_lds_ring(LPW)) + l;
     const int TQ_NONE = 0x7fffffff;
     int gq = 0;            // tags of the list looked at so far
     int qhead = 0, qn = 0; // queue: entries [0, qn), front at qhead

@@ -5,6 +5,7 @@
 // can be checked against the oracle on a machine without a GPU.  It is not part
 // of libaisx.so and nothing in the product can reach it.
 #include <barrier>
+#include <memory>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -31,12 +32,16 @@ namespace aisx { long msk_stats[8]; }
 using namespace aisx;
 
 struct EmuShared {
-    std::barrier<> bar;
+    std::barrier<> bar;                                // workgroup barrier
+    std::vector<std::unique_ptr<std::barrier<>>> wbar; // one per wave: ballots / lane exchanges
     int nthreads;
     std::vector<char> lds;
-    unsigned long long x64[1024];
-    double xf64[1024];
-    explicit EmuShared(int nt, size_t ldsbytes) : bar(nt), nthreads(nt), lds(ldsbytes + 64) {}
+    unsigned long long x64[2048] = {};
+    explicit EmuShared(int nt, size_t ldsbytes) : bar(nt), nthreads(nt), lds(ldsbytes + 64)
+    {
+        for (int w = 0; w * 64 < nt; w++)
+            wbar.emplace_back(new std::barrier<>(std::min(64, nt - w * 64)));
+    }
 };
 
 struct EmuCtx {
@@ -48,16 +53,23 @@ struct EmuCtx {
     int by() const { return by_; }
     char* lds() const { return sh->lds.data(); }
     void sync() const { sh->bar.arrive_and_wait(); }
+    void wsync() const { sh->wbar[tid_ >> 6]->arrive_and_wait(); }
+    // a lane that leaves the kernel for good: it stops counting in the barriers
+    void retire() const
+    {
+        sh->wbar[tid_ >> 6]->arrive_and_drop();
+        sh->bar.arrive_and_drop();
+    }
     int wave_base() const { return tid_ & ~63; }
     // wave collectives: one barrier per call; the exchange slots are double-buffered
     // (bank = parity of this lane's call count; all lanes of a block call in lock-step)
     mutable unsigned ncall = 0;
-    unsigned long long* bank() const { return sh->x64 + ((ncall++ & 1u) ? 512 : 0); }
+    unsigned long long* bank() const { return sh->x64 + ((ncall++ & 1u) ? 1024 : 0); }
     unsigned long long ballot(bool p) const
     {
         unsigned long long* b = bank();
         b[tid_] = p ? 1ull : 0ull;
-        sync();
+        wsync();
         unsigned long long m = 0;
         for (int l = 0; l < 64 && wave_base() + l < sh->nthreads; l++)
             m |= b[wave_base() + l] << l;
@@ -76,7 +88,7 @@ struct EmuCtx {
         memcpy(&raw, &v, sizeof(T));
         unsigned long long* b = bank();
         b[tid_] = raw;
-        sync();
+        wsync();
         int s = wave_base() + (src_lane & 63);
         if (s >= sh->nthreads)
             s = tid_;
@@ -170,7 +182,7 @@ void emu_msk(const MskParams* p)
     const bool aux = p->err || p->mu_out;
     auto go = [&](auto lpw_tag) {
         constexpr int L = decltype(lpw_tag)::value;
-        run_grid((p->nchan + L - 1) / L, 1, L, msk_lds_bytes(L), [&](EmuCtx& cx) {
+        run_grid((p->nchan + 63) / 64, 1, 64 * (64 / L), MSK_LDS_BYTES, [&](EmuCtx& cx) {
             if (p->osps == 2)
                 aux ? msk_body<EmuCtx, true, true, L>(cx, *p) : msk_body<EmuCtx, false, true, L>(cx, *p);
             else
@@ -302,7 +314,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.ct = h->ct.data(); p.ct_n = h->ct_n.data(); p.ct_cap = h->ct_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
-    p.lds_tab_off = msk_lds_ring(h->lpw);
+    p.lds_tab_off = MSK_LDS_TABOFF;
     p.lpw = h->lpw;
 }
 
