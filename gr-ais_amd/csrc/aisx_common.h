@@ -74,6 +74,8 @@ AISX_HD float branchless_clip(float x, float clip)
     return 0.5f * x1;
 }
 
+AISX_HD int aisx_popc64(unsigned long long v) { return __builtin_popcountll(v); }
+
 // gr::fast_atan2f (gnuradio-runtime fast_atan2f.cc); `tab` = 257-entry table.
 // Written with selects instead of the upstream if/else ladder (a divergent
 // ladder costs a wave every arm); every arithmetic operation and operand is the

@@ -819,7 +819,7 @@ static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_t
     t.ct = h->d_ct;
     t.ct_n = h->d_ct_n;
     t.ct_cap = h->ct_cap;
-    hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 255) / 256), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 3) / 4), dim3(256), 0, st, t); // a wave per channel
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }

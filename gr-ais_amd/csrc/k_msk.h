@@ -346,6 +346,20 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int TRIG_FORCED = (int)0x80000001;
 
     // the reference's loop head for one lane, in its order (:138-164)
+    // how far a lane can run before the next event: the first iidx at which its front tag can
+    // fire (tag_trig), the data horizon, the end of the general_work call
+    auto bounds = [&](int spos) {
+        tag_trig = 0x7fffffff;
+        if (nt_rel != 0x7fffffff && iidx <= nt_rel) { // (a tag the loop stepped over stays in front for good)
+            int i = nt_rel - jump_margin - 1;
+            while (!((float)nt_rel < ((float)i + d_sps)))
+                i++;
+            tag_trig = i;
+        }
+        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - (spos - iidx) + 1) : 0x7fffffff;
+        fast_lim = ninp < tag_trig ? ninp : tag_trig;
+        fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
+    };
     auto events = [&](const int PAR) -> int {
         if (!(oidx < noutput && iidx < ninp)) { // this general_work() call is over (:138)
             base += iidx;                       // consume_each(iidx)
@@ -380,24 +394,20 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             }
             tq_pop();
             nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
-            tag_trig = TRIG_FORCED;
-            fast_lim = iidx + 1; // the reference runs this iteration whatever comes next: one
-                                 // iteration, then back here (one tag per iteration, :140)
+            // The reference runs this iteration whatever comes next (one tag per iteration,
+            // :140).  Usually the bounds that hold after it can be set right away; if the next
+            // event is already due, the lane gets one iteration and comes back here.
+            bounds(sb >> SLOT_SH);
+            if (fast_lim <= iidx) {
+                tag_trig = TRIG_FORCED;
+                fast_lim = iidx + 1;
+            }
             return ((d_div & 1) == PAR) ? EV_GO : EV_OTHER_PARITY;
         }
         // nothing to do now: how far can this lane run before the next event?
-        tag_trig = 0x7fffffff;
-        if (nt_rel != 0x7fffffff && iidx <= nt_rel) { // (a tag the loop stepped over stays in front for good)
-            int i = nt_rel - jump_margin - 1;
-            while (!((float)nt_rel < ((float)i + d_sps)))
-                i++;
-            tag_trig = i;
-        }
+        bounds(spos);
         if (waiting)
             return EV_PARK; // (the bound is re-armed when the chunk lands)
-        const int chunk_lim = more ? (loaded_s - 8 - jump_margin + MSK_OFF - (spos - iidx) + 1) : 0x7fffffff;
-        fast_lim = ninp < tag_trig ? ninp : tag_trig;
-        fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
         return EV_GO;
     };
 
@@ -561,19 +571,23 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             // with `room` items below its bound is good for room / pair_adv pairs (see pair_adv); the wave
             // takes what the slowest lane can do (at most MSK_PAIRS_MAX: one chunk's worth, the
             // next chunk is then due).  The trips run with no test at all.
-            const long long room = (long long)fast_lim - (long long)iidx - (long long)pair_margin;
-            int can = room <= 0 ? 0 : (room >= 1000000 ? MSK_PAIRS_MAX : (int)((float)room * pair_adv_inv));
+            // (fast_lim may be INT_MIN = "unknown" or INT_MAX = "no bound": no overflow either way)
+            const int room = fast_lim > iidx ? fast_lim - iidx - pair_margin : 0;
+            int can = (int)((float)room * pair_adv_inv);
+            can = can < MSK_PAIRS_MAX ? can : MSK_PAIRS_MAX;
             const int ocan = OSPS2 ? (noutput - oidx) / 2 : (noutput - oidx) - 1;
             can = can < ocan ? can : ocan;
             if (!lock_ok || !(d_mu >= 0.f && d_mu <= 1.f)) // (the loop below takes mu in [0, 1] for granted)
                 can = 0;
-            can = can < MSK_PAIRS_MAX ? can : MSK_PAIRS_MAX;
-            int npairs = MSK_PAIRS_MAX; // = min over the lanes of `can`
-            if (cx.ballot(can >= MSK_PAIRS_MAX) != ALL) {
-                npairs = 0;
-                for (int bit = MSK_PAIRS_MAX / 2; bit; bit >>= 1)
-                    if (cx.ballot(can >= npairs + bit) == ALL)
-                        npairs += bit;
+            int npairs = 0; // = min over the lanes of `can`
+            if (cx.ballot(can >= 1) == ALL) { // (the usual way out near an event: one ballot)
+                npairs = MSK_PAIRS_MAX;
+                if (cx.ballot(can >= MSK_PAIRS_MAX) != ALL) {
+                    npairs = 1;
+                    for (int bit = MSK_PAIRS_MAX / 2; bit; bit >>= 1)
+                        if (npairs + bit < MSK_PAIRS_MAX && cx.ballot(can >= npairs + bit) == ALL)
+                            npairs += bit;
+                }
             }
             if (npairs > 0) {
                 const int sb_entry = sb;
@@ -763,7 +777,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     p.status[c] = status;
 }
 
-// Tag prepass: one lane per channel merges the tags carried over from the previous call with
+// Tag prepass: one wave per channel merges the tags carried over from the previous call with
 // this call's, keeps the time_est ones at or after nitems_read (:125-130 asks for that key
 // only) and writes them as msk_ctag.  Runs before msk_body on the same stream.
 struct TagPrepParams {
@@ -777,28 +791,35 @@ struct TagPrepParams {
 template <class Ctx>
 AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
 {
-    const int c = cx.bx() * cx.nthreads() + cx.tid();
+    // one wave per channel: 64 records per step, coalesced; ballot + popcount compaction
+    // keeps the list order
+    const int l = cx.tid() & 63;
+    const int c = cx.bx() * (cx.nthreads() >> 6) + (cx.tid() >> 6);
     if (c >= p.nchan)
         return;
     const unsigned long long R = p.nread[c];
     msk_ctag* out = p.ct + (long)c * p.ct_cap;
-    int w = 0;
+    int w = 0; // wave-uniform
     auto scan = [&](const tag_rec* list, int n) {
-        for (int k0 = 0; k0 < n; k0 += 8) {
-            tag_rec t[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                t[j] = list[k0 + j < n ? k0 + j : n - 1]; // eight loads in flight
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (k0 + j < n && t[j].key == KEY_TIME_EST && t[j].offset >= R && w < p.ct_cap) {
-                    const unsigned long long d = t[j].offset - R;
-                    msk_ctag e;
-                    e.rel = d > 0x7ffffff0ull ? 0x7ffffff0 : (int)d;
-                    e.val = (float)t[j].value;
-                    out[w++] = e;
-                }
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + l;
+            tag_rec t;
+            t.offset = 0;
+            t.value = 0;
+            t.key = -1;
+            if (k < n)
+                t = list[k];
+            const bool keep = (k < n) && t.key == KEY_TIME_EST && t.offset >= R;
+            const unsigned long long m = cx.ballot(keep);
+            const int pos = w + aisx_popc64(m & ((1ull << l) - 1ull));
+            if (keep && pos < p.ct_cap) {
+                const unsigned long long d = t.offset - R;
+                msk_ctag e;
+                e.rel = d > 0x7ffffff0ull ? 0x7ffffff0 : (int)d;
+                e.val = (float)t.value;
+                out[pos] = e;
             }
+            w += aisx_popc64(m);
         }
     };
     int nc = p.ctag_n_in[c];
@@ -811,7 +832,8 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
             nn = p.tag_cap;
         scan(p.tags + (long)c * p.tag_cap, nn);
     }
-    p.ct_n[c] = w;
+    if (l == 0)
+        p.ct_n[c] = w < p.ct_cap ? w : p.ct_cap;
 }
 
 // Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)

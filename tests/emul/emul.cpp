@@ -329,7 +329,7 @@ static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_count
     t.tags = tags; t.tag_count = tag_counts; t.tag_cap = tag_cap;
     t.nread = h->nread.data();
     t.ct = h->ct.data(); t.ct_n = h->ct_n.data(); t.ct_cap = h->ct_cap;
-    run_grid((h->nchan + 63) / 64, 1, 64, 64, [&](EmuCtx& cx) { tagprep_body(cx, t); });
+    run_grid((h->nchan + 3) / 4, 1, 256, 64, [&](EmuCtx& cx) { tagprep_body(cx, t); });
 }
 
 static void emu_msk_bittail(EmuMsk* h, const cf* syms, long sym_stride, const int* produced, unsigned char* bits,
