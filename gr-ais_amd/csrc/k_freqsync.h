@@ -254,6 +254,21 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
     const int total = p.nvec * FS_F;
     const int nchunks = total / FSM_CH;
     // software pipeline: wave 0 produces the phases of chunk k while waves 1..7 mix chunk k-1
+    cf nxt[FSM_UPW];
+#pragma unroll
+    for (int q = 0; q < FSM_UPW; q++)
+        nxt[q] = mk(0.f, 0.f);
+    auto fetch = [&](long k0) {
+#pragma unroll
+        for (int q = 0; q < FSM_UPW; q++) {
+            const int u = (wave - 1) + FSM_MIXW * q;
+            const int r = u % FSM_CPW, c = cbase + r;
+            const long idx = k0 + (u / FSM_CPW) * 64 + l;
+            nxt[q] = mk(0.f, 0.f);
+            if (u < FSM_UNITS && c < p.nchan)
+                nxt[q] = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
+        }
+    };
     for (int k = 0; k <= nchunks; k++) {
         if (wave == 0) {
             if (mylive && k < nchunks) {
@@ -286,28 +301,28 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
                     }
                 }
             }
-        } else if (k > 0) {
-            const long k0 = (long)(k - 1) * FSM_CH;
-            const float* src = PH + ((k - 1) & 1) * FSM_CPW * FSM_PITCH;
-            cf s[FSM_UPW];
+        } else {
+            // the items of chunk k are fetched now and mixed in the next trip (their latency
+            // hides behind this trip's sin/cos and the barrier)
+            cf cur[FSM_UPW];
 #pragma unroll
-            for (int q = 0; q < FSM_UPW; q++) {
-                const int u = (wave - 1) + FSM_MIXW * q;
-                const int r = u % FSM_CPW, c = cbase + r;
-                const long idx = k0 + (u / FSM_CPW) * 64 + l;
-                s[q] = mk(0.f, 0.f);
-                if (u < FSM_UNITS && c < p.nchan)
-                    s[q] = (idx < p.npend) ? p.pend_in[(long)c * FS_F + idx] : p.in[(long)c * p.in_stride + idx - p.npend];
-            }
+            for (int q = 0; q < FSM_UPW; q++)
+                cur[q] = nxt[q];
+            if (k < nchunks)
+                fetch((long)k * FSM_CH);
+            if (k > 0) {
+                const long k0 = (long)(k - 1) * FSM_CH;
+                const float* src = PH + ((k - 1) & 1) * FSM_CPW * FSM_PITCH;
 #pragma unroll
-            for (int q = 0; q < FSM_UPW; q++) {
-                const int u = (wave - 1) + FSM_MIXW * q;
-                const int r = u % FSM_CPW, c = cbase + r;
-                const int h = u / FSM_CPW;
-                if (u < FSM_UNITS && c < p.nchan) {
-                    float sn, cs;
-                    det_sincos(src[r * FSM_PITCH + h * 64 + l], &sn, &cs);
-                    p.out[(long)c * p.out_stride + k0 + h * 64 + l] = cmul_exact(s[q], mk(cs, sn));
+                for (int q = 0; q < FSM_UPW; q++) {
+                    const int u = (wave - 1) + FSM_MIXW * q;
+                    const int r = u % FSM_CPW, c = cbase + r;
+                    const int h = u / FSM_CPW;
+                    if (u < FSM_UNITS && c < p.nchan) {
+                        float sn, cs;
+                        det_sincos(src[r * FSM_PITCH + h * 64 + l], &sn, &cs);
+                        p.out[(long)c * p.out_stride + k0 + h * 64 + l] = cmul_exact(cur[q], mk(cs, sn));
+                    }
                 }
             }
         }
