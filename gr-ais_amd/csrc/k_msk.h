@@ -494,6 +494,14 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         d_mu = d_mu - fl;
     };
 
+#ifdef MSK_PROF
+    long long pf_t0 = __builtin_readcyclecounter(), pf_lock = 0, pf_land = 0, pf_gen = 0, pf_n[4] = {0, 0, 0, 0}, pf_fail = 0, pf_nfail = 0;
+#define PF_BEGIN long long pf_a = __builtin_readcyclecounter();
+#define PF_END(acc) acc += __builtin_readcyclecounter() - pf_a;
+#else
+#define PF_BEGIN
+#define PF_END(acc)
+#endif
     u64 P = 0; // parked lanes: nothing more to do before the next chunk lands (or ever)
     u64 E = 0; // lanes whose next iteration has d_div even
     // oidx < noutput was checked on the odd step before an even one and cannot have changed
@@ -509,6 +517,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         u64 goM = mine & okM;
         const u64 evM = mine & ~okM;
         if (evM != 0ull) {
+#ifdef MSK_PROF
+            pf_n[3]++;
+#endif
             int code = -1;
             if (cx.inv_ballot(evM))
                 code = events(PAR);
@@ -524,14 +535,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
 
     const u64 ALL = cx.ballot(true);
-#ifdef MSK_PROF
-    long long pf_t0 = __builtin_readcyclecounter(), pf_lock = 0, pf_land = 0, pf_gen = 0, pf_n[4] = {0, 0, 0, 0};
-#define PF_BEGIN long long pf_a = __builtin_readcyclecounter();
-#define PF_END(acc) acc += __builtin_readcyclecounter() - pf_a;
-#else
-#define PF_BEGIN
-#define PF_END(acc)
-#endif
+
     // Bounds for the check-free pair loop.  iidx after any number of iterations is iidx0 +
     // (mu0 + the sum of the omega and gain * err terms) - (the current mu), and mu stays in
     // [0, 1]: the fraction carries over, so a run of c pairs moves iidx by less than
@@ -589,6 +593,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                             npairs += bit;
                 }
             }
+#ifdef MSK_PROF
+            if (npairs == 0) { pf_fail += __builtin_readcyclecounter() - pf_a; pf_nfail++; }
+#endif
             if (npairs > 0) {
                 const int sb_entry = sb;
                 cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
@@ -704,7 +711,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #ifdef MSK_PROF
     if (c == 0) {
         long long pf_t1 = __builtin_readcyclecounter();
-        printf("msk prof: total %lld lock %lld land %lld gen %lld | pairs %lld runs %lld genpasses %lld\n", pf_t1 - pf_t0, pf_lock, pf_land, pf_gen, pf_n[0], pf_n[1], pf_n[2]);
+        printf("msk prof: total %lld lock %lld (failed entries %lld: %lld) land %lld gen %lld | pairs %lld runs %lld genpasses %lld events %lld\n", pf_t1 - pf_t0, pf_lock, pf_nfail, pf_fail, pf_land, pf_gen, pf_n[0], pf_n[1], pf_n[2], pf_n[3]);
     }
 #endif
     if (!live)
