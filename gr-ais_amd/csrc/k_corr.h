@@ -140,30 +140,57 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
 
     ldsT[t] = p.wtab[(16 * (t >> 3) * (t & 7)) & (CF_F - 1)];
     cx.sync();
+    // value n1 of this thread is window item i = t + 128 n1; in an interior tile it is a
+    // correlation output iff i >= N (i < F = N + L always)
+    unsigned vmask_int = 0;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++)
+        if (t + CF_T * n1 >= N)
+            vmask_int |= 1u << n1;
 
     for (int tile = 0; tile < p.tiles_per_seg; tile++) {
         const int k0 = (seg * p.tiles_per_seg + tile) * L;
         if (k0 >= n)
             break;
         cf x[16], v[2][8];
-        // window w[i] = stream[k0 - N + i]; stream index < 0 comes from the history
+        // a tile whose whole window and all L outputs lie inside this call's items (all but the
+        // first and the last of a channel): no per-element bounds tests, the few that remain
+        // (i < L, i >= N) are decided per 128-element slice in scalar code
+        const bool interior = (k0 - N >= 0) && (k0 + L <= n);
+        if (interior) {
+            const cf* w = xin + (k0 - N);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) {
-            const int i = t + CF_T * n1;
-            const int s = k0 - N + i;
-            cf val = mk(0.f, 0.f);
-            if (s < 0)
-                val = hist[N + s];
-            else if (s < n)
-                val = xin[s];
-            x[n1] = val;
-        }
-        // A2: out[k0 + i] = stream[k0 + i - N] = w[i]   (lib/corr_est_cc_impl.cc:184)
+            for (int n1 = 0; n1 < 16; n1++)
+                x[n1] = (w + CF_T * n1)[(unsigned)t]; // uniform base + 32-bit lane offset
+            // A2: out[k0 + i] = stream[k0 + i - N] = w[i]   (lib/corr_est_cc_impl.cc:184)
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) {
-            const int i = t + CF_T * n1;
-            if (i < L && k0 + i < n)
-                xout[k0 + i] = x[n1];
+            for (int n1 = 0; n1 < 16; n1++) {
+                const int lo = CF_T * n1;
+                cf* on = xout + (k0 + lo);
+                if (lo + CF_T <= L)
+                    on[(unsigned)t] = x[n1];
+                else if (lo < L && lo + t < L)
+                    on[(unsigned)t] = x[n1];
+            }
+        } else {
+            // window w[i] = stream[k0 - N + i]; stream index < 0 comes from the history
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const int i = t + CF_T * n1;
+                const int s = k0 - N + i;
+                cf val = mk(0.f, 0.f);
+                if (s < 0)
+                    val = hist[N + s];
+                else if (s < n)
+                    val = xin[s];
+                x[n1] = val;
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const int i = t + CF_T * n1;
+                if (i < L && k0 + i < n)
+                    xout[k0 + i] = x[n1];
+            }
         }
         cf_forward(cx, x, p.wtab, ldsX, ldsT, v);
         // spectrum x H, inverse radix-8
@@ -203,20 +230,41 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
             x[k1] = (k1 == 0) ? a : cmul_conj_fma(a, p.wtab[k1 * t]);
         }
         dft16<true>(x);
-        // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197)
+        // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197).  Which of the
+        // thread's 16 values are correlation outputs is a 16-bit mask (constant over interior
+        // tiles); the threshold test adds to a hit mask without branching; only a wave with a
+        // hit (rare) walks its bits.
+        unsigned vmask = vmask_int;
+        if (!interior) {
+            vmask = 0;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const int m = t + CF_T * n1 - N;
+                if (m >= 0 && m < L && k0 + m < n)
+                    vmask |= 1u << n1;
+            }
+        }
+        const int kb = k0 + t - N; // output index of value n1: kb + 128 n1
+        if (p.dense_corr) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++)
+                if ((vmask >> n1) & 1u)
+                    xcorr[kb + CF_T * n1] = x[n1];
+        }
+        unsigned hit = 0;
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) {
-            const int i = t + CF_T * n1;
-            const int m = i - N;
-            const int k = k0 + m;
-            if (m >= 0 && m < L && k < n) {
-                const cf y = x[n1];
-                if (p.dense_corr)
-                    xcorr[k] = y;
-                const float mg = mag2(y);
-                if (!(mg <= p.thresh)) {
+            const float mg = mag2(x[n1]);
+            hit |= (!(mg <= p.thresh)) ? (1u << n1) : 0u;
+        }
+        hit &= vmask;
+        if (cx.ballot(hit != 0u) != 0ull) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                if ((hit >> n1) & 1u) {
+                    const int k = kb + CF_T * n1;
                     if (!p.dense_corr)
-                        xcorr[k] = y;
+                        xcorr[k] = x[n1];
                     cx.atomic_or64(&abits[k >> 6], 1ull << (k & 63));
                 }
             }
