@@ -3,6 +3,7 @@
 // atomics.  (tests/emul has the CPU model of the same interface.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "aisx_common.h"
 
 namespace aisx {
 
@@ -20,6 +21,60 @@ struct DevCtx {
     __device__ __forceinline__ unsigned long long ballot(bool p) const { return __builtin_amdgcn_ballot_w64(p); }
     // per-lane predicate from a wave-uniform mask (the mask goes straight into exec / vcc)
     __device__ __forceinline__ bool inv_ballot(unsigned long long m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    // complex primitives of the FFT butterflies (k_fft.h): one packed-fp32 instruction each,
+    // the +-j rotation done by the operand-select / negate modifiers
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ v2f tov(cf a) { v2f r; r.x = a.re; r.y = a.im; return r; }
+    static __device__ __forceinline__ cf tocf(v2f a) { return mk(a.x, a.y); }
+    __device__ __forceinline__ cf cadd(cf a, cf b) const { return tocf(tov(a) + tov(b)); }
+    __device__ __forceinline__ cf csub(cf a, cf b) const { return tocf(tov(a) - tov(b)); }
+    __device__ __forceinline__ cf add_mj(cf a, cf b) const // a - j b = (a.re + b.im, a.im - b.re)
+    {
+        v2f r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+        return tocf(r);
+    }
+    __device__ __forceinline__ cf add_pj(cf a, cf b) const // a + j b = (a.re - b.im, a.im + b.re)
+    {
+        v2f r;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+        return tocf(r);
+    }
+    // a (c + j s) with c = +-K[CS], s = +-K[SS]; K = 0: (cos(pi/8), sin(pi/8)), 1: (sqrt(1/2), sqrt(1/2)),
+    // each living in one scalar register pair for the whole kernel
+    template <int KSEL, int CS, bool CNEG, int SS, bool SNEG>
+    __device__ __forceinline__ cf cmul_sel(cf a) const
+    {
+        v2f k;
+        if (KSEL == 0) {
+            k.x = 0.92387953251128673848f;
+            k.y = 0.38268343236508978178f;
+        } else {
+            k.x = 0.70710678118654752440f;
+            k.y = 0.70710678118654752440f;
+        }
+        v2f m, r;
+        const v2f av = tov(a);
+        // m = (a.re c, a.im c)
+        if (CS == 0 && !CNEG)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(m) : "v"(av), "s"(k));
+        else if (CS == 0 && CNEG)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(av), "s"(k));
+        else if (CS == 1 && !CNEG)
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(m) : "v"(av), "s"(k));
+        else
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(av), "s"(k));
+        // r = (-a.im s + m.re, a.re s + m.im)
+        if (SS == 0 && !SNEG)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
+        else if (SS == 0 && SNEG)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
+        else if (SS == 1 && !SNEG)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
+        else
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
+        return tocf(r);
+    }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // scheduling fences: the value is materialised here, in program order with the other pins
@@ -42,6 +97,25 @@ struct DevCtx {
     __device__ __forceinline__ int readlane_i32(int v, int lane) const { return __builtin_amdgcn_readlane(v, lane); }
     __device__ __forceinline__ int ctz64(unsigned long long v) const { return __ffsll((long long)v) - 1; }
     __device__ __forceinline__ void atomic_or64(unsigned long long* p, unsigned long long v) const { atomicOr(p, v); }
+};
+
+// The same context with the butterfly primitives left to the compiler (plain C++ complex
+// arithmetic).  The F = 2048 correlator is bound by the latency of its L2 twiddle / spectrum
+// reads at 3 waves per SIMD, not by VALU issue, and schedules better without opaque
+// instructions in the way (measured: 1.20 ms against 1.37 ms per launch).
+struct DevCtxC : DevCtx {
+    __device__ __forceinline__ cf cadd(cf a, cf b) const { return mk(a.re + b.re, a.im + b.im); }
+    __device__ __forceinline__ cf csub(cf a, cf b) const { return mk(a.re - b.re, a.im - b.im); }
+    __device__ __forceinline__ cf add_mj(cf a, cf b) const { return mk(a.re + b.im, a.im - b.re); }
+    __device__ __forceinline__ cf add_pj(cf a, cf b) const { return mk(a.re - b.im, a.im + b.re); }
+    template <int KSEL, int CS, bool CNEG, int SS, bool SNEG>
+    __device__ __forceinline__ cf cmul_sel(cf a) const
+    {
+        const float k0 = KSEL == 0 ? 0.92387953251128673848f : 0.70710678118654752440f;
+        const float k1 = KSEL == 0 ? 0.38268343236508978178f : 0.70710678118654752440f;
+        const float c = CNEG ? -(CS ? k1 : k0) : (CS ? k1 : k0), s = SNEG ? -(SS ? k1 : k0) : (SS ? k1 : k0);
+        return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
+    }
 };
 
 } // namespace aisx

@@ -46,14 +46,14 @@ extern "C" int aisx_set_device(int device)
 __global__ __launch_bounds__(CF_T) void k_corr_inith(CorrInitParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevCtx cx{ smem };
+    DevCtxC cx{ { smem } };
     corr_inith_body(cx, p);
 }
 
 __global__ __launch_bounds__(CF_T, 3) void k_corr_main(CorrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevCtx cx{ smem };
+    DevCtxC cx{ { smem } };
     corr_main_body(cx, p);
 }
 

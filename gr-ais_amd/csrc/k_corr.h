@@ -56,7 +56,7 @@ template <class Ctx>
 AISX_DI void cf_forward(Ctx& cx, cf (&x)[16], const cf* wtab, cf* ldsX, const cf* ldsT, cf (&v)[2][8])
 {
     const int t = cx.tid();
-    dft16<false>(x);
+    dft16<false>(cx, x);
     // W_2048^{k1*t}: gathered from the 16 KB table (L1/L2 resident) where it is used --
     // holding the 15 values in VGPRs across the tile loop costs a wave of occupancy
 #pragma unroll
@@ -71,7 +71,7 @@ AISX_DI void cf_forward(Ctx& cx, cf (&x)[16], const cf* wtab, cf* ldsX, const cf
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++)
             x[n2] = ldsX[cf_pos(k1, n2 * 8 + n3)];
-        dft16<false>(x);
+        dft16<false>(cx, x);
 #pragma unroll
         for (int k2 = 1; k2 < 16; k2++)
             x[k2] = cmul_fma(x[k2], ldsT[k2 * 8 + n3]);
@@ -90,7 +90,7 @@ AISX_DI void cf_forward(Ctx& cx, cf (&x)[16], const cf* wtab, cf* ldsX, const cf
             v[h][2 * pr] = ldsX[ch];
             v[h][2 * pr + 1] = ldsX[ch + 1];
         }
-        dft8<false>(v[h]);
+        dft8<false>(cx, v[h]);
     }
 }
 
@@ -202,7 +202,7 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
 #pragma unroll
             for (int k3 = 0; k3 < 8; k3++)
                 v[h][k3] = cmul_fma(v[h][k3], Hq[k3]);
-            dft8<true>(v[h]);
+            dft8<true>(cx, v[h]);
 #pragma unroll
             for (int pr = 0; pr < 4; pr++) {
                 const int ch = base + 2 * (pr ^ swz);
@@ -218,7 +218,7 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
                 cf a = ldsX[cf_pos(k1, k2 * 8 + n3)];
                 x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, ldsT[k2 * 8 + n3]);
             }
-            dft16<true>(x);
+            dft16<true>(cx, x);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++)
                 ldsX[cf_pos(k1, n2 * 8 + n3)] = x[n2];
@@ -229,7 +229,7 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
             cf a = ldsX[cf_pos(k1, t)];
             x[k1] = (k1 == 0) ? a : cmul_conj_fma(a, p.wtab[k1 * t]);
         }
-        dft16<true>(x);
+        dft16<true>(cx, x);
         // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197).  Which of the
         // thread's 16 values are correlation outputs is a 16-bit mask (constant over interior
         // tiles); the threshold test adds to a hit mask without branching; only a wave with a

@@ -69,7 +69,7 @@ template <class Ctx>
 AISX_DI void cf4_forward(Ctx& cx, cf (&x)[16], const cf (&wp)[4], cf* ldsX, const cf* ldsT)
 {
     const int t = cx.tid();
-    dft16<false>(x);
+    dft16<false>(cx, x);
     cf4_pow_twiddles<false>(x, wp); // W_4096^{k1*t}
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++)
@@ -80,7 +80,7 @@ AISX_DI void cf4_forward(Ctx& cx, cf (&x)[16], const cf (&wp)[4], cf* ldsX, cons
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++)
             x[n2] = ldsX[cf4_pos(k1, n2 * 16 + n3)];
-        dft16<false>(x);
+        dft16<false>(cx, x);
 #pragma unroll
         for (int k2 = 1; k2 < 16; k2++)
             x[k2] = cmul_fma(x[k2], ldsT[k2 * 16 + n3]); // W_256^{k2*n3}
@@ -98,7 +98,7 @@ AISX_DI void cf4_forward(Ctx& cx, cf (&x)[16], const cf (&wp)[4], cf* ldsX, cons
             x[2 * pr] = ldsX[ch];
             x[2 * pr + 1] = ldsX[ch + 1];
         }
-        dft16<false>(x);
+        dft16<false>(cx, x);
     }
 }
 
@@ -214,7 +214,7 @@ AISX_DI void corr4_main_body(Ctx& cx, const CorrParams& p)
 #pragma unroll
             for (int k3 = 0; k3 < 16; k3++)
                 x[k3] = cmul_fma(x[k3], Hq[k3]);
-            dft16<true>(x);
+            dft16<true>(cx, x);
 #pragma unroll
             for (int pr = 0; pr < 8; pr++) {
                 const int ch = base + 2 * (pr ^ swz);
@@ -230,7 +230,7 @@ AISX_DI void corr4_main_body(Ctx& cx, const CorrParams& p)
                 cf a = ldsX[cf4_pos(k1, k2 * 16 + n3)];
                 x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, ldsT[k2 * 16 + n3]);
             }
-            dft16<true>(x);
+            dft16<true>(cx, x);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++)
                 ldsX[cf4_pos(k1, n2 * 16 + n3)] = x[n2];
@@ -240,7 +240,7 @@ AISX_DI void corr4_main_body(Ctx& cx, const CorrParams& p)
         for (int k1 = 0; k1 < 16; k1++)
             x[k1] = ldsX[cf4_pos(k1, t)];
         cf4_pow_twiddles<true>(x, wp);
-        dft16<true>(x);
+        dft16<true>(cx, x);
         // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197).  Which of the
         // thread's 16 values are correlation outputs is a 16-bit mask (constant over interior
         // tiles); the threshold test adds to a hit mask without branching; only a wave with a

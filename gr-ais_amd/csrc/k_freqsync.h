@@ -69,7 +69,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
         }
         x[n1] = cmul_exact(s, s); // multiply_cc of the stream with itself
     }
-    dft16<false>(x);
+    dft16<false>(cx, x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++)
         x[k1] = cmul_fma(x[k1], tw1[k1]);
@@ -82,7 +82,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++)
             x[n2] = X[k1 * FS_ROW + n2 * 4 + n3];
-        dft16<false>(x);
+        dft16<false>(cx, x);
 #pragma unroll
         for (int k2 = 1; k2 < 16; k2++)
             x[k2] = cmul_fma(x[k2], T2[k2 * 4 + n3]);
@@ -98,7 +98,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
         const int q = l + 64 * h, k1 = q >> 4, k2 = q & 15;
         cf y0 = X[k1 * FS_ROW + k2 * 4 + 0], y1 = X[k1 * FS_ROW + k2 * 4 + 1];
         cf y2 = X[k1 * FS_ROW + k2 * 4 + 2], y3 = X[k1 * FS_ROW + k2 * 4 + 3];
-        dft4<false>(y0, y1, y2, y3);
+        dft4<false>(cx, y0, y1, y2, y3);
         const int kb = k1 + 16 * k2; // frequency index k = kb + 256*k3
         a[4 * h + 0] = cabs_f(y0);
         a[4 * h + 1] = cabs_f(y1);

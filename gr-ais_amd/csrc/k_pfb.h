@@ -66,7 +66,7 @@ AISX_DI void pfb_body(Ctx& cx, const PfbParams& p)
         x[n1] = mk(ar, ai);
     }
     // inverse 1024-point DFT across the branches (e^{+j}): DIF, 16 x 16 x 4
-    dft16<true>(x);
+    dft16<true>(cx, x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++)
         x[k1] = cmul_conj_fma(x[k1], p.wtab[(k1 * l) & (PFB_M - 1)]);
@@ -79,7 +79,7 @@ AISX_DI void pfb_body(Ctx& cx, const PfbParams& p)
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++)
             x[n2] = X[k1 * PFB_ROW + n2 * 4 + n3];
-        dft16<true>(x);
+        dft16<true>(cx, x);
 #pragma unroll
         for (int k2 = 1; k2 < 16; k2++)
             x[k2] = cmul_conj_fma(x[k2], T2[k2 * 4 + n3]);
@@ -94,7 +94,7 @@ AISX_DI void pfb_body(Ctx& cx, const PfbParams& p)
         const int q = l + 64 * h, k1 = q >> 4, k2 = q & 15;
         cf y0 = X[k1 * PFB_ROW + k2 * 4 + 0], y1 = X[k1 * PFB_ROW + k2 * 4 + 1];
         cf y2 = X[k1 * PFB_ROW + k2 * 4 + 2], y3 = X[k1 * PFB_ROW + k2 * 4 + 3];
-        dft4<true>(y0, y1, y2, y3);
+        dft4<true>(cx, y0, y1, y2, y3);
         const int mb = k1 + 16 * k2; // lane m = mb + 256*k3
         cf ys[4] = { y0, y1, y2, y3 };
 #pragma unroll

@@ -76,6 +76,19 @@ struct EmuCtx {
         return m;
     }
     float fract(float x) const { return x - floorf(x); }
+    // complex primitives of the FFT butterflies: the arithmetic of the packed instructions
+    cf cadd(cf a, cf b) const { return mk(a.re + b.re, a.im + b.im); }
+    cf csub(cf a, cf b) const { return mk(a.re - b.re, a.im - b.im); }
+    cf add_mj(cf a, cf b) const { return mk(a.re + b.im, a.im - b.re); }
+    cf add_pj(cf a, cf b) const { return mk(a.re - b.im, a.im + b.re); }
+    template <int KSEL, int CS, bool CNEG, int SS, bool SNEG>
+    cf cmul_sel(cf a) const
+    {
+        const float K[2][2] = { { 0.92387953251128673848f, 0.38268343236508978178f },
+                                { 0.70710678118654752440f, 0.70710678118654752440f } };
+        const float c = CNEG ? -K[KSEL][CS] : K[KSEL][CS], s = SNEG ? -K[KSEL][SS] : K[KSEL][SS];
+        return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
+    }
     void pin(float&) const {}
     void pin(int&) const {}
     void pin_mask(unsigned long long&) const {}
