@@ -15,6 +15,9 @@ struct DevCtx {
     __device__ __forceinline__ int by() const { return blockIdx.y; }
     __device__ __forceinline__ char* lds() const { return lds_; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // lanes of a wave run in lock step and LDS operations of a wave complete in order: nothing
+    // to do (the CPU lane model needs a real barrier here)
+    __device__ __forceinline__ void wave_sync() const { __builtin_amdgcn_wave_barrier(); }
     // a lane that leaves the kernel for good before its workgroup's barriers (nothing to do
     // on the device: the hardware counts waves, not lanes)
     __device__ __forceinline__ void retire() const {}

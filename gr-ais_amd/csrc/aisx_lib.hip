@@ -787,6 +787,9 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.mmse = h->d_mmse;
     p.lds_tab_off = MSK_LDS_TABOFF;
     p.lpw = h->lpw;
+    p.lds_wave_stride = msk_lds_wave(h->lpw);
+    p.tq_stride = h->lpw;
+    p.tq_private = 0;
 }
 
 // compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows

@@ -89,6 +89,12 @@ struct MskParams {
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
     int lds_tab_off;   // = MSK_LDS_TABOFF
+    // LDS bytes between the regions of consecutive waves, tag-queue entries between consecutive
+    // queue slots, and whether every lane has a queue column of its own.  On the device the NQ
+    // lanes of a channel share one column (they run in lock step and write the same values:
+    // stride msk_lds_wave(lpw), lpw, 0); the CPU lane model, whose lanes are free-running
+    // threads, gives each lane its own (stride msk_lds_ring(lpw) + MSK_TAGQ * 64 * 8, 64, 1).
+    int lds_wave_stride, tq_stride, tq_private;
     int lpw;           // channels (active lanes) per wave, = the build's LPW: 16, 32 or 64
 };
 
@@ -127,18 +133,23 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // other lanes stall a lane less, LDS returns fewer bytes per instruction, a chunk load
     // touches fewer lines -- and the 64 channels still sit on one CU, leaving the others alone.
     static_assert(64 % LPW == 0, "whole waves");
-    const int wv = cx.tid() >> 6, l = cx.tid() & 63;
-    if (l >= LPW) {
-        cx.retire();
-        return;
-    }
+    // All 64 lanes stay: lane i runs the channel of lane i % LPW (identical arithmetic, identical
+    // stores to identical addresses -- a wave64 instruction costs the same with 16 or 64 lanes
+    // enabled), and when a chunk is fetched and landed lane i handles share i / LPW of it, so a
+    // chunk costs 64 / LPW times fewer instructions than with LPW lanes at work.
+    constexpr int NQ = 64 / LPW;          // lanes per channel = shares of a chunk
+    constexpr int QS = MSK_CHUNK / NQ;    // samples of a chunk per lane
+    const int wv = cx.tid() >> 6;
+    const int l = cx.tid() & (LPW - 1);   // the channel (ring column, tag queue column) of this lane
+    const int q = (cx.tid() & 63) / LPW;  // its share of a chunk
+    const bool owner = q == 0;            // the lane that writes the channel's state back
     const int cbase = cx.bx() * 64 + wv * LPW;
     const int c = cbase + l;
     const bool live = c < p.nchan;
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
     char* const lds0 = cx.lds();
-    char* const lds = lds0 + wv * msk_lds_wave(LPW); // this wave's rings [MSK_SLOTS][LPW] and tag queue
+    char* const lds = lds0 + wv * p.lds_wave_stride; // this wave's rings [MSK_SLOTS][LPW] and tag queue
     cf* ring = (cf*)lds;
     // [130][MSK_TAPS_PITCH], one per workgroup, behind the waves' regions; the offset comes in
     // as a kernel argument so that it sits in a scalar register and a row address is one
@@ -149,7 +160,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     for (int i = wv * LPW + l; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
     if (wv == 0 && l < MSK_TAPS_PITCH)
-        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f;
+        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f; // (written by the NQ lanes of a channel alike)
     if (cbase >= p.nchan) { // a wave with no channel at all (ragged last workgroup)
         cx.sync();
         return;
@@ -191,14 +202,15 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // MSK_TAGQ entries per lane, entry k of lane l at tq[k * LPW + l]; a longer list is queued
     // in instalments.
     typedef msk_ctag tq_ent;
-    tq_ent* const tq = (tq_ent*)(lds + msk_lds_ring(LPW)) + l;
+    tq_ent* const tq = (tq_ent*)(lds + msk_lds_ring(LPW)) + (p.tq_private ? (cx.tid() & 63) : l);
+    const int TQS = p.tq_stride;
     const int TQ_NONE = 0x7fffffff;
     int gq = 0;            // tags of the list looked at so far
     int qhead = 0, qn = 0; // queue: entries [0, qn), front at qhead
     auto tq_fill = [&]() {
         // (keeps the entry popped last: its offset may still be >= nitems_read at the end)
         if (qn > 0) {
-            tq[0] = tq[(qn - 1) * LPW];
+            tq[0] = tq[(qn - 1) * TQS];
             qn = 1;
         }
         qhead = qn;
@@ -211,7 +223,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             for (int j = 0; j < 4; j++) {
                 if (qn < MSK_TAGQ && gq < ntot) {
                     gq++;
-                    tq[qn * LPW] = t[j];
+                    tq[qn * TQS] = t[j];
                     qn++;
                 }
             }
@@ -225,7 +237,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (qhead >= qn && gq < ntot)
             tq_fill();
         if (qhead < qn) {
-            const tq_ent e = tq[qhead * LPW];
+            const tq_ent e = tq[qhead * TQS];
             fr_rel = e.rel;
             nt_val = e.val;
         } else {
@@ -295,21 +307,21 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int nchunks = (n + 8 + MSK_CHUNK - 1) / MSK_CHUNK;
     // chunk fetch: lane l walks its own channel row (64 samples = 512 contiguous bytes per
     // lane and chunk; the 16 lines involved stay in L1 across the 32 load instructions)
-    cf r[MSK_CHUNK];
+    cf r[QS]; // this lane's share of the chunk in flight
     const cf* myin = p.in + (long)cc * p.in_stride;
     auto issue_chunk = [&](int t) {
-        const int s0 = t * MSK_CHUNK;
-        if (s0 + MSK_CHUNK <= n) { // whole chunk inside the input: 16-byte loads, no predicates
+        const int s0 = t * MSK_CHUNK + q * QS;
+        if (t * MSK_CHUNK + MSK_CHUNK <= n) { // whole chunk inside the input: 16-byte loads, no predicates
             const cf_pair* src = (const cf_pair*)(myin + s0); // (dead lanes re-read the last channel's row)
 #pragma unroll
-            for (int k = 0; k < MSK_CHUNK / 2; k++) {
+            for (int k = 0; k < QS / 2; k++) {
                 const cf_pair v = src[k];
                 r[2 * k] = v.a;
                 r[2 * k + 1] = v.b;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < MSK_CHUNK; k++) {
+            for (int k = 0; k < QS; k++) {
                 r[k] = mk(0.f, 0.f);
                 if (s0 + k < n)
                     r[k] = myin[s0 + k];
@@ -319,9 +331,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     auto land_chunk = [&](int t) {
         const int slot0 = (t * MSK_CHUNK + MSK_OFF) & (MSK_RING - 1); // multiple of 64
 #pragma unroll
-        for (int k = 0; k < MSK_CHUNK; k++)
-            myring[(slot0 + k) * LPW] = r[k];
-        if (slot0 == 0) { // mirror the first 8 slots behind slot 255
+        for (int k = 0; k < QS; k++)
+            myring[(slot0 + q * QS + k) * LPW] = r[k];
+        if (slot0 == 0 && q == 0) { // mirror the first 8 slots behind slot 255
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 myring[(MSK_RING + k) * LPW] = r[k];
@@ -679,7 +691,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #ifdef MSK_EMU_STATS
                 if (l == 0) msk_stats[4]++;
 #endif
+                cx.wave_sync(); // (lane model: every lane is done with the slots about to be overwritten)
                 land_chunk(landed);
+                cx.wave_sync(); // (lane model: the shares the other lanes wrote are in place)
                 landed++;
                 more = landed < nchunks;
                 if (more)
@@ -709,12 +723,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     }
 
 #ifdef MSK_PROF
-    if (c == 0) {
+    if (c == 0 && owner) {
         long long pf_t1 = __builtin_readcyclecounter();
         printf("msk prof: total %lld lock %lld (failed entries %lld: %lld) land %lld gen %lld | pairs %lld runs %lld genpasses %lld events %lld\n", pf_t1 - pf_t0, pf_lock, pf_nfail, pf_fail, pf_land, pf_gen, pf_n[0], pf_n[1], pf_n[2], pf_n[3]);
     }
 #endif
-    if (!live)
+    if (!live || !owner)
         return;
     if (worst_imu >= (unsigned)MSK_ZERO_ROW)
         status |= MSK_ST_INTERP_RANGE;
@@ -744,7 +758,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
         int w = 0;
         for (int k = 0; k < qn; k++) { // queued ones (value already narrowed to the float the loop uses)
-            const tq_ent e = tq[k * LPW];
+            const tq_ent e = tq[k * TQS];
             if (e.rel < base)
                 continue;
             if (w < p.ctag_cap) {

@@ -54,6 +54,7 @@ struct EmuCtx {
     char* lds() const { return sh->lds.data(); }
     void sync() const { sh->bar.arrive_and_wait(); }
     void wsync() const { sh->wbar[tid_ >> 6]->arrive_and_wait(); }
+    void wave_sync() const { wsync(); }
     // a lane that leaves the kernel for good: it stops counting in the barriers
     void retire() const
     {
@@ -195,7 +196,7 @@ void emu_msk(const MskParams* p)
     const bool aux = p->err || p->mu_out;
     auto go = [&](auto lpw_tag) {
         constexpr int L = decltype(lpw_tag)::value;
-        run_grid((p->nchan + 63) / 64, 1, 64 * (64 / L), MSK_LDS_BYTES, [&](EmuCtx& cx) {
+        run_grid((p->nchan + 63) / 64, 1, 64 * (64 / L), p->lds_tab_off + MSK_LDS_MMSE, [&](EmuCtx& cx) {
             if (p->osps == 2)
                 aux ? msk_body<EmuCtx, true, true, L>(cx, *p) : msk_body<EmuCtx, false, true, L>(cx, *p);
             else
@@ -327,8 +328,12 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.ct = h->ct.data(); p.ct_n = h->ct_n.data(); p.ct_cap = h->ct_cap;
     p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
-    p.lds_tab_off = MSK_LDS_TABOFF;
+    // free-running lanes: every lane gets a tag-queue column of its own (see MskParams)
     p.lpw = h->lpw;
+    p.lds_wave_stride = msk_lds_ring(h->lpw) + MSK_TAGQ * 64 * 8;
+    p.tq_stride = 64;
+    p.tq_private = 1;
+    p.lds_tab_off = (64 / h->lpw) * p.lds_wave_stride;
 }
 
 static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap)
