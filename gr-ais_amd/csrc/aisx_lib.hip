@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CF4_T) void k_corr4_inith(CorrInitParams p)
     corr4_inith_body(cx, p);
 }
 
-__global__ __launch_bounds__(CF4_T, 2) void k_corr4_main(CorrParams p)
+__global__ __launch_bounds__(CF4_T, 3) void k_corr4_main(CorrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };

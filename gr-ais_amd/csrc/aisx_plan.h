@@ -71,7 +71,7 @@ inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored, int F)
 inline void corr_grid(int nchan, int n, int L, int F, int* nseg, int* tiles_per_seg)
 {
     const int ntiles = (n + L - 1) / L;
-    const long slots = 256L * (F == CF_F ? 6 : 2); // resident workgroups per CU of the two builds
+    const long slots = 256L * (F == CF_F ? 6 : 3); // resident workgroups per CU of the two builds
     int best = 1;
     double best_cost = 1e30;
     for (int ns = 1; ns <= 16; ns++) {
