@@ -609,6 +609,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             if (npairs == 0) { pf_fail += __builtin_readcyclecounter() - pf_a; pf_nfail++; }
 #endif
             if (npairs > 0) {
+              // the run itself on the LPW owner lanes only (nothing in it needs the wave: no
+              // ballot, and 16 lanes' worth of LDS traffic instead of 64); the mirror lanes
+              // take the owners' state over afterwards
+              if (owner) {
                 const int sb_entry = sb;
                 cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
                 float nl_prev = d_dly_diff_1.re;
@@ -673,6 +677,20 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
                 if (!(d_mu >= 0.f && d_mu <= 1.f)) // (non-finite input: upstream would have thrown)
                     status |= MSK_ST_INTERP_RANGE;
+              }
+              if (NQ > 1) { // lane i <- lane i % LPW
+                d_mu = cx.shfl_f32(d_mu, l);
+                d_omega = cx.shfl_f32(d_omega, l);
+                sb = cx.shfl_i32(sb, l);
+                d_div = cx.shfl_i32(d_div, l);
+                oidx = cx.shfl_i32(oidx, l);
+                iidx = cx.shfl_i32(iidx, l);
+                ob = (unsigned)cx.shfl_i32((int)ob, l);
+                status = cx.shfl_i32(status, l);
+                prev_sq = mk(cx.shfl_f32(prev_sq.re, l), cx.shfl_f32(prev_sq.im, l));
+                last_interp = mk(cx.shfl_f32(last_interp.re, l), cx.shfl_f32(last_interp.im, l));
+                d_dly_diff_1 = mk(cx.shfl_f32(d_dly_diff_1.re, l), cx.shfl_f32(d_dly_diff_1.im, l));
+              }
 #ifdef MSK_PROF
                 pf_n[0] += npairs; pf_n[1]++;
 #endif
