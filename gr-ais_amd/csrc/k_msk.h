@@ -556,7 +556,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const float wmax = d_sps + fabsf(p.limit);
     const float pair_adv = 2.0f * wmax + 3.0f * fabsf(p.gain);
     const float pair_adv_inv = 0.9999f / pair_adv;
-    const int pair_margin = 2;
     // mu + omega stays positive there (so that floor is a truncation and mu - floor(mu) the
     // hardware's fract) as long as the loop filter cannot pull mu below -omega:
     const bool lock_ok = 3.0f * fabsf(p.gain) + fabsf(p.limit) + 0.01f < d_sps;
@@ -587,9 +586,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             // with `room` items below its bound is good for room / pair_adv pairs (see pair_adv); the wave
             // takes what the slowest lane can do (at most MSK_PAIRS_MAX: one chunk's worth, the
             // next chunk is then due).  The trips run with no test at all.
+            // Every iteration of a run must START below the bound.  The last one of c pairs
+            // starts after c - 1 pairs and one even iteration, i.e. at most
+            // 1 + (c - 1) pair_adv + wmax items further on (see pair_adv).
             // (fast_lim may be INT_MIN = "unknown" or INT_MAX = "no bound": no overflow either way)
-            const int room = fast_lim > iidx ? fast_lim - iidx - pair_margin : 0;
-            int can = (int)((float)room * pair_adv_inv);
+            const float room = fast_lim > iidx ? (float)(fast_lim - iidx) - (1.001f + wmax) : -1.f;
+            int can = room >= 0.f ? (int)(room * pair_adv_inv) + 1 : 0;
             can = can < MSK_PAIRS_MAX ? can : MSK_PAIRS_MAX;
             const int ocan = OSPS2 ? (noutput - oidx) / 2 : (noutput - oidx) - 1;
             can = can < ocan ? can : ocan;
