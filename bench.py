@@ -155,8 +155,8 @@ def bench_wideband(args, torch, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=65536)
     ap.add_argument("--template", choices=["S", "P"], default="S", help="S: stock 896-sample template; P: 112-sample preamble")
@@ -214,6 +214,8 @@ def main():
         outs = [dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
                      produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(2)]
         s_main, s_msk = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        s_tail = torch.cuda.Stream(device=device)  # the bit tail of step k runs beside the recovery of step k+1
+        dem.clockrec.set_tail_stream(s_tail)
         msk_done = [None, None]
         state = dict(k=0)
 

@@ -218,6 +218,16 @@ class msk_timing_recovery_cc:
             prod.data_ptr(), _stream_ptr(stream)), "msk_timing_recovery_cc.work")
         return dict(syms=syms, err=err, mu=mu, bits=bits, produced=prod)
 
+    def set_tail_stream(self, stream):
+        """Run the NRZI bit tail of every work() call on `stream` (None: back on the call's own
+        stream).  The caller then alternates between two sets of output buffers (outs=) and orders
+        its readers of `bits` after that stream (wait_tail)."""
+        check(_lib.lib().aisx_msk_set_tail_stream(self._h, _stream_ptr(stream) if stream is not None else None,
+                                                  1 if stream is not None else 0), "set_tail_stream")
+
+    def wait_tail(self, stream=None):
+        check(_lib.lib().aisx_msk_wait_tail(self._h, _stream_ptr(stream)), "wait_tail")
+
     def last_status(self, stream=None):
         st = C.c_int(0)
         check(_lib.lib().aisx_msk_last_status(self._h, C.byref(st), _stream_ptr(stream)), "last_status")

@@ -541,8 +541,17 @@ struct aisx_msk {
     cf* d_tprev[2] = { nullptr, nullptr };
     unsigned char* d_tbit[2] = { nullptr, nullptr };
     int tcur = 0;
-    cf* d_symscratch = nullptr; // symbols for the bit tail when the caller takes bits only
-    size_t symscratch_len = 0;
+    // symbols for the bit tail when the caller takes bits only; two, alternating, so that the
+    // bit tail of call k may still read one while call k+1 writes the other (tail stream)
+    cf* d_symscratch[2] = { nullptr, nullptr };
+    size_t symscratch_len[2] = { 0, 0 };
+    int callpar = 0;
+    // optional: the bit tail on a stream of its own (aisx_msk_set_tail_stream)
+    bool tail_on = false;
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_msk = nullptr, ev_tail[2] = { nullptr, nullptr };
+    bool ev_tail_set[2] = { false, false };
+    int* d_produced2 = nullptr; // second internal `produced` array (alternates with d_produced)
     unsigned long long* d_nread = nullptr;
     cf* d_carry[2] = { nullptr, nullptr };
     int* d_carry_len[2] = { nullptr, nullptr };
@@ -654,6 +663,7 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         CK(dev_alloc(&h->d_ctag_n[k], nchan));
     }
     CK(dev_alloc(&h->d_produced, nchan));
+    CK(dev_alloc(&h->d_produced2, nchan));
     CK(dev_alloc(&h->d_consumed, nchan));
     CK(dev_alloc(&h->d_status, nchan));
     CK(dev_alloc(&h->d_mmse, 129 * 8));
@@ -692,7 +702,14 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
         dev_free(h->d_tprev[k]);
         dev_free(h->d_tbit[k]);
     }
-    dev_free(h->d_symscratch);
+    dev_free(h->d_symscratch[0]);
+    dev_free(h->d_symscratch[1]);
+    dev_free(h->d_produced2);
+    if (h->ev_msk)
+        (void)hipEventDestroy(h->ev_msk);
+    for (int k = 0; k < 2; k++)
+        if (h->ev_tail[k])
+            (void)hipEventDestroy(h->ev_tail[k]);
     dev_free(h->d_ct);
     dev_free(h->d_ct_n);
     dev_free(h->d_nread);
@@ -879,35 +896,78 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         set_err("aisx_msk_process_stream: out_stride %ld too large (the 64 rows of a wave must lie within 4 GiB)", out_stride);
         return AISX_ERR_INVALID;
     }
+    const int par = h->callpar;
+    h->callpar ^= 1;
+    if (h->tail_on && h->ev_tail_set[par]) // the bit tail of two calls ago may still read this parity's buffers
+        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[par], 0));
     if (!syms) { // the kernel always writes symbols (the bit tail reads them back): give them a home
         const size_t need = (size_t)h->nchan * (size_t)out_stride;
-        if (need > h->symscratch_len) {
+        if (need > h->symscratch_len[par]) {
             AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-            dev_free(h->d_symscratch);
-            h->d_symscratch = nullptr;
-            h->symscratch_len = 0;
-            if ((rc = dev_alloc(&h->d_symscratch, need)) != AISX_OK)
+            dev_free(h->d_symscratch[par]);
+            h->d_symscratch[par] = nullptr;
+            h->symscratch_len[par] = 0;
+            if ((rc = dev_alloc(&h->d_symscratch[par], need)) != AISX_OK)
                 return rc;
             AISX_HIPCHK(hipDeviceSynchronize()); // (the zero fill runs on the null stream)
-            h->symscratch_len = need;
+            h->symscratch_len[par] = need;
         }
-        syms = h->d_symscratch;
+        syms = h->d_symscratch[par];
     }
     p.syms = syms;
     p.err = d_err;
     p.mu_out = d_mu;
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
-    p.produced = d_produced ? d_produced : h->d_produced;
+    p.produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
     if ((rc = msk_launch(p, (h->nchan + 63) / 64, (hipStream_t)stream)) != AISX_OK)
         return rc;
     h->cur ^= 1;
     if (d_bits) {
         // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
         const int max_out = std::min<long>(p.out_cap, (long)((n + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * h->osps + 16);
-        if ((rc = msk_launch_bittail(h, syms, out_stride, p.produced, d_bits, out_stride, max_out, (hipStream_t)stream)) != AISX_OK)
+        hipStream_t ts = (hipStream_t)stream;
+        if (h->tail_on) { // the bit tail has no part in the recurrence: let the next call start
+            AISX_HIPCHK(hipEventRecord(h->ev_msk, (hipStream_t)stream));
+            AISX_HIPCHK(hipStreamWaitEvent(h->tail_stream, h->ev_msk, 0));
+            ts = h->tail_stream;
+        }
+        if ((rc = msk_launch_bittail(h, syms, out_stride, p.produced, d_bits, out_stride, max_out, ts)) != AISX_OK)
             return rc;
+        if (h->tail_on) {
+            AISX_HIPCHK(hipEventRecord(h->ev_tail[par], h->tail_stream));
+            h->ev_tail_set[par] = true;
+        }
     }
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_set_tail_stream(aisx_msk* h, void* tail_stream, int enable)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (!enable) {
+        h->tail_on = false;
+        return AISX_OK;
+    }
+    if (!h->ev_msk)
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_msk, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++)
+        if (!h->ev_tail[k])
+            AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_tail[k], hipEventDisableTiming));
+    h->tail_stream = (hipStream_t)tail_stream;
+    h->tail_on = true;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_wait_tail(aisx_msk* h, void* stream)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (h->tail_on)
+        for (int k = 0; k < 2; k++)
+            if (h->ev_tail_set[k])
+                AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[k], 0));
     return AISX_OK;
 }
 

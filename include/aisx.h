@@ -156,6 +156,14 @@ int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, 
                             uint8_t* d_bits, long out_stride, int* d_produced, void* stream);
 /* status word per channel of the last call, or-ed over channels (0 = clean) */
 int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
+/* The NRZI bit tail (quadrature demod .. invert, python/ais_demod.py:48-52) has no part in
+ * the timing recurrence.  With a tail stream set (enable != 0) aisx_msk_process_stream
+ * launches it there, ordered after the call's recovery kernel, so that the next call need
+ * not wait for it: d_bits of a call is complete on THAT stream (aisx_msk_wait_tail makes
+ * another stream wait for it); the caller must then alternate between two d_bits / d_syms /
+ * d_produced buffers from call to call.  Default: off, everything on the call's stream. */
+int aisx_msk_set_tail_stream(aisx_msk* h, void* tail_stream, int enable);
+int aisx_msk_wait_tail(aisx_msk* h, void* stream);
 /* GNU Radio path (nchan == 1), host pointers as general_work() receives them
  * (impl :107-206): tags = the time_est tags get_tags_in_range would return or
  * any superset, nitems_read = nitems_read(0).  *consumed is what to pass to
