@@ -282,6 +282,42 @@ def test_msk_many_tags_per_call(ais):
         assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
 
 
+def test_msk_bit_tail_on_its_own_stream(ais):
+    # aisx_msk_set_tail_stream: same bits, computed on a second stream while the next call runs
+    import torch
+    from ais_amd import synth
+
+    nchan, lens = 20, [4000, 3000, 5000, 2000]
+    xs = np.stack([synth.make_channel(700 + c, sum(lens), "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
+    a = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    b = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    tail = torch.cuda.Stream()
+    b.set_tail_stream(tail)
+    cap = b.out_capacity
+    outs = [dict(syms=None, bits=torch.zeros((nchan, cap), dtype=torch.uint8, device="cuda"),
+                 produced=torch.zeros(nchan, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    k = 0
+    got = []
+    for i, L in enumerate(lens):
+        x = _dev(xs[:, k:k + L])
+        ra = a.work(x, want_syms=False)
+        b.work(x, outs=outs[i & 1])
+        b.wait_tail()  # (the current stream now waits for the tail)
+        torch.cuda.synchronize()
+        pa = ra["produced"].cpu().numpy()
+        pb = outs[i & 1]["produced"].cpu().numpy()
+        assert np.array_equal(pa, pb)
+        ba, bb = ra["bits"].cpu().numpy(), outs[i & 1]["bits"].cpu().numpy()
+        for c in range(nchan):
+            assert np.array_equal(ba[c, :pa[c]], bb[c, :pb[c]])
+        got.append(int(pa.sum()))
+        k += L
+    assert sum(got) > nchan * sum(lens) / 4 * 0.95
+    b.set_tail_stream(None)
+    rb = b.work(_dev(xs[:, :100]))
+    assert rb["produced"].shape[0] == nchan
+
+
 @pytest.mark.parametrize("family", ["P", "S"])
 def test_core_chain_corr_to_msk_bits_identical(ais, family):
     # corr_est -> msk -> NRZI bits with the tags handed over on the device, vs
