@@ -282,6 +282,59 @@ def test_msk_many_tags_per_call(ais):
         assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
 
 
+@pytest.mark.parametrize("lpw", [16, 32, 64])
+def test_msk_channels_per_wave_builds(ais, lpw, monkeypatch):
+    # the three builds of the timing-recovery kernel (16 / 32 / 64 channels per wave) give the
+    # same bits and symbols as the oracle; the library picks 16, AISX_MSK_LPW overrides it
+    from ais_amd import synth
+
+    monkeypatch.setenv("AISX_MSK_LPW", str(lpw))
+    rng = np.random.default_rng(40 + lpw)
+    nchan, lens = 70, [5000, 3000]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(800 + c, total, "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
+    blk = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    cap = 32
+    tg_all = []
+    for c in range(nchan):
+        t = np.zeros(12, dtype=ais.TAG_DTYPE)
+        t["offset"] = np.sort(rng.choice(np.arange(10, total - 10), size=12, replace=False))
+        t["value"] = rng.uniform(-0.9, 0.9, 12)
+        t["key"] = 2
+        t["chan"] = c
+        tg_all.append(t)
+    o = [orc.MskStream(4.0, 0.04, 0.01, 1) for _ in range(nchan)]
+    import torch
+    k = 0
+    for L in lens:
+        tg = np.zeros((nchan, cap), dtype=ais.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        sels = []
+        for c in range(nchan):
+            sel = tg_all[c][(tg_all[c]["offset"] >= k) & (tg_all[c]["offset"] < k + L)]
+            tg[c, : len(sel)] = sel
+            cnt[c] = len(sel)
+            sels.append(sel)
+        d_tags = torch.as_tensor(tg.view(np.uint8).reshape(nchan, -1).copy()).cuda()
+        d_cnt = torch.as_tensor(cnt).cuda()
+        r = blk.work(_dev(xs[:, k:k + L]), tags_ptrs=(d_tags.data_ptr(), d_cnt.data_ptr(), cap))
+        assert blk.last_status() == 0
+        prod = r["produced"].cpu().numpy()
+        syms = r["syms"].cpu().numpy()
+        for c in range(0, nchan, 3):
+            ot = np.zeros(len(sels[c]), dtype=orc.TAG_DTYPE)
+            ot["offset"], ot["value"], ot["key"] = sels[c]["offset"], sels[c]["value"], sels[c]["key"]
+            out, _, _, _ = o[c].step(xs[c, k:k + L], ot, want_aux=True)
+            assert prod[c] == len(out)
+            assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
+        for c in range(nchan):  # keep the oracles of the channels not compared in step
+            if c % 3:
+                ot = np.zeros(len(sels[c]), dtype=orc.TAG_DTYPE)
+                ot["offset"], ot["value"], ot["key"] = sels[c]["offset"], sels[c]["value"], sels[c]["key"]
+                o[c].step(xs[c, k:k + L], ot, want_aux=True)
+        k += L
+
+
 def test_msk_bit_tail_on_its_own_stream(ais):
     # aisx_msk_set_tail_stream: same bits, computed on a second stream while the next call runs
     import torch
