@@ -353,32 +353,52 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
             const int src = cx.ctz64(nz);
             const unsigned long long word = cx.shfl_u64(we, src);
             int pk = (base + src) * 64 + cx.ctz64(word);
-            // climb to the local maximum (:202-204)
-            cf cp = corr[pk];
-            float mp = mag2(cp);
-            while (pk < n - 1) {
-                const int q = pk + 1;
-                if (!((A[q >> 6] >> (q & 63)) & 1ull))
-                    break; // mag[q] <= thresh < mag[pk]
-                const cf cq = corr[q];
-                const float mq = mag2(cq);
-                if (!(mp < mq))
-                    break;
-                pk = q;
-                cp = cq;
-                mp = mq;
+            // One window per detection: lane j looks at item q0 + j, q0 = pk - 1 -- its
+            // above-threshold bit and its correlation value, fetched in one go -- so that the
+            // climb (:202-204) and the centre of mass (:219-227) cost one memory round trip
+            // instead of one per step.
+            cf cp = mk(0.f, 0.f);
+            float mp = 0.f, m0 = 0.f, m2 = 0.f;
+            bool have0 = false, have2 = false;
+            for (;;) {
+                const int q0 = pk - 1;
+                const int wa = (q0 < 0 ? 0 : q0) >> 6;
+                const unsigned long long WA = A[wa];
+                const unsigned long long WB = (wa + 1 < nwords) ? A[wa + 1] : 0ull;
+                const int pos = q0 + lane;
+                const bool inside = pos >= 0 && pos < n;
+                const unsigned long long wsel = ((pos >> 6) == wa) ? WA : WB;
+                const bool above = inside && ((pos >> 6) <= wa + 1) && ((wsel >> (pos & 63)) & 1ull);
+                cf cv = mk(0.f, 0.f);
+                if (inside && (above || p.dense_corr))
+                    cv = corr[pos];
+                const float mg = mag2(cv);
+                // climb: from item q to q + 1 while q + 1 is above threshold and larger
+                const float mg_next = cx.shfl_down_f32(mg, 1);
+                const unsigned long long AB = cx.ballot(above);
+                const bool step_ok = (lane < 63) && ((AB >> (lane + 1)) & 1ull) && (mg < mg_next);
+                const unsigned long long C = cx.ballot(step_ok);
+                const int run = cx.ctz64(~(C >> 1)); // consecutive climbs from lane 1 (= pk)
+                const int jp = 1 + run;              // lane of the local maximum, if it is inside the window
+                if (jp >= 63) { // the climb runs off the window: move the window there and go on
+                    pk = q0 + 62;
+                    continue;
+                }
+                pk = q0 + jp;
+                cp = mk(cx.shfl_f32(cv.re, jp), cx.shfl_f32(cv.im, jp));
+                mp = mag2(cp);
+                have0 = p.dense_corr || ((AB >> (jp - 1)) & 1ull);
+                have2 = p.dense_corr || ((AB >> (jp + 1)) & 1ull);
+                m0 = cx.shfl_f32(mg, jp - 1);
+                m2 = cx.shfl_f32(mg, jp + 1);
+                break;
             }
             // centre of mass (:219-227)
             double center = 0.0;
             if (pk > 0 && pk < n - 1) {
-                float m0, m2;
-                if (p.dense_corr || ((A[(pk - 1) >> 6] >> ((pk - 1) & 63)) & 1ull))
-                    m0 = mag2(corr[pk - 1]);
-                else
+                if (!have0)
                     m0 = resolve_direct_mag(cx, p, c, pk - 1);
-                if (p.dense_corr || ((A[(pk + 1) >> 6] >> ((pk + 1) & 63)) & 1ull))
-                    m2 = mag2(corr[pk + 1]);
-                else
+                if (!have2)
                     m2 = resolve_direct_mag(cx, p, c, pk + 1);
                 double nom = 0, den = 0;
                 nom += (double)(1.0f * m0);
