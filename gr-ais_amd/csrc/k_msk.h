@@ -3,33 +3,32 @@
 // :62-64 as a second, fully parallel kernel over the symbols the first one wrote.
 //
 // The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
-// is across channels, so one lane owns one channel and a wave owns 64.  Every
-// lane keeps a ring of the last 256 samples of its channel in LDS, stored
-// slot-major (ring[slot][lane]): a lane always touches its own pair of banks, so
-// the 8-tap reads are conflict free however far the lanes drift apart, and a
-// chunk lands with conflict-free stores.  The memory schedule is the same for all
-// lanes: chunk t = new samples [64t, 64t+64) of every channel is fetched (one
-// 16-byte load per lane per two samples, each lane walking its own row, issued
-// BEFORE the iterations that consume chunk t-1 so the loads fly under the
-// recurrence) and landed afterwards; lanes then iterate, each at its own pace,
-// until none can go on without the next chunk.  Symbols are stored straight from
-// the loop (fire and forget).
+// is across channels.  A workgroup carries 64 channels as 64 / LPW waves (LPW = 16 by
+// default: four waves, one per SIMD), each wave on its own; inside a wave all 64 lanes
+// stay enabled, lane i running the channel of lane i % LPW.  Every channel keeps a ring
+// of its last 256 samples in LDS, stored slot-major (ring[slot][channel of the wave]): an
+// 8-tap read never conflicts however far the channels drift apart.  Chunk t = new samples
+// [64t, 64t+64) of every channel is fetched into registers one chunk ahead (16-byte loads,
+// the 64 / LPW lanes of a channel each taking a share) and lands in the rings as soon as
+// no lane still reads the slots it overwrites.  Symbols are stored straight from the loop.
 //
-// A lone wave issues one instruction every ~2.3 ns whatever the dependencies
-// (tools/ubench), so the loop is written for instruction count:
+// A lone wave issues one instruction every ~2.3 ns whatever the dependencies and however
+// few lanes are enabled (tools/ubench), so the loop is written for instruction count:
 //  * the reference's iteration comes in two kinds, d_div even (emit a symbol) and
-//    d_div odd (run the loop filter).  The body is unrolled into an even step and an
-//    odd step, each executed by the lanes of that parity: lanes fall into lock step
-//    after one pass and stay there (a time_est tag can shift a lane by one step, it
-//    rejoins on the next pass), so neither kind pays for the other;
-//  * every rare event of the reference's loop head (end of this general_work call,
-//    the next chunk not landed yet, a time_est tag coming into range) is folded into
-//    one per-lane bound fast_lim on iidx; only a lane that reaches it runs the
-//    event code, behind a wave-uniform branch.  Lane predicates (parked, parity)
-//    live as 64-bit wave masks in scalar registers: the per-step bookkeeping is a
-//    handful of scalar ops;
+//    d_div odd (run the loop filter).  While no lane is near an event, (even, odd) pairs
+//    run in lock step in a counted loop with no test inside: the number of pairs every
+//    lane can run follows from a per-lane bound fast_lim on iidx (end of this
+//    general_work call, data horizon, next time_est tag) and the proven maximum advance
+//    of a pair; the wave takes the minimum;
+//  * lanes at an event run the reference's loop head in its order (events()) behind
+//    wave-uniform branches, then even and odd iterations as masked steps; parity and
+//    "parked" are 64-bit wave masks in scalar registers.  A tag reset can shift a lane
+//    by one iteration, it rejoins the lock step on the next pass;
+//  * the time_est tags come compacted (tagprep_body) and are queued in LDS, so a firing
+//    tag costs an LDS read;
 //  * the bit tail (quadrature demod, slicer, differential decoder, invert) has no
-//    feedback into the loop and runs afterwards over all symbols in parallel.
+//    feedback into the loop and runs afterwards over all symbols in parallel
+//    (bittail_body).
 // All arithmetic is the reference's float/double sequence, unfused: bit-identical
 // to the CPU restatement.
 #pragma once
@@ -39,7 +38,7 @@ namespace aisx {
 
 enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERFLOW = 4, MSK_ST_OUT_FULL = 8 };
 
-constexpr int MSK_T = 64;
+constexpr int MSK_T = 64;    // lanes of a wave
 constexpr int MSK_RING = 256;   // slots per lane (power of two)
 constexpr int MSK_SLOTS = MSK_RING + 8; // + 8 mirror slots: an 8-tap read never wraps
 constexpr int MSK_CHUNK = 64;   // samples per chunk
