@@ -12,7 +12,7 @@
 // same positions, inverse is DIT (natural out): no reordering pass.
 // The template spectrum H (16 KB) and the twiddle table W_2048 (16 KB) stay in
 // L2 and are read where they are used: keeping them in LDS / VGPRs costs
-// occupancy (35 KB LDS, 225 VGPRs => 2 waves/SIMD; now 18 KB, 154 VGPRs => 3).
+// occupancy (35 KB LDS, 225 VGPRs => 2 waves/SIMD; now 18 KB, 132 VGPRs => 3).
 // LDS image: 16 rows x 136 complex (row pad 8 => the radix-16 passes over
 // stride-8 columns hit 64 distinct banks per half wave) with the 16-byte chunk
 // index XOR-ed by (k2>>2)&3 so the stride-1 radix-8 pass reads ds_read_b128
