@@ -84,25 +84,29 @@ def pmc_traffic(nchan, T, N):
     return d.get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(chain, family, sps, T, nch=32):
-    """The CPU oracle (a plain-C port of the reference's algorithm, single
-    thread) on a bounded sample of the same workload."""
+def cpu_baseline(chain, family, sps, T, budget_s=12.0, max_ch=512):
+    """The CPU oracle (a plain-C port of the reference's algorithm, single thread) on a bounded
+    sample of the same workload: whole channels of T samples, one after the other, until about
+    `budget_s` seconds of CPU work are done."""
     import oracle_py as orc
     from ais_amd import synth
 
     tmpl = make_template(family, sps)
     stock = chain == "stock"
-    xs = [synth.make_channel(synth.SEED0 + c, T, family, sps, amp=0.3 if stock else 1.0,
-                             cfo_max=500.0 if stock else 15.0)[0] for c in range(nch)]
-    dem = [orc.Demod(sps, tmpl, stages=3 if stock else 0) for _ in range(nch)]
-    dem[0].step(xs[0][:4096])  # warm the FFT plan cache
-    dem[0] = orc.Demod(sps, tmpl, stages=3 if stock else 0)
-    t0 = time.perf_counter()
-    for c in range(nch):
-        dem[c].step(xs[c])
-    dt = time.perf_counter() - t0
-    return dict(value=nch * T / dt / 1e6, unit="complex MS/s", cores=1, kind="port",
-                sample="%d channels x %d samples, chain=%s, oracle/ais_oracle.c single thread" % (nch, T, chain))
+    warm = orc.Demod(sps, tmpl, stages=3 if stock else 0)
+    warm.step(synth.make_channel(synth.SEED0, 4096, family, sps)[0])  # warm the FFT plan cache
+    spent, nch = 0.0, 0
+    while spent < budget_s and nch < max_ch:
+        x = synth.make_channel(synth.SEED0 + nch, T, family, sps, amp=0.3 if stock else 1.0,
+                               cfo_max=500.0 if stock else 15.0)[0]
+        dem = orc.Demod(sps, tmpl, stages=3 if stock else 0)
+        t0 = time.perf_counter()
+        dem.step(x)
+        spent += time.perf_counter() - t0
+        nch += 1
+    return dict(value=nch * T / spent / 1e6, unit="complex MS/s", cores=1, kind="port",
+                sample="%d channels x %d samples (%.1f s of CPU work), chain=%s, oracle/ais_oracle.c single thread"
+                       % (nch, T, spent, chain))
 
 
 def bench_wideband(args, torch, device):
