@@ -78,6 +78,25 @@ struct DevCtx {
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
         return tocf(r);
     }
+    // lo = v of lane (i & ~W), hi = v of lane (i | W), W = 16 or 32: one row swap per 32 bits
+    // (v_permlane16_swap / v_permlane32_swap with both operands = v)
+    template <int W>
+    __device__ __forceinline__ void pair_rows(cf v, cf& lo, cf& hi) const
+    {
+        static_assert(W == 16 || W == 32, "row width");
+        const unsigned a = __float_as_uint(v.re), b = __float_as_uint(v.im);
+        if (W == 16) {
+            const auto ra = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+            const auto rb = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+            lo = mk(__uint_as_float(ra[0]), __uint_as_float(rb[0]));
+            hi = mk(__uint_as_float(ra[1]), __uint_as_float(rb[1]));
+        } else {
+            const auto ra = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+            const auto rb = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+            lo = mk(__uint_as_float(ra[0]), __uint_as_float(rb[0]));
+            hi = mk(__uint_as_float(ra[1]), __uint_as_float(rb[1]));
+        }
+    }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // scheduling fences: the value is materialised here, in program order with the other pins

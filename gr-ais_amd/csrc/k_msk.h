@@ -448,10 +448,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4)); // 16-byte aligned rows
         const tap4 tlo = tp4[0], thi = tp4[1];
         const float tp[8] = { tlo[0], tlo[1], tlo[2], tlo[3], thi[0], thi[1], thi[2], thi[3] };
-        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * SLOT_B)) | (unsigned)(l * 8)));
+        // (ring items are 8-byte aligned: 64-bit LDS reads, two slots per instruction)
+        struct alignas(8) cf8 { float re, im; };
+        const cf8* sp = (const cf8*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * SLOT_B)) | (unsigned)(l * 8)));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            sv[k] = sp[k * LPW];
+            const cf8 t = sp[k * LPW];
+            sv[k] = mk(t.re, t.im);
             tv[k] = tp[7 - k];
         }
     };
@@ -610,10 +613,80 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             if (npairs == 0) { pf_fail += __builtin_readcyclecounter() - pf_a; pf_nfail++; }
 #endif
             if (npairs > 0) {
-              // the run itself on the LPW owner lanes only (nothing in it needs the wave: no
-              // ballot, and 16 lanes' worth of LDS traffic instead of 64); the mirror lanes
-              // take the owners' state over afterwards
-              if (owner) {
+              if constexpr (NQ >= 2) {
+                // Two lanes per channel share a pair: lane i (i / LPW even) runs the even
+                // iteration, lane i + LPW the odd one, at the same time.  The even iteration has
+                // no feedback into mu (:179), so where the odd one reads is known when the pair
+                // starts; each lane does ONE interpolation (one burst of LDS reads, one sum), the
+                // squares cross over by a row swap (v_permlane16/32_swap), and the loop filter is
+                // computed by both lanes alike.  (With LPW = 16 lanes 32..63 do the same once more.)
+                const bool roleO = (q & 1) != 0;
+                cf sqO = prev_sq, sqE = mk(0.f, 0.f), acc = last_interp;
+                float nl_prev = d_dly_diff_1.re;
+                const int sb_entry = sb;
+                for (int k = 0; k < npairs; k++) {
+#ifdef MSK_EMU_STATS
+                    if (l == 0 && q == 0) msk_stats[0]++;
+#endif
+                    const float m1 = d_mu + d_omega;                               // :199-201, m1 > 0:
+                    const float muO = cx.fract(m1);                                // m1 - floorf(m1)
+                    const int sb1 = sb + (int)m1 * SLOT_B;                         // (int)floorf(m1)
+                    cf sv[8];
+                    float tv[8];
+                    fir_load((unsigned)(int)rintf((roleO ? muO : d_mu) * 128.0f), roleO ? sb1 : sb, sv, tv);
+                    acc = fir_sum(sv, tv);
+                    const cf sq = cmul_exact(acc, acc);                            // :171
+                    cf sE, s1;
+                    cx.template pair_rows<LPW>(sq, sE, s1);                        // even lane's, odd lane's
+                    const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
+                    const float nlO = s1.re * sE.re + s1.im * sE.im;
+                    const float err = branchless_clip(nlO - nlE, 3.0f);            // :179-184
+                    d_omega += p.gain_omega * err;
+                    d_omega = d_sps + branchless_clip(d_omega - d_sps, p.limit);
+                    const float mu2 = muO + p.gain * err;
+                    if (OSPS2) {                                                   // :186-191
+                        const unsigned o = ob + (roleO ? 8u : 0u);
+                        *(cf*)(osym0 + o) = acc;
+                        if (AUX) {
+                            if (oerr0)
+                                *(float*)(oerr0 + (o >> 1)) = roleO ? err : nlE - nl_prev;
+                            if (omu0)
+                                *(float*)(omu0 + (o >> 1)) = roleO ? mu2 : d_mu;
+                        }
+                        ob += 16u;
+                    } else {
+                        if (!roleO) {
+                            *(cf*)(osym0 + ob) = acc;
+                            if (AUX) {
+                                if (oerr0)
+                                    *(float*)(oerr0 + (ob >> 1)) = nlE - nl_prev;
+                                if (omu0)
+                                    *(float*)(omu0 + (ob >> 1)) = d_mu;
+                            }
+                        }
+                        ob += 8u;
+                    }
+                    const float m2 = mu2 + d_omega;                                // > 0 (lock_ok)
+                    d_mu = cx.fract(m2);
+                    sb = sb1 + (int)m2 * SLOT_B;
+                    sqE = sE;
+                    sqO = s1;
+                    nl_prev = nlO;
+                }
+                // the state every lane of the channel carries on with
+                cf accE, accO;
+                cx.template pair_rows<LPW>(acc, accE, accO);
+                d_div += 2 * npairs;
+                oidx += OSPS2 ? 2 * npairs : npairs;
+                iidx += (sb - sb_entry) >> SLOT_SH;
+                prev_sq = sqO;
+                last_interp = accO;
+                // :174 imaginary part of the last nlin_out: only ever read back as state
+                d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
+                if (!(d_mu >= 0.f && d_mu <= 1.f)) // (non-finite input: upstream would have thrown)
+                    status |= MSK_ST_INTERP_RANGE;
+              } else {
+                // one lane per channel (LPW = 64): both iterations of a pair in the same lane
                 const int sb_entry = sb;
                 cf sqO = prev_sq, sqE = mk(0.f, 0.f), accO = last_interp;
                 float nl_prev = d_dly_diff_1.re;
@@ -678,19 +751,6 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
                 if (!(d_mu >= 0.f && d_mu <= 1.f)) // (non-finite input: upstream would have thrown)
                     status |= MSK_ST_INTERP_RANGE;
-              }
-              if (NQ > 1) { // lane i <- lane i % LPW
-                d_mu = cx.shfl_f32(d_mu, l);
-                d_omega = cx.shfl_f32(d_omega, l);
-                sb = cx.shfl_i32(sb, l);
-                d_div = cx.shfl_i32(d_div, l);
-                oidx = cx.shfl_i32(oidx, l);
-                iidx = cx.shfl_i32(iidx, l);
-                ob = (unsigned)cx.shfl_i32((int)ob, l);
-                status = cx.shfl_i32(status, l);
-                prev_sq = mk(cx.shfl_f32(prev_sq.re, l), cx.shfl_f32(prev_sq.im, l));
-                last_interp = mk(cx.shfl_f32(last_interp.re, l), cx.shfl_f32(last_interp.im, l));
-                d_dly_diff_1 = mk(cx.shfl_f32(d_dly_diff_1.re, l), cx.shfl_f32(d_dly_diff_1.im, l));
               }
 #ifdef MSK_PROF
                 pf_n[0] += npairs; pf_n[1]++;

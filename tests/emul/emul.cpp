@@ -111,6 +111,19 @@ struct EmuCtx {
         memcpy(&out, &r, sizeof(T));
         return out;
     }
+    // lo = v of lane (i & ~W), hi = v of lane (i | W)
+    template <int W>
+    void pair_rows(cf v, cf& lo, cf& hi) const
+    {
+        unsigned long long raw = 0;
+        memcpy(&raw, &v, sizeof(cf));
+        unsigned long long* b = bank();
+        b[tid_] = raw;
+        wsync();
+        const int ln = tid_ & 63;
+        memcpy(&lo, &b[wave_base() + (ln & ~W)], sizeof(cf));
+        memcpy(&hi, &b[wave_base() + (ln | W)], sizeof(cf));
+    }
     unsigned long long shfl_u64(unsigned long long v, int src) const { return xchg(v, src); }
     float shfl_f32(float v, int src) const { return xchg(v, src); }
     int shfl_i32(int v, int src) const { return xchg(v, src); }
