@@ -271,11 +271,15 @@ class square_and_fft_sync_cc:
     def reset(self):
         check(_lib.lib().aisx_freqsync_reset(self._h), "reset")
 
-    def work(self, x, want_fhat=False, stream=None):
+    def work(self, x, want_fhat=False, stream=None, out=None):
+        """`out`: optional preallocated (nchan, >= n + fftlen) complex64 buffer the result is a view of."""
         x = _dev_c64(x, self.nchan)
         n = x.shape[1]
         cap = n + self.fftlen
-        out = torch.empty((self.nchan, cap), dtype=torch.complex64, device=x.device)
+        if out is None:
+            out = torch.empty((self.nchan, cap), dtype=torch.complex64, device=x.device)
+        elif out.shape[0] != self.nchan or out.shape[1] < cap or out.dtype != torch.complex64 or out.stride(1) != 1:
+            raise ValueError("out must be a (nchan, >= n + fftlen) complex64 buffer")
         nv = cap // self.fftlen + 1
         fh = torch.empty((self.nchan, nv), dtype=torch.float32, device=x.device) if want_fhat else None
         nout = C.c_int(0)

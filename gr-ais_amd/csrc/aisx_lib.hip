@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 }
 
 template <bool AUX, bool OSPS2, int LPW>
-__global__ __launch_bounds__(64 * (64 / LPW)) void k_msk(MskParams p)
+__global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk(MskParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
@@ -102,21 +102,23 @@ __global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
 static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
 {
     typedef void (*kfn)(MskParams);
-    static const kfn fns[12] = {
+    static const kfn fns[20] = {
         k_msk<false, false, 16>, k_msk<false, true, 16>, k_msk<true, false, 16>, k_msk<true, true, 16>,
         k_msk<false, false, 32>, k_msk<false, true, 32>, k_msk<true, false, 32>, k_msk<true, true, 32>,
         k_msk<false, false, 64>, k_msk<false, true, 64>, k_msk<true, false, 64>, k_msk<true, true, 64>,
+        k_msk<false, false, 8>,  k_msk<false, true, 8>,  k_msk<true, false, 8>,  k_msk<true, true, 8>,
+        k_msk<false, false, 4>,  k_msk<false, true, 4>,  k_msk<true, false, 4>,  k_msk<true, true, 4>,
     };
-    static bool big_lds[12] = { false };
-    const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : 2);
+    static bool big_lds[20] = { false };
+    const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : (p.lpw == 64 ? 2 : (p.lpw == 8 ? 3 : 4)));
     const int v = li * 4 + (((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0));
-    const int lds = MSK_LDS_BYTES;
+    const int lds = msk_lds_bytes(p.lpw);
     if (!big_lds[v]) {
         AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         big_lds[v] = true;
     }
-    // a workgroup = 64 channels = 64 / lpw waves with lpw lanes at work each
-    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(64 * (64 / p.lpw)), lds, st, p);
+    // a workgroup = msk_waves(lpw) waves with lpw channels each
+    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(64 * msk_waves(p.lpw)), lds, st, p);
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }
@@ -627,13 +629,16 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
     h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
     {
-        // 16 channels per wave, four waves (one per SIMD) and 64 channels per workgroup: fewer
-        // lanes per wave = fewer events of other lanes to wait for, and the kernel still keeps
-        // to nchan / 64 CUs, which leaves the rest of the chip to the stages that run beside it
-        h->lpw = 16;
+        // 8 channels per wave, four waves (one per SIMD), 32 channels and ~84 KB of LDS per
+        // workgroup: fewer lanes per wave = fewer events of other lanes to wait for (a tag costs
+        // the whole wave a general pass), and half of each CU's LDS stays free for the stages
+        // that run beside this kernel on the other stream.  Measured on the whole flowgraph:
+        // 7.2 / 6.3 / 5.5 ms per launch at 16 / 8 / 4 channels per wave; 8 gives the shortest
+        // step (at 4 the kernel sits on all 256 CUs and slows the bandwidth-bound stages more)
+        h->lpw = 8;
         if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
-            if (v == 16 || v == 32 || v == 64)
+            if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
                 h->lpw = v;
         }
     }
@@ -802,7 +807,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.consumed = h->d_consumed;
     p.status = h->d_status;
     p.mmse = h->d_mmse;
-    p.lds_tab_off = MSK_LDS_TABOFF;
+    p.lds_tab_off = msk_lds_taboff(h->lpw);
     p.lpw = h->lpw;
     p.lds_wave_stride = msk_lds_wave(h->lpw);
     p.tq_stride = h->lpw;
@@ -920,7 +925,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.out_stride = out_stride;
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
-    if ((rc = msk_launch(p, (h->nchan + 63) / 64, (hipStream_t)stream)) != AISX_OK)
+    if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), (hipStream_t)stream)) != AISX_OK)
         return rc;
     h->cur ^= 1;
     if (d_bits) {

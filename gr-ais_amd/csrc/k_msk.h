@@ -50,11 +50,14 @@ constexpr int msk_lds_ring(int lpw) { return MSK_SLOTS * lpw * 8; } // rings: [M
 constexpr int MSK_ZERO_ROW = 129; // an all-zero tap row: where an out-of-range mu lands
 constexpr int MSK_LDS_MMSE = ((130 * MSK_TAPS_PITCH * 4 + 511) / 512) * 512; // whole slot rows: folds into ds offsets
 constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
-// a workgroup always carries 64 channels, as 64 / lpw waves of lpw lanes; every wave has its own
-// rings and tag queue, the tap table behind them is shared
+// a workgroup is msk_waves(lpw) waves with lpw channels each: 64 channels for lpw >= 16, four
+// waves (one per SIMD) of 8 or 4 channels below; every wave has its own rings and tag queue, the
+// tap table behind them is shared
+constexpr int msk_waves(int lpw) { return lpw >= 16 ? 64 / lpw : 4; }
+constexpr int msk_wg_channels(int lpw) { return msk_waves(lpw) * lpw; }
 constexpr int msk_lds_wave(int lpw) { return msk_lds_ring(lpw) + MSK_TAGQ * lpw * 8; }
-constexpr int MSK_LDS_TABOFF = msk_lds_wave(64);          // = (64 / lpw) * msk_lds_wave(lpw) for every lpw
-constexpr int MSK_LDS_BYTES = MSK_LDS_TABOFF + MSK_LDS_MMSE;
+constexpr int msk_lds_taboff(int lpw) { return msk_waves(lpw) * msk_lds_wave(lpw); }
+constexpr int msk_lds_bytes(int lpw) { return msk_lds_taboff(lpw) + MSK_LDS_MMSE; }
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
@@ -87,7 +90,7 @@ struct MskParams {
     cf* syms; float* err; float* mu_out; long out_stride; int out_cap;
     int* produced; int* consumed; int* status;
     const float* mmse; // [129][8]
-    int lds_tab_off;   // = MSK_LDS_TABOFF
+    int lds_tab_off;   // = msk_lds_taboff(lpw)
     // LDS bytes between the regions of consecutive waves, tag-queue entries between consecutive
     // queue slots, and whether every lane has a queue column of its own.  On the device the NQ
     // lanes of a channel share one column (they run in lock step and write the same values:
@@ -124,8 +127,8 @@ template <class Ctx, bool AUX, bool OSPS2, int LPW>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
     constexpr int SLOT_B = LPW * 8;                                   // bytes per ring slot row
-    constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : 7);      // log2(SLOT_B)
-    static_assert(LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
+    constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : (LPW == 16 ? 7 : (LPW == 8 ? 6 : 5))); // log2(SLOT_B)
+    static_assert(LPW == 4 || LPW == 8 || LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
     typedef unsigned long long u64;
     // A workgroup carries 64 channels as 64 / LPW waves, LPW lanes of each at work, every
     // wave on its own (its own SIMD, rings, tag queue, pace).  Few channels per wave: events of
@@ -142,7 +145,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int l = cx.tid() & (LPW - 1);   // the channel (ring column, tag queue column) of this lane
     const int q = (cx.tid() & 63) / LPW;  // its share of a chunk
     const bool owner = q == 0;            // the lane that writes the channel's state back
-    const int cbase = cx.bx() * 64 + wv * LPW;
+    const int cbase = cx.bx() * msk_wg_channels(LPW) + wv * LPW;
     const int c = cbase + l;
     const bool live = c < p.nchan;
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
@@ -156,10 +159,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     float* mm = (float*)(lds0 + p.lds_tab_off);
     cf* myring = ring + l;                     // slot k of this lane: myring[k * LPW]
 
-    for (int i = wv * LPW + l; i < 129 * 8; i += 64)
+    for (int i = cx.tid(); i < 129 * 8; i += cx.nthreads())
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
-    if (wv == 0 && l < MSK_TAPS_PITCH)
-        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + l] = 0.f; // (written by the NQ lanes of a channel alike)
+    if (cx.tid() < MSK_TAPS_PITCH)
+        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + cx.tid()] = 0.f;
     if (cbase >= p.nchan) { // a wave with no channel at all (ragged last workgroup)
         cx.sync();
         return;
@@ -332,10 +335,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #pragma unroll
         for (int k = 0; k < QS; k++)
             myring[(slot0 + q * QS + k) * LPW] = r[k];
-        if (slot0 == 0 && q == 0) { // mirror the first 8 slots behind slot 255
+        if (slot0 == 0 && q * QS < 8) { // mirror the first 8 slots behind slot 255
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                myring[(MSK_RING + k) * LPW] = r[k];
+            for (int k = 0; k < (QS < 8 ? QS : 8); k++)
+                myring[(MSK_RING + q * QS + k) * LPW] = r[k];
         }
     };
     issue_chunk(0);
@@ -428,21 +431,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const unsigned imu = (unsigned)(int)rintf(mu * 128.0f);
         return imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
     };
-    auto fir = [&](unsigned row, int sbpos) -> cf {
-        const float* tp = (const float*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
-        const cf* sp = (const cf*)(lds + (((unsigned)sbpos & (unsigned)((MSK_RING - 1) * SLOT_B)) | (unsigned)(l * 8)));
-        cf acc = mk(0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const cf s = sp[k * LPW]; // mirror slots: no wrap inside the 8 taps
-            const float tk = tp[7 - k];
-            acc.re += s.re * tk;
-            acc.im += s.im * tk;
-        }
-        return acc;
-    };
-
-    // the same in two halves, so that the loads can be issued well before the sum
+    // in two halves, so that the loads can be issued well before the sum
     auto fir_load = [&](unsigned row, int sbpos, cf* sv, float* tv) {
         typedef float tap4 __attribute__((vector_size(16)));
         const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4)); // 16-byte aligned rows
@@ -466,6 +455,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             acc.im += sv[k].im * tv[k];
         }
         return acc;
+    };
+
+    auto fir = [&](unsigned row, int sbpos) -> cf {
+        cf sv[8];
+        float tv[8];
+        fir_load(row, sbpos, sv, tv);
+        return fir_sum(sv, tv);
     };
 
     // one reference iteration (:166-201), d_div of parity PAR, for the lanes exec covers
@@ -614,13 +610,14 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #endif
             if (npairs > 0) {
               if constexpr (NQ >= 2) {
-                // Two lanes per channel share a pair: lane i (i / LPW even) runs the even
-                // iteration, lane i + LPW the odd one, at the same time.  The even iteration has
+                // Two lanes per channel share a pair: lane i (in an even row of 16, or the lower half with LPW = 32) runs the even
+                // iteration, lane i + 16 (i + 32 with LPW = 32) the odd one, at the same time.  The even iteration has
                 // no feedback into mu (:179), so where the odd one reads is known when the pair
                 // starts; each lane does ONE interpolation (one burst of LDS reads, one sum), the
                 // squares cross over by a row swap (v_permlane16/32_swap), and the loop filter is
-                // computed by both lanes alike.  (With LPW = 16 lanes 32..63 do the same once more.)
-                const bool roleO = (q & 1) != 0;
+                // computed by both lanes alike.  (With LPW <= 16 the other copies of a channel do the same once more.)
+                constexpr int ROW = LPW <= 16 ? 16 : 32; // lane i and lane i ^ ROW carry the same channel
+                const bool roleO = (cx.tid() & ROW) != 0;
                 cf sqO = prev_sq, sqE = mk(0.f, 0.f), acc = last_interp;
                 float nl_prev = d_dly_diff_1.re;
                 const int sb_entry = sb;
@@ -637,7 +634,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     acc = fir_sum(sv, tv);
                     const cf sq = cmul_exact(acc, acc);                            // :171
                     cf sE, s1;
-                    cx.template pair_rows<LPW>(sq, sE, s1);                        // even lane's, odd lane's
+                    cx.template pair_rows<ROW>(sq, sE, s1);                        // even lane's, odd lane's
                     const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
                     const float nlO = s1.re * sE.re + s1.im * sE.im;
                     const float err = branchless_clip(nlO - nlE, 3.0f);            // :179-184
@@ -675,7 +672,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 }
                 // the state every lane of the channel carries on with
                 cf accE, accO;
-                cx.template pair_rows<LPW>(acc, accE, accO);
+                cx.template pair_rows<ROW>(acc, accE, accO);
                 d_div += 2 * npairs;
                 oidx += OSPS2 ? 2 * npairs : npairs;
                 iidx += (sb - sb_entry) >> SLOT_SH;

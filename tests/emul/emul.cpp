@@ -209,7 +209,7 @@ void emu_msk(const MskParams* p)
     const bool aux = p->err || p->mu_out;
     auto go = [&](auto lpw_tag) {
         constexpr int L = decltype(lpw_tag)::value;
-        run_grid((p->nchan + 63) / 64, 1, 64 * (64 / L), p->lds_tab_off + MSK_LDS_MMSE, [&](EmuCtx& cx) {
+        run_grid((p->nchan + msk_wg_channels(L) - 1) / msk_wg_channels(L), 1, 64 * msk_waves(L), p->lds_tab_off + MSK_LDS_MMSE, [&](EmuCtx& cx) {
             if (p->osps == 2)
                 aux ? msk_body<EmuCtx, true, true, L>(cx, *p) : msk_body<EmuCtx, false, true, L>(cx, *p);
             else
@@ -220,6 +220,10 @@ void emu_msk(const MskParams* p)
         go(std::integral_constant<int, 16>{});
     else if (p->lpw == 32)
         go(std::integral_constant<int, 32>{});
+    else if (p->lpw == 8)
+        go(std::integral_constant<int, 8>{});
+    else if (p->lpw == 4)
+        go(std::integral_constant<int, 4>{});
     else
         go(std::integral_constant<int, 64>{});
 }
@@ -346,7 +350,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.lds_wave_stride = msk_lds_ring(h->lpw) + MSK_TAGQ * 64 * 8;
     p.tq_stride = 64;
     p.tq_private = 1;
-    p.lds_tab_off = (64 / h->lpw) * p.lds_wave_stride;
+    p.lds_tab_off = msk_waves(h->lpw) * p.lds_wave_stride;
 }
 
 static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap)

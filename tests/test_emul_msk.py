@@ -23,14 +23,15 @@ def _rand_tags(rng, n, count, chan=0):
     return tags
 
 
-@pytest.mark.parametrize("sps,osps", [(4.0, 1), (4.0, 2), (5.2083, 1), (5.0, 1)])
-def test_emul_msk_stream_bit_exact(sps, osps):
+@pytest.mark.parametrize("sps,osps,lpw", [(4.0, 1, 64), (4.0, 2, 64), (5.2083, 1, 32), (5.0, 1, 16), (4.0, 1, 8),
+                                          (4.0, 2, 4), (4.0, 1, 4)])
+def test_emul_msk_stream_bit_exact(sps, osps, lpw):
     rng = np.random.default_rng(int(sps * 10) + osps)
     # > 64 channels so that both channels of a lane are live in the 2-channels-per-lane kernel
-    nchan, lens = (67 if (sps, osps) == (4.0, 1) else 3), [1500, 37, 900, 1, 700]
+    nchan, lens = (67 if (sps, osps, lpw) in ((4.0, 1, 64), (4.0, 1, 8)) else (21 if lpw == 4 else 3)), [1500, 37, 900, 1, 700]
     total = sum(lens)
     xs = np.stack([_signal(50 + c, total, 4)[0] for c in range(nchan)])
-    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan, lpw=(16 if sps == 5.0 else (32 if sps == 5.2083 else 64)))
+    e = emu.MskStream(sps, 0.04, 0.01, osps, nchan=nchan, lpw=lpw)  # channels per wave
     o = [orc.MskStream(sps, 0.04, 0.01, osps) for _ in range(nchan)]
     bt = [orc.BitTail() for _ in range(nchan)]
     # tags: a mix of plausible time_est tags, NaN, other keys, clustered offsets

@@ -282,7 +282,7 @@ def test_msk_many_tags_per_call(ais):
         assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
 
 
-@pytest.mark.parametrize("lpw", [16, 32, 64])
+@pytest.mark.parametrize("lpw", [4, 8, 16, 32, 64])
 def test_msk_channels_per_wave_builds(ais, lpw, monkeypatch):
     # the three builds of the timing-recovery kernel (16 / 32 / 64 channels per wave) give the
     # same bits and symbols as the oracle; the library picks 16, AISX_MSK_LPW overrides it
