@@ -220,7 +220,7 @@ constexpr int FSM_T = 512;             // wave 0 walks the NCO phases, waves 1..
 constexpr int FSM_CPW = 16;            // channels per workgroup (256 workgroups at 4096 channels: one per CU)
 constexpr int FSM_MIXW = FSM_T / 64 - 1;
 constexpr int FSM_CH = 128;            // samples per chunk
-constexpr int FSM_PITCH = FSM_CH + 1;  // floats per channel row in LDS
+constexpr int FSM_PITCH = FSM_CH + 4;  // floats per channel row in LDS (rows 16-byte aligned: the walk stores four phases at a time)
 constexpr int FSM_UNITS = FSM_CPW * (FSM_CH / 64);            // (channel, 64-sample half) units per chunk
 constexpr int FSM_UPW = (FSM_UNITS + FSM_MIXW - 1) / FSM_MIXW; // units per mixing wave
 constexpr int FSM_LDS_BYTES = 2 * FSM_CPW * FSM_PITCH * 4;    // two phase buffers
@@ -289,10 +289,21 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
                 // the fmod wrap.  With |d| < 2 pi the argument of the wrap stays below 4 pi in
                 // magnitude and fmod is a select (nco_wrap_small): no branch in the recurrence.
                 if (fabsf(d) < 6.0f) {
-#pragma unroll 8
-                    for (int i = 0; i < FSM_CH; i++) {
+                    // (a lone wave pays ~18 cycles of issue per LDS instruction: one 128-bit
+                    // store per four phases)
+                    typedef float ph4 __attribute__((vector_size(16)));
+#pragma unroll 2
+                    for (int i = 0; i < FSM_CH; i += 4) {
+                        ph4 v;
                         ph = nco_wrap_small(ph + d);
-                        dst[i] = ph;
+                        v[0] = ph;
+                        ph = nco_wrap_small(ph + d);
+                        v[1] = ph;
+                        ph = nco_wrap_small(ph + d);
+                        v[2] = ph;
+                        ph = nco_wrap_small(ph + d);
+                        v[3] = ph;
+                        *(ph4*)(dst + i) = v;
                     }
                 } else {
                     for (int i = 0; i < FSM_CH; i++) {
