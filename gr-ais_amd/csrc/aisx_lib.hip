@@ -73,7 +73,8 @@ __global__ __launch_bounds__(CF4_T, 3) void k_corr4_main(CorrParams p)
 
 __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
-    DevCtx cx{ nullptr };
+    __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
+    DevCtx cx{ (char*)atab };
     corr_resolve_body(cx, p);
 }
 

@@ -18,6 +18,7 @@
 // index XOR-ed by (k2>>2)&3 so the stride-1 radix-8 pass reads ds_read_b128
 // conflict free.
 #pragma once
+#include <type_traits>
 #include "aisx_common.h"
 #include "k_fft.h"
 
@@ -299,28 +300,58 @@ struct ResolveParams {
 };
 
 template <class Ctx>
-AISX_DI float resolve_direct_mag(Ctx& cx, const ResolveParams& p, int c, int k)
+AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk, bool want0, bool want2, float& m0, float& m2)
 {
     // corr[k] = sum_j taps[j] * x[k - j], recomputed in direct form (double
-    // accumulation) for a below-threshold neighbour of a peak; only feeds the
-    // 3-point centre of mass.
+    // accumulation) for the below-threshold neighbours k = pk - 1 / pk + 1 of a peak; only
+    // feeds the 3-point centre of mass.  Both neighbours in one pass over the taps (one
+    // memory round trip, not two).
     const int lane = cx.tid();
     const cf* xin = p.in + (long)c * p.in_stride;
     const cf* hist = p.hist_in + (long)c * p.N;
-    double ar = 0.0, ai = 0.0;
-    for (int j = lane; j < p.N; j += 64) {
-        const int s = k - j;
-        cf xv = (s >= 0) ? xin[s] : hist[p.N + s];
-        cf tv = p.taps[j];
-        ar += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
-        ai += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
-    }
+    double ar0 = 0.0, ai0 = 0.0, ar2 = 0.0, ai2 = 0.0;
+    // (no branch inside the loops: the loads of all trips go out together)
+    auto pass = [&](auto w0, auto w2) {
+        constexpr bool W0 = decltype(w0)::value, W2 = decltype(w2)::value;
+        for (int j = lane; j < p.N; j += 64) {
+            const int s0 = pk - 1 - j, s2 = pk + 1 - j;
+            const cf tv = p.taps[j];
+            if (W0) {
+                const cf xv = (s0 >= 0) ? xin[s0] : hist[p.N + s0];
+                ar0 += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
+                ai0 += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
+            }
+            if (W2) {
+                const cf xv = (s2 >= 0) ? xin[s2] : hist[p.N + s2];
+                ar2 += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
+                ai2 += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
+            }
+        }
+    };
+    typedef std::true_type yes;
+    typedef std::false_type no;
+    if (want0 && want2)
+        pass(yes{}, yes{});
+    else if (want0)
+        pass(yes{}, no{});
+    else
+        pass(no{}, yes{});
+    if (want0) { // (wave-uniform)
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        ar += cx.shfl_xor_f64(ar, o);
-        ai += cx.shfl_xor_f64(ai, o);
+        for (int o = 32; o >= 1; o >>= 1) {
+            ar0 += cx.shfl_xor_f64(ar0, o);
+            ai0 += cx.shfl_xor_f64(ai0, o);
+        }
+        m0 = mag2(mk((float)ar0, (float)ai0));
     }
-    return mag2(mk((float)ar, (float)ai));
+    if (want2) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ar2 += cx.shfl_xor_f64(ar2, o);
+            ai2 += cx.shfl_xor_f64(ai2, o);
+        }
+        m2 = mag2(mk((float)ar2, (float)ai2));
+    }
 }
 
 template <class Ctx>
@@ -333,6 +364,12 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
     tag_rec* tags = p.tags + (long)c * p.tag_cap;
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
+    // fast_atan2f's table next to the wave (a detection is a chain of dependent memory round
+    // trips; this one becomes an LDS read)
+    float* atab = (float*)cx.lds();
+    for (int k = lane; k < 257; k += 64)
+        atab[k] = p.atan_tab[k];
+    cx.sync();
     int ntag = 0;
     int i = 0;
     for (int base = 0; base < nwords; base += 64) {
@@ -363,8 +400,13 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
             for (;;) {
                 const int q0 = pk - 1;
                 const int wa = (q0 < 0 ? 0 : q0) >> 6;
-                const unsigned long long WA = A[wa];
-                const unsigned long long WB = (wa + 1 < nwords) ? A[wa + 1] : 0ull;
+                // (words base .. base + 63 of the bitmask are in the wave's registers)
+                const int ra = wa - base, rb = wa + 1 - base;
+                unsigned long long WA = cx.shfl_u64(w, ra & 63), WB = cx.shfl_u64(w, rb & 63);
+                if (ra < 0 || ra > 63)
+                    WA = A[wa];
+                if (rb < 0 || rb > 63)
+                    WB = (wa + 1 < nwords) ? A[wa + 1] : 0ull;
                 const int pos = q0 + lane;
                 const bool inside = pos >= 0 && pos < n;
                 const unsigned long long wsel = ((pos >> 6) == wa) ? WA : WB;
@@ -396,10 +438,8 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
             // centre of mass (:219-227)
             double center = 0.0;
             if (pk > 0 && pk < n - 1) {
-                if (!have0)
-                    m0 = resolve_direct_mag(cx, p, c, pk - 1);
-                if (!have2)
-                    m2 = resolve_direct_mag(cx, p, c, pk + 1);
+                if (!have0 || !have2)
+                    resolve_direct_mag2(cx, p, c, pk, !have0, !have2, m0, m2);
                 double nom = 0, den = 0;
                 nom += (double)(1.0f * m0);
                 den += (double)m0;
@@ -409,7 +449,7 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
                 den += (double)m2;
                 center = nom / den - 2.0;
             }
-            const float phase = fast_atan2f_tab(cp.im, cp.re, p.atan_tab); // :247
+            const float phase = fast_atan2f_tab(cp.im, cp.re, atab); // :247
             if (lane == 0) {
                 const unsigned long long o0 = p.written + (unsigned long long)pk;
                 const unsigned long long o1 = o0 + p.mark_delay;

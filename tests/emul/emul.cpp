@@ -192,7 +192,7 @@ void emu_corr_main(const CorrParams* p, int nchan, int F)
 
 void emu_corr_resolve(const ResolveParams* p, int nchan)
 {
-    run_grid(nchan, 1, 64, 0, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
+    run_grid(nchan, 1, 64, 260 * 4, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
 }
 
 #ifdef MSK_EMU_STATS
