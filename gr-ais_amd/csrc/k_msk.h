@@ -3,9 +3,9 @@
 // :62-64 as a second, fully parallel kernel over the symbols the first one wrote.
 //
 // The loop is a strict recurrence through (mu, omega, iidx): the only parallelism
-// is across channels.  A workgroup carries 64 channels as 64 / LPW waves (LPW = 16 by
-// default: four waves, one per SIMD), each wave on its own; inside a wave all 64 lanes
-// stay enabled, lane i running the channel of lane i % LPW.  Every channel keeps a ring
+// is across channels.  A workgroup is msk_waves(LPW) waves of LPW channels each (LPW = 8
+// by default: four waves, one per SIMD, 32 channels), each wave on its own; inside a wave
+// all 64 lanes stay enabled, lane i carrying the channel of lane i % LPW.  Every channel keeps a ring
 // of its last 256 samples in LDS, stored slot-major (ring[slot][channel of the wave]): an
 // 8-tap read never conflicts however far the channels drift apart.  Chunk t = new samples
 // [64t, 64t+64) of every channel is fetched into registers one chunk ahead (16-byte loads,
@@ -19,7 +19,9 @@
 //    run in lock step in a counted loop with no test inside: the number of pairs every
 //    lane can run follows from a per-lane bound fast_lim on iidx (end of this
 //    general_work call, data horizon, next time_est tag) and the proven maximum advance
-//    of a pair; the wave takes the minimum;
+//    of a pair; the wave takes the minimum.  In a run two lanes share a channel's pair:
+//    one does the even iteration, the other the odd one at the same time (the even one
+//    has no feedback into mu), the squares cross over by a row swap;
 //  * lanes at an event run the reference's loop head in its order (events()) behind
 //    wave-uniform branches, then even and odd iterations as masked steps; parity and
 //    "parked" are 64-bit wave masks in scalar registers.  A tag reset can shift a lane
@@ -97,7 +99,7 @@ struct MskParams {
     // stride msk_lds_wave(lpw), lpw, 0); the CPU lane model, whose lanes are free-running
     // threads, gives each lane its own (stride msk_lds_ring(lpw) + MSK_TAGQ * 64 * 8, 64, 1).
     int lds_wave_stride, tq_stride, tq_private;
-    int lpw;           // channels (active lanes) per wave, = the build's LPW: 16, 32 or 64
+    int lpw;           // channels per wave, = the build's LPW: 4, 8, 16, 32 or 64
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -130,10 +132,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : (LPW == 16 ? 7 : (LPW == 8 ? 6 : 5))); // log2(SLOT_B)
     static_assert(LPW == 4 || LPW == 8 || LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
     typedef unsigned long long u64;
-    // A workgroup carries 64 channels as 64 / LPW waves, LPW lanes of each at work, every
-    // wave on its own (its own SIMD, rings, tag queue, pace).  Few channels per wave: events of
-    // other lanes stall a lane less, LDS returns fewer bytes per instruction, a chunk load
-    // touches fewer lines -- and the 64 channels still sit on one CU, leaving the others alone.
+    // A workgroup is msk_waves(LPW) waves of LPW channels, every wave on its own (its own
+    // SIMD, rings, tag queue, pace).  Few channels per wave: events of other lanes stall a
+    // lane less, LDS returns fewer bytes per instruction, a chunk load touches fewer lines.
     static_assert(64 % LPW == 0, "whole waves");
     // All 64 lanes stay: lane i runs the channel of lane i % LPW (identical arithmetic, identical
     // stores to identical addresses -- a wave64 instruction costs the same with 16 or 64 lanes

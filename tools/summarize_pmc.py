@@ -14,6 +14,20 @@ src = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 c, n = pmc_avg(glob.glob(os.path.join(src, "pmc_*")), "k_corr4_main")
 m, nm = pmc_avg(glob.glob(os.path.join(src, "msk_*")), "k_msk<")
+if not c:  # only the timing-recovery passes were collected this time
+    W, pairs = m["SQ_WAVES"], 16384
+    msk = {
+        "kernel": "k_msk<false,false,8> inside the whole-flowgraph chain (about 107 time_est tags per channel and step)",
+        "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex 'k_msk<' --output-format csv -- python bench.py "
+                   "--steps 2 --warmup 1 --single-chain --no-cpu-baseline  (two passes)",
+        "per_launch": m,
+        "per_wave_and_pair_of_iterations": {k: v / W / pairs for k, v in m.items() if k != "SQ_WAVES"},
+        "notes": "%d waves (workgroups of four, %d channels per wave), 16384 (even, odd) iteration pairs per channel and "
+                 "launch. Cycle counters are quad-cycles per wave: x4 for cycles." % (int(W), int(4096 / W)),
+    }
+    json.dump(msk, open("profiles/%s_msk_sq_counters.json" % tag, "w"), indent=1)
+    print(json.dumps(msk["per_wave_and_pair_of_iterations"]))
+    sys.exit(0)
 hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
 tiles = 4096 * 21 / (c["SQ_WAVES"] / 4)  # tiles walked by one workgroup (4 waves)
 pmc = {

@@ -71,7 +71,7 @@ if __name__ == "__main__":
     json.dump(line, open("profiles/%s_default_bench_line.json" % tag, "w"), indent=1)
     md = ["# rocprofv3 --kernel-trace --stats -- python bench.py   (MI355X, default run)", "",
           "Command on the GPU box: `cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats "
-          "--output-format csv -d gpurun_out/fin4/stats -- python bench.py`; summarised by `tools/summarize_profile.py`.", "",
+          "--output-format csv -d gpurun_out/<dir>/stats -- python bench.py`; summarised by `tools/summarize_profile.py`.", "",
           "bench.py's line of the same run (`%s_default_bench_line.json`): value %.0f complex MS/s, %.2f ms/step, "
           "`roofline.kernel_ms` %.3f (hipEvents over the timed region), `kernel_ms_alone` %.3f."
           % (tag, line["value"], line["ms_per_step"], line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms_alone"]), "",
