@@ -83,6 +83,9 @@ __global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk(MskParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
+    // the recurrence is latency-bound and issues little: its waves go first on their SIMDs, ahead
+    // of the throughput kernels of the other stream that share them
+    __builtin_amdgcn_s_setprio(3);
     msk_body<DevCtx, AUX, OSPS2, LPW>(cx, p);
 }
 
