@@ -126,7 +126,7 @@ constexpr int AGC8_G = 8;
 constexpr int AGC8_NG = AGC_TL / AGC8_G;               // groups with outputs per tile (= AGC_T)
 constexpr int AGC8_MAXQ = AGC_MAXW / AGC8_G;           // halo groups at most
 constexpr int AGC8_GROUPS = AGC8_NG + AGC8_MAXQ;       // group maxima per buffer
-constexpr int AGC8_LDS_BYTES = (2 * AGC8_GROUPS + AGC8_GROUPS * AGC8_G) * 4;
+constexpr int AGC8_LDS_BYTES = (2 * AGC8_GROUPS + AGC8_NG * AGC8_G) * 4; // group maxima x 2, prefix maxima of the NG groups windows end in
 static_assert(AGC8_NG == AGC_T, "one output group per thread");
 static_assert(AGC8_MAXQ <= AGC_T, "at most one halo group per thread");
 
@@ -140,7 +140,8 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     const int tile = cx.bx();
     float* GA = (float*)cx.lds();            // group maxima, ping
     float* GB = GA + AGC8_GROUPS;            // ... pong
-    float* PF = GB + AGC8_GROUPS;            // prefix maxima of every group: PF[g * 8 + k] = max(e[8g .. 8g+k])
+    float* PF = GB + AGC8_GROUPS;            // prefix maxima of the groups a window can end in, g = Q .. Q + NG - 1:
+                                             // PF[(g - Q) * 8 + k] = max(e[8g .. 8g+k])
     const int H = p.W - 1;
     const int Q = p.W / AGC8_G;
     const int n = p.n;
@@ -181,11 +182,18 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         for (int k = 0; k < AGC8_G; k++)
             e[k] = (g * AGC8_G + k < E) ? agc_envelope(v[k]) : 0.f; // (0 never wins: floor 1e-12)
         float run = e[0];
-        PF[g * AGC8_G] = run;
+        float pfx[AGC8_G];
+        pfx[0] = run;
 #pragma unroll
         for (int k = 1; k < AGC8_G; k++) {
             run = run < e[k] ? e[k] : run;
-            PF[g * AGC8_G + k] = run;
+            pfx[k] = run;
+        }
+        const int gp = g - Q;
+        if (gp >= 0 && gp < AGC8_NG) {
+#pragma unroll
+            for (int k = 0; k < AGC8_G; k++)
+                PF[gp * AGC8_G + k] = pfx[k];
         }
         GA[g] = run;
         if (keep) {
@@ -230,7 +238,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         // whole groups t+1 .. t+Q-1
         const float w1 = src[t + 1], w2 = src[t + Q - (1 << K)];
         const float gw = w1 < w2 ? w2 : w1;
-        const float* pf = PF + (t + Q) * AGC8_G; // prefix maxima of the group the window ends in
+        const float* pf = PF + t * AGC8_G; // prefix maxima of group t + Q, the one the window ends in
         cf o[AGC8_G];
 #pragma unroll
         for (int k = 0; k < AGC8_G; k++) {
