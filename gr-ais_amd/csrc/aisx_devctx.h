@@ -97,6 +97,9 @@ struct DevCtx {
             hi = mk(__uint_as_float(ra[1]), __uint_as_float(rb[1]));
         }
     }
+    // v of lane - 1 / lane + 1, 0 at the ends of the wave: one DPP move each (wave_shr:1 / wave_shl:1)
+    __device__ __forceinline__ unsigned lane_prev_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+    __device__ __forceinline__ unsigned lane_next_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // scheduling fences: the value is materialised here, in program order with the other pins

@@ -369,6 +369,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     ResolveParams r;
     r.abits = h->d_abits;
     r.abits_stride = h->abits_stride;
+    r.L = h->L;
     r.corr = p.corr;
     r.corr_stride = p.corr_stride;
     r.dense_corr = p.dense_corr;

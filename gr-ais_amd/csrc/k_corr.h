@@ -50,6 +50,33 @@ struct CorrParams {
     float thresh;
 };
 
+// The rare path of the main kernels' epilogue: this wave has at least one value above the
+// threshold.  Hits go to the sparse scratch and to the hit bitmask.  The resolver's 3-point centre
+// of mass (:219-227) also wants the two neighbours of a peak, which are usually below the
+// threshold: consecutive lanes hold consecutive outputs (value n1 of thread t is element
+// m = t + T n1 of the tile's transform, T a multiple of 64), so a lane whose neighbour lane has a
+// hit leaves its own value in the scratch too.  Which neighbours that covers follows from the
+// position alone -- element m +- 1 exists in the tile (N <= m +- 1 < F) and in the same wave
+// ((m & 63) != 63 resp. != 0) -- and the resolver applies the same rule (corr_resolve_body); a
+// neighbour in another wave or tile is recomputed there in direct form.
+template <class Ctx>
+AISX_DI void corr_emit_hits(Ctx& cx, const CorrParams& p, unsigned hit, unsigned vmask, const cf (&x)[16], cf* xcorr,
+                            unsigned long long* abits, int kb, int stride)
+{
+    // (the hit masks of lane - 1 and lane + 1; 0 past the ends of the wave)
+    const unsigned nb = (cx.lane_prev_u32(hit) | cx.lane_next_u32(hit)) & vmask & ~hit;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++) {
+        if (((hit | nb) >> n1) & 1u) {
+            const int k = kb + stride * n1;
+            if (!p.dense_corr)
+                xcorr[k] = x[n1];
+            if ((hit >> n1) & 1u)
+                cx.atomic_or64(&abits[k >> 6], 1ull << (k & 63));
+        }
+    }
+}
+
 // ---- forward passes shared by init and main -------------------------------
 // On entry x[n1] = w[t + 128*n1].  On exit v[h][k3] holds the spectrum at
 // position (q = t + 128*h, k3), i.e. logical index q*8 + k3.
@@ -259,17 +286,8 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
             hit |= (!(mg <= p.thresh)) ? (1u << n1) : 0u;
         }
         hit &= vmask;
-        if (cx.ballot(hit != 0u) != 0ull) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                if ((hit >> n1) & 1u) {
-                    const int k = kb + CF_T * n1;
-                    if (!p.dense_corr)
-                        xcorr[k] = x[n1];
-                    cx.atomic_or64(&abits[k >> 6], 1ull << (k & 63));
-                }
-            }
-        }
+        if (cx.ballot(hit != 0u) != 0ull)
+            corr_emit_hits(cx, p, hit, vmask, x, xcorr, abits, kb, CF_T);
         cx.sync();
     }
     // carry the last N stream samples to the next call (set_history(N+1), :95)
@@ -288,6 +306,7 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
 struct ResolveParams {
     const unsigned long long* abits; long abits_stride;
     const cf* corr; long corr_stride; int dense_corr;
+    int L; // outputs per tile of the main kernel (its FFT size is L + N)
     const cf* in; long in_stride;
     const cf* hist_in; // history the correlation of this call started from
     const cf* taps;    // d_symbols as stored (reversed conjugate), N entries
@@ -411,13 +430,28 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
                 const bool inside = pos >= 0 && pos < n;
                 const unsigned long long wsel = ((pos >> 6) == wa) ? WA : WB;
                 const bool above = inside && ((pos >> 6) <= wa + 1) && ((wsel >> (pos & 63)) & 1ull);
+                const unsigned long long AB = cx.ballot(above);
+                // below-threshold items the main kernel left in the scratch next to a hit
+                // (corr_emit_hits): element m of its tile, same tile and same wave as the hit
+                bool nbr = false;
+                if (!p.dense_corr) {
+                    const int F = p.L + p.N;
+                    const int t0 = ((q0 < 0 ? 0 : q0) / p.L) * p.L; // first output of the tile the window starts in
+                    int m = pos - t0 + p.N;
+                    if (m >= F)
+                        m -= p.L;
+                    const bool left_hit = lane > 0 && ((AB >> (lane - 1)) & 1ull);   // item pos - 1 is a hit
+                    const bool right_hit = lane < 63 && ((AB >> (lane + 1)) & 1ull); // item pos + 1 is a hit
+                    nbr = inside && !above &&
+                          ((left_hit && m - 1 >= p.N && ((m - 1) & 63) != 63) || (right_hit && m + 1 < F && ((m + 1) & 63) != 0));
+                }
                 cf cv = mk(0.f, 0.f);
-                if (inside && (above || p.dense_corr))
+                if (inside && (above || nbr || p.dense_corr))
                     cv = corr[pos];
                 const float mg = mag2(cv);
                 // climb: from item q to q + 1 while q + 1 is above threshold and larger
                 const float mg_next = cx.shfl_down_f32(mg, 1);
-                const unsigned long long AB = cx.ballot(above);
+                const unsigned long long HV = AB | cx.ballot(nbr); // lanes whose value is in hand
                 const bool step_ok = (lane < 63) && ((AB >> (lane + 1)) & 1ull) && (mg < mg_next);
                 const unsigned long long C = cx.ballot(step_ok);
                 const int run = cx.ctz64(~(C >> 1)); // consecutive climbs from lane 1 (= pk)
@@ -429,8 +463,8 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
                 pk = q0 + jp;
                 cp = mk(cx.shfl_f32(cv.re, jp), cx.shfl_f32(cv.im, jp));
                 mp = mag2(cp);
-                have0 = p.dense_corr || ((AB >> (jp - 1)) & 1ull);
-                have2 = p.dense_corr || ((AB >> (jp + 1)) & 1ull);
+                have0 = p.dense_corr || ((HV >> (jp - 1)) & 1ull);
+                have2 = p.dense_corr || ((HV >> (jp + 1)) & 1ull);
                 m0 = cx.shfl_f32(mg, jp - 1);
                 m2 = cx.shfl_f32(mg, jp + 1);
                 break;

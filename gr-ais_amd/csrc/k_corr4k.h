@@ -269,17 +269,8 @@ AISX_DI void corr4_main_body(Ctx& cx, const CorrParams& p)
             hit |= (!(mg <= p.thresh)) ? (1u << n1) : 0u;
         }
         hit &= vmask;
-        if (cx.ballot(hit != 0u) != 0ull) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
-                if ((hit >> n1) & 1u) {
-                    const int k = kb + CF4_T * n1;
-                    if (!p.dense_corr)
-                        xcorr[k] = x[n1];
-                    cx.atomic_or64(&abits[k >> 6], 1ull << (k & 63));
-                }
-            }
-        }
+        if (cx.ballot(hit != 0u) != 0ull)
+            corr_emit_hits(cx, p, hit, vmask, x, xcorr, abits, kb, CF4_T);
         cx.sync();
     }
     // carry the last N stream samples to the next call (set_history(N+1), :95)

@@ -124,6 +124,8 @@ struct EmuCtx {
         memcpy(&lo, &b[wave_base() + (ln & ~W)], sizeof(cf));
         memcpy(&hi, &b[wave_base() + (ln | W)], sizeof(cf));
     }
+    unsigned lane_prev_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l > 0 ? l - 1 : l); return l > 0 ? r : 0u; }
+    unsigned lane_next_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l < 63 ? l + 1 : l); return l < 63 ? r : 0u; }
     unsigned long long shfl_u64(unsigned long long v, int src) const { return xchg(v, src); }
     float shfl_f32(float v, int src) const { return xchg(v, src); }
     int shfl_i32(int v, int src) const { return xchg(v, src); }
@@ -282,7 +284,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.n = n; p.N = h->N; p.L = h->L; p.nseg = nseg; p.tiles_per_seg = tps; p.thresh = h->cs.thresh;
     emu_corr_main(&p, h->nchan, h->F);
     ResolveParams r;
-    r.abits = p.abits; r.abits_stride = astride; r.corr = p.corr; r.corr_stride = p.corr_stride; r.dense_corr = p.dense_corr;
+    r.abits = p.abits; r.abits_stride = astride; r.L = h->L; r.corr = p.corr; r.corr_stride = p.corr_stride; r.dense_corr = p.dense_corr;
     r.in = in; r.in_stride = in_stride; r.hist_in = p.hist_in; r.taps = h->cs.symbols.data();
     r.n = n; r.N = h->N; r.isps = h->cs.isps; r.mark_delay = h->cs.mark_delay; r.written = h->written;
     r.emit_port1 = corr ? 1 : 0; r.tags = tags; r.tag_cap = tag_cap; r.tag_count = tag_count; r.atan_tab = aisx_atan_table;
