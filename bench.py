@@ -210,25 +210,27 @@ def main():
                                 preamble_symbols=tmpl)
         corr = dem.preamble_detect
         corr.set_profiling(True)
-        # preallocated inter-stage buffers, double-buffered by step parity: the timing
-        # recovery of step k (latency-bound, one wave per CU) runs on its own stream under the
-        # bandwidth-bound stages of step k+1
-        y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(2)]
+        # preallocated inter-stage buffers, three of each in rotation: the timing recovery of
+        # step k (latency-bound) runs on its own stream under the streaming stages of step k+1;
+        # with a third buffer the streaming stages of step k+2 need not wait for it either
+        # (the two sides take about the same time, and every wait of one for the other adds up)
+        NBUF = 3
+        y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(NBUF)]
         cap = dem.clockrec.out_capacity
         outs = [dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
-                     produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(2)]
+                     produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(NBUF)]
         s_main, s_msk = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
         s_tail = torch.cuda.Stream(device=device)  # the bit tail of step k runs beside the recovery of step k+1
         dem.clockrec.set_tail_stream(s_tail)
-        msk_done = [None, None]
+        msk_done = [None] * NBUF
         state = dict(k=0)
 
         def step():
             k = state["k"]
-            par = k & 1
+            par = k % NBUF
             with torch.cuda.stream(s_main):
                 if msk_done[par] is not None:
-                    s_main.wait_event(msk_done[par])  # step k-2 released y_corr[par] and its tags
+                    s_main.wait_event(msk_done[par])  # step k-3 released y_corr[par] and its tags
                 y = x
                 if stock:
                     y, _ = dem.freq_sync.work(y)

@@ -143,10 +143,11 @@ struct aisx_corr {
     long abits_stride = 0;
     cf* d_scratch = nullptr;
     long scratch_stride = 0;
-    // tags are double-buffered by call parity so that a consumer on another stream
-    // (the timing-recovery kernel) can still read call k's tags while call k+1 runs
-    tag_rec* d_tags2[2] = { nullptr, nullptr };
-    int* d_tag_count2[2] = { nullptr, nullptr };
+    // tags rotate through three buffers so that a consumer on another stream (the
+    // timing-recovery stage) can still read call k's tags while calls k+1 and k+2 run
+    static constexpr int NTAGBUF = 3;
+    tag_rec* d_tags2[NTAGBUF] = { nullptr, nullptr, nullptr };
+    int* d_tag_count2[NTAGBUF] = { nullptr, nullptr, nullptr };
     int tag_cur = 0; // buffer the LAST call wrote
     tag_rec* d_tags = nullptr;
     int* d_tag_count = nullptr;
@@ -230,7 +231,7 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     CK(dev_alloc(&h->d_hist[1], (size_t)nchan * nsym));
     CK(dev_alloc(&h->d_abits, (size_t)nchan * h->abits_stride));
     CK(dev_alloc(&h->d_scratch, (size_t)nchan * h->scratch_stride, false));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < aisx_corr::NTAGBUF; k++) {
         CK(dev_alloc(&h->d_tags2[k], (size_t)nchan * h->tag_cap));
         CK(dev_alloc(&h->d_tag_count2[k], nchan));
     }
@@ -261,7 +262,7 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_hist[1]);
     dev_free(h->d_abits);
     dev_free(h->d_scratch);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < aisx_corr::NTAGBUF; k++) {
         dev_free(h->d_tags2[k]);
         dev_free(h->d_tag_count2[k]);
     }
@@ -383,7 +384,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.mark_delay = h->mark_delay;
     r.written = h->written;
     r.emit_port1 = d_corr ? 1 : 0;
-    h->tag_cur ^= 1;
+    h->tag_cur = (h->tag_cur + 1) % aisx_corr::NTAGBUF;
     h->d_tags = h->d_tags2[h->tag_cur];
     h->d_tag_count = h->d_tag_count2[h->tag_cur];
     r.tags = h->d_tags;
