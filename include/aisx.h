@@ -108,7 +108,9 @@ int aisx_corr_last_kernel_ms(aisx_corr* h, float* ms);
 /* durations of the main kernel in the calls made since profiling was switched on
  * (the most recent 64 at most), oldest first */
 int aisx_corr_kernel_ms_history(aisx_corr* h, float* ms, int cap, int* n);
-/* device tag buffers of the last call: tags[c * cap + k], k < min(counts[c], cap) */
+/* device tag buffers of the last call: tags[c * cap + k], k < min(counts[c], cap).  The
+ * handle rotates through three sets: the pointers of call k stay valid (for a consumer on
+ * another stream) until call k+3 is launched. */
 int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int** d_counts, int* cap);
 /* copy the last call's tags to the host, channel by channel in emission order;
  * synchronises the stream.  Returns AISX_ERR_OVERFLOW if a channel overflowed
