@@ -88,6 +88,43 @@ def msk_stream():
     return d
 
 
+def agc_stream():
+    """feedforward_agc_cc(W, 2.0) for W = 512 (stock) and 37, ragged calls with carried history;
+    a silent stretch (the 1e-12 floor) and a NaN sample included."""
+    lens = [1500, 1, 700, 1895]
+    rng = np.random.default_rng(5)
+    x = (rng.normal(size=sum(lens)) + 1j * rng.normal(size=sum(lens))).astype(np.complex64)
+    x *= np.linspace(0.05, 20, x.size).astype(np.float32)
+    x[600:1300] = 0
+    x[2000] = np.nan
+    d = dict(x=x, lens=np.array(lens, np.int32), reference=np.float32(2.0))
+    for W in (512, 37):
+        a = orc.Agc(W, 2.0)
+        k = 0
+        for i, L in enumerate(lens):
+            d["w%d_out%d" % (W, i)] = a.work(x[k:k + L])
+            k += L
+    return d
+
+
+def freqsync_stream():
+    """square_and_fft_sync_cc(38400, 9600, 1024): NCO-corrected output and one frequency
+    estimate per 1024-vector, ragged calls (a partial vector is carried), an all-zero vector
+    (the stale-maxpos rule, lib/freqest_impl.cc:68 vs :74)."""
+    lens = [4096, 1000, 24, 3072]
+    x, _ = synth.make_channel(301, sum(lens), "P", SPS, amp=0.5, cfo_max=500.0)
+    x[2048:3072] = 0
+    f = orc.FreqSync(38400.0, 9600.0, 1024)
+    d = dict(x=x, lens=np.array(lens, np.int32))
+    k = 0
+    for i, L in enumerate(lens):
+        out, fh = f.process(x[k:k + L])
+        d["out%d" % i] = out
+        d["fhat%d" % i] = fh
+        k += L
+    return d
+
+
 def chain(stages, seed0, amp, cfo):
     """python/ais_demod.py:56 for two channels, two steps of 8192 samples: stages = 0 is the
     hot path alone (corr_est -> msk -> bits), stages = 3 the whole connect order."""
@@ -116,6 +153,8 @@ def main():
         "corr_kat.npz": corr_kat(),
         "corr_stream.npz": corr_stream(),
         "msk_stream.npz": msk_stream(),
+        "agc_stream.npz": agc_stream(),
+        "freqsync_stream.npz": freqsync_stream(),
         "chain_core.npz": chain(0, 900, 1.0, 15.0),
         "chain_stock.npz": chain(3, 700, 0.3, 500.0),
     }
