@@ -14,10 +14,10 @@ src = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 c, n = pmc_avg(glob.glob(os.path.join(src, "pmc_*")), "k_corr4_main")
 m, nm = pmc_avg(glob.glob(os.path.join(src, "msk_*")), "k_msk<")
-if not c:  # only the timing-recovery passes were collected this time
+def write_msk(m):
     W, pairs = m["SQ_WAVES"], 16384
     msk = {
-        "kernel": "k_msk<false,false,8> inside the whole-flowgraph chain (about 107 time_est tags per channel and step)",
+        "kernel": "k_msk<false,false,%d> inside the whole-flowgraph chain (about 107 time_est tags per channel and step)" % int(4096 / W),
         "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex 'k_msk<' --output-format csv -- python bench.py "
                    "--steps 2 --warmup 1 --single-chain --no-cpu-baseline  (two passes)",
         "per_launch": m,
@@ -27,6 +27,10 @@ if not c:  # only the timing-recovery passes were collected this time
     }
     json.dump(msk, open("profiles/%s_msk_sq_counters.json" % tag, "w"), indent=1)
     print(json.dumps(msk["per_wave_and_pair_of_iterations"]))
+
+
+if not c:  # only the timing-recovery passes were collected this time
+    write_msk(m)
     sys.exit(0)
 hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
 tiles = 4096 * 21 / (c["SQ_WAVES"] / 4)  # tiles walked by one workgroup (4 waves)
@@ -52,16 +56,6 @@ pmc = {
                 100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]),
 }
 json.dump(pmc, open("profiles/%s_corr_main_pmc.json" % tag, "w"), indent=1)
-W, pairs = m["SQ_WAVES"], 16384
-msk = {
-    "kernel": "k_msk<false,false,16> inside the whole-flowgraph chain (about 107 time_est tags per channel and step)",
-    "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex 'k_msk<' --output-format csv -- python bench.py --steps 2 "
-               "--warmup 1 --single-chain --no-cpu-baseline  (two passes)",
-    "per_launch": m,
-    "per_wave_and_pair_of_iterations": {k: v / W / pairs for k, v in m.items() if k != "SQ_WAVES"},
-    "notes": "256 waves (64 workgroups of four), 16384 (even, odd) iteration pairs per channel and launch. Cycle counters are "
-             "quad-cycles per wave: x4 for cycles.",
-}
-json.dump(msk, open("profiles/%s_msk_sq_counters.json" % tag, "w"), indent=1)
 print(pmc["notes"])
-print(json.dumps(msk["per_wave_and_pair_of_iterations"]))
+if m:
+    write_msk(m)
