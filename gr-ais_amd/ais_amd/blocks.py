@@ -67,6 +67,7 @@ class corr_est_cc:
     def set_symbols(self, symbols):
         s = np.ascontiguousarray(symbols, dtype=np.complex64)
         check(_lib.lib().aisx_corr_set_symbols(self._h, s.ctypes.data_as(C.c_void_p), s.size), "set_symbols")
+        self._N = s.size
 
     def history(self):
         return _lib.lib().aisx_corr_history(self._h)
@@ -174,12 +175,14 @@ class msk_timing_recovery_cc:
 
     def set_limit(self, limit):
         check(_lib.lib().aisx_msk_set_limit(self._h, float(limit)), "set_limit")
+        self.out_capacity = _lib.lib().aisx_msk_out_capacity(self._h)
 
     def get_limit(self):
         return _lib.lib().aisx_msk_get_limit(self._h)
 
     def set_sps(self, sps):
         check(_lib.lib().aisx_msk_set_sps(self._h, float(sps)), "set_sps")
+        self.out_capacity = _lib.lib().aisx_msk_out_capacity(self._h)
 
     def get_sps(self):
         return _lib.lib().aisx_msk_get_sps(self._h)
@@ -205,6 +208,29 @@ class msk_timing_recovery_cc:
         mu = o.get("mu") if "mu" in o else (torch.empty((self.nchan, cap), dtype=torch.float32, device=dev) if want_aux else None)
         bits = o.get("bits") if "bits" in o else (torch.empty((self.nchan, cap), dtype=torch.uint8, device=dev) if want_bits else None)
         prod = o.get("produced") if "produced" in o else torch.empty(self.nchan, dtype=torch.int32, device=dev)
+        stride = None
+        for name, t, dt in (("syms", syms, torch.complex64), ("err", err, torch.float32), ("mu", mu, torch.float32),
+                            ("bits", bits, torch.uint8)):
+            if t is None:
+                continue
+            if (t.dim() != 2 or t.shape[0] != self.nchan or t.dtype != dt or t.stride(1) != 1 or not t.is_cuda
+                    or t.shape[1] < 1 or t.stride(0) < t.shape[1]):
+                raise ValueError("msk_timing_recovery_cc.work: outs[%r] must be a (nchan, cap) %s device tensor with "
+                                 "unit inner stride" % (name, dt))
+            if stride is None:
+                stride, width = t.stride(0), t.shape[1]
+            elif t.stride(0) != stride:
+                raise ValueError("msk_timing_recovery_cc.work: all output tensors must share one row stride")
+            else:
+                width = min(width, t.shape[1])
+        if prod.dim() != 1 or prod.shape[0] < self.nchan or prod.dtype != torch.int32 or not prod.is_cuda:
+            raise ValueError("msk_timing_recovery_cc.work: outs['produced'] must be an int32 device tensor of nchan items")
+        if stride is None:
+            stride = width = cap
+        if width < stride:
+            # rows narrower than their stride (a column slice): the kernel bounds its writes by the
+            # stride it is given, so hand it rows it owns entirely
+            raise ValueError("msk_timing_recovery_cc.work: output rows must be as wide as their stride")
         if tags_ptrs is not None:
             tptr, cptr, tcap = tags_ptrs  # as returned by corr_est_cc.tags_device() right after its work()
         elif tags_from is not None:
@@ -214,7 +240,7 @@ class msk_timing_recovery_cc:
         check(_lib.lib().aisx_msk_process_stream(
             self._h, x.data_ptr(), x.stride(0), n, tptr, cptr, tcap,
             syms.data_ptr() if syms is not None else None, err.data_ptr() if err is not None else None,
-            mu.data_ptr() if mu is not None else None, bits.data_ptr() if bits is not None else None, cap,
+            mu.data_ptr() if mu is not None else None, bits.data_ptr() if bits is not None else None, stride,
             prod.data_ptr(), _stream_ptr(stream)), "msk_timing_recovery_cc.work")
         return dict(syms=syms, err=err, mu=mu, bits=bits, produced=prod)
 
@@ -306,6 +332,16 @@ class freqest:
                                            _stream_ptr(stream)), "freqest.work")
         return out[:, :nvec]
 
+    def work_host(self, vecs):
+        """GNU Radio path: `vecs` = input_items[0], whole fftlen-vectors on the host; returns
+        output_items[0] (one float per vector).  One call = one freqest::work call."""
+        v = np.ascontiguousarray(vecs, dtype=np.complex64).reshape(-1)
+        nvec = v.size // self.fftlen
+        out = np.zeros(max(nvec, 1), dtype=np.float32)
+        got = check(_lib.lib().aisx_freqest_work_host(self._fs._h, nvec, v.ctypes.data_as(C.c_void_p),
+                                                      out.ctypes.data_as(C.c_void_p)), "freqest.work_host")
+        return out[:got]
+
 
 class feedforward_agc_cc:
     """analog.feedforward_agc_cc(nsamples, reference) as used at python/ais_demod.py:35."""
@@ -325,6 +361,10 @@ class feedforward_agc_cc:
 
     def reset(self):
         check(_lib.lib().aisx_agc_reset(self._h), "reset")
+
+    def set_floor(self, floor_env):
+        """initial max_env of the window search: 1e-4 (GNU Radio 3.7/3.8, the default) or 1e-12."""
+        check(_lib.lib().aisx_agc_set_floor(self._h, float(floor_env)), "set_floor")
 
     def work(self, x, out=None, stream=None):
         x = _dev_c64(x, self.nchan)

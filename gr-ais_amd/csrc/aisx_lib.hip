@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "aisx_devctx.h"
@@ -154,6 +155,7 @@ struct aisx_corr {
     float* d_atan = nullptr;
     uint64_t written = 0;
     int last_emit_port1 = 0;
+    int corr_hist_zero = 0; // set by set_symbols(), consumed by the next call
     int prof = 0; // aisx_corr_set_profiling
     static constexpr int NEV = 64; // ring of event pairs: one per call, read back after the timed region
     hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
@@ -290,16 +292,63 @@ extern "C" int aisx_corr_symbols(const aisx_corr* h, aisx_cf32* out, int cap)
 
 extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int nsym)
 {
-    if (!h || !symbols)
+    if (!h || !symbols || nsym < 1)
         return AISX_ERR_INVALID;
-    if (nsym != h->N) {
-        set_err("aisx_corr_set_symbols: length %d != %d (re-create the block to change the template length)", nsym,
-                h->N);
+    if (nsym > CORR_MAX_TEMPLATE) {
+        set_err("aisx_corr_set_symbols: template of %d samples exceeds the %d supported (F = %d build)", nsym,
+                CORR_MAX_TEMPLATE, CF4_F);
         return AISX_ERR_INVALID;
     }
-    // lib/corr_est_cc_impl.cc:132-162: stored as given, threshold untouched
+    AISX_HIPCHK(hipDeviceSynchronize()); // (the caller holds d_setlock in the reference, :135: no work() in flight)
+    int rc;
+    if (nsym != h->N) {
+        // lib/corr_est_cc_impl.cc:144-158: the FFT filter is rebuilt for the new length, output
+        // multiple, history (nsym + 1) and sample delay follow it.  The block's history: the
+        // scheduler would hand the nsym items before the next new one; this handle holds the
+        // last N of them -- kept right-aligned, older ones (nsym > N) read as zero.
+        const int Nold = h->N, keep = std::min(Nold, nsym);
+        cf* nh[2] = { nullptr, nullptr };
+        cf* ntaps = nullptr;
+        if ((rc = dev_alloc(&nh[0], (size_t)h->nchan * nsym)) != AISX_OK || (rc = dev_alloc(&nh[1], (size_t)h->nchan * nsym)) != AISX_OK ||
+            (rc = dev_alloc(&ntaps, nsym)) != AISX_OK) {
+            dev_free(nh[0]);
+            dev_free(nh[1]);
+            dev_free(ntaps);
+            return rc;
+        }
+        AISX_HIPCHK(hipMemcpy2D(nh[0] + (nsym - keep), sizeof(cf) * nsym, h->d_hist[h->hist_cur] + (Nold - keep), sizeof(cf) * Nold,
+                                sizeof(cf) * keep, h->nchan, hipMemcpyDeviceToDevice));
+        dev_free(h->d_hist[0]);
+        dev_free(h->d_hist[1]);
+        dev_free(h->d_taps);
+        h->d_hist[0] = nh[0];
+        h->d_hist[1] = nh[1];
+        h->d_taps = ntaps;
+        h->hist_cur = 0;
+        const int F = corr_pick_fft(nsym);
+        if (F != h->F) {
+            dev_free(h->d_tapspad);
+            dev_free(h->d_Hpos);
+            dev_free(h->d_wtab);
+            if ((rc = dev_alloc(&h->d_tapspad, F)) != AISX_OK || (rc = dev_alloc(&h->d_Hpos, F)) != AISX_OK ||
+                (rc = dev_alloc(&h->d_wtab, F)) != AISX_OK)
+                return rc;
+            std::vector<cf> w = corr_wtab(F);
+            AISX_HIPCHK(hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * F, hipMemcpyHostToDevice));
+            h->F = F;
+        }
+        h->N = nsym;
+        h->L = h->F - nsym;
+        h->symbols.resize(nsym);
+        // :143-144 set_output_multiple(d_filter->set_taps(d_symbols))
+        h->out_multiple = (int)(2 * pow(2.0, ceil(log((double)nsym) / log(2.0)))) - nsym + 1;
+    }
+    // :136 stored as given (no conjugate / reverse, unlike the constructor :58-63); d_thresh untouched
     memcpy(h->symbols.data(), symbols, sizeof(cf) * nsym);
-    h->mark_delay = h->mark_delay >= (unsigned)nsym ? (unsigned)nsym - 1 : h->mark_delay;
+    h->mark_delay = h->mark_delay >= (unsigned)nsym ? (unsigned)nsym - 1 : h->mark_delay; // :160-161
+    // [GR] fft_filter_ccc::set_taps zeroes the filter's tail: the correlation of the next call
+    // starts from zeros, the delayed pass-through from the history as before
+    h->corr_hist_zero = 1;
     return corr_upload_taps(h);
 }
 
@@ -316,6 +365,7 @@ extern "C" int aisx_corr_reset(aisx_corr* h)
         return AISX_ERR_INVALID;
     AISX_HIPCHK(hipMemset(h->d_hist[0], 0, sizeof(cf) * (size_t)h->nchan * h->N));
     AISX_HIPCHK(hipMemset(h->d_hist[1], 0, sizeof(cf) * (size_t)h->nchan * h->N));
+    AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fill vs. the caller's non-blocking streams)
     h->hist_cur = 0;
     h->written = 0;
     return AISX_OK;
@@ -328,6 +378,22 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         (d_corr && corr_stride < n)) {
         set_err("aisx_corr_process: bad argument (n=%d, max_items=%d)", n, h ? h->max_items : -1);
         return AISX_ERR_INVALID;
+    }
+    {
+        // out is the input delayed by N and is written while neighbouring tiles are still being
+        // read (the resolver reads d_in once more after that): the three buffers must be distinct
+        auto span = [&](const void* b, long stride) {
+            const char* lo = (const char*)b;
+            return std::make_pair(lo, lo + sizeof(cf) * ((size_t)(h->nchan - 1) * (size_t)stride + (size_t)n));
+        };
+        auto overlap = [](std::pair<const char*, const char*> a, std::pair<const char*, const char*> b) {
+            return a.first < b.second && b.first < a.second;
+        };
+        const auto ri = span(d_in, in_stride), ro = span(d_out, out_stride);
+        if (overlap(ri, ro) || (d_corr && (overlap(ri, span(d_corr, corr_stride)) || overlap(ro, span(d_corr, corr_stride))))) {
+            set_err("aisx_corr_process: d_in, d_out and d_corr must not overlap (no in-place operation)");
+            return AISX_ERR_INVALID;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     int nseg, tps;
@@ -354,6 +420,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     p.nseg = nseg;
     p.tiles_per_seg = tps;
     p.thresh = h->thresh;
+    p.corr_hist_zero = h->corr_hist_zero;
     const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
@@ -377,6 +444,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.in = p.in;
     r.in_stride = in_stride;
     r.hist_in = p.hist_in;
+    r.corr_hist_zero = h->corr_hist_zero;
     r.taps = h->d_taps;
     r.n = n;
     r.N = h->N;
@@ -394,6 +462,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
     AISX_HIPCHK(hipGetLastError());
     h->hist_cur ^= 1;
+    h->corr_hist_zero = 0;
     h->written += (uint64_t)n;
     h->last_emit_port1 = r.emit_port1;
     return AISX_OK;
@@ -580,6 +649,29 @@ struct aisx_msk {
     int st_in_cap = 0, st_out_cap = 0, st_tag_cap = 0;
 };
 
+// What the kernel's LDS rings and the carry buffer are sized for (k_msk.h): one general_work call
+// of a single output must fit the carry (forecast(1) + the pre-item), a pair of iterations must
+// stay well inside a 64-sample chunk, and omega must stay positive under the clip of :182
+// (omega in [d_sps - |limit|, d_sps + |limit|], `limit` is absolute).
+static int msk_check_geometry(float d_sps, float gain, float limit)
+{
+    const float wmin = d_sps - fabsf(limit), wmax = d_sps + fabsf(limit);
+    if (!(wmin >= 0.5f) || msk_forecast(d_sps, 1) + 1 > aisx_msk::carry_cap || !(2.f * wmax + 3.f * fabsf(gain) <= 32.f)) {
+        set_err("msk_timing_recovery: sps/2 = %g with limit %g and gain %g is outside what the gfx950 kernel is sized for "
+                "(sps/2 - |limit| >= 0.5, forecast(1) < %d items, 2 (sps/2 + |limit|) + 3 |gain| <= 32)",
+                d_sps, limit, gain, aisx_msk::carry_cap);
+        return AISX_ERR_INVALID;
+    }
+    return AISX_OK;
+}
+// items per channel one call can produce at most: every output consumes at least
+// 2 (d_sps - |limit|) input items (osps = 1; half of that for osps = 2)
+static int msk_out_cap(const aisx_msk* h)
+{
+    const double wmin = (double)h->d_sps - fabs((double)h->limit);
+    return (int)ceil((h->max_items + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16;
+}
+
 static int msk_init_state(aisx_msk* h)
 {
     const int nc = h->nchan;
@@ -625,6 +717,8 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     int rc = require_device();
     if (rc != AISX_OK)
         return rc;
+    if ((rc = msk_check_geometry(msk_setup(sps, gain).d_sps, gain, limit)) != AISX_OK)
+        return rc;
     aisx_msk* h = new aisx_msk();
     h->nchan = nchan;
     h->max_items = max_items;
@@ -633,7 +727,7 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->d_sps = msk_setup(sps, gain).d_sps; // :70
     h->gain = gain;
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
-    h->out_cap = (int)((max_items + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * osps + 16;
+    h->out_cap = msk_out_cap(h);
     {
         // 8 channels per wave, four waves (one per SIMD), 32 channels and ~84 KB of LDS per
         // workgroup: fewer lanes per wave = fewer events of other lanes to wait for (a tag costs
@@ -756,14 +850,18 @@ extern "C" int aisx_msk_set_gain(aisx_msk* h, float gain)
         return AISX_ERR_OUT_OF_RANGE;
     }
     h->gain_omega = (float)(gain * gain * 0.25);
-    return AISX_OK;
+    return msk_check_geometry(h->d_sps, gain, h->limit);
 }
 extern "C" float aisx_msk_get_gain(const aisx_msk* h) { return h ? h->gain : 0.f; }
 extern "C" int aisx_msk_set_limit(aisx_msk* h, float limit)
 {
     if (!h)
         return AISX_ERR_INVALID;
+    const int rc = msk_check_geometry(h->d_sps, h->gain, limit);
+    if (rc != AISX_OK)
+        return rc; // (the reference accepts any value, :90-92; this build is sized, see msk_check_geometry)
     h->limit = limit;
+    h->out_cap = msk_out_cap(h); // callers size their outputs by aisx_msk_out_capacity(): ask again
     return AISX_OK;
 }
 extern "C" float aisx_msk_get_limit(const aisx_msk* h) { return h ? h->limit : 0.f; }
@@ -771,7 +869,11 @@ extern "C" int aisx_msk_set_sps(aisx_msk* h, float sps)
 {
     if (!h)
         return AISX_ERR_INVALID;
+    const int rc = msk_check_geometry((float)(sps / 2.0), h->gain, h->limit);
+    if (rc != AISX_OK)
+        return rc;
     h->d_sps = (float)(sps / 2.0); // :70
+    h->out_cap = msk_out_cap(h);
     std::vector<float> om(h->nchan, h->d_sps); // :71 d_omega = d_sps
     AISX_HIPCHK(hipMemcpy(h->d_omega, om.data(), sizeof(float) * h->nchan, hipMemcpyHostToDevice));
     return AISX_OK;
@@ -782,7 +884,16 @@ extern "C" int aisx_msk_forecast(const aisx_msk* h, int noutput_items)
     return h ? msk_forecast(h->d_sps, noutput_items) : AISX_ERR_INVALID;
 }
 extern "C" int aisx_msk_out_capacity(const aisx_msk* h) { return h ? h->out_cap : AISX_ERR_INVALID; }
-extern "C" int aisx_msk_reset(aisx_msk* h) { return h ? msk_init_state(h) : AISX_ERR_INVALID; }
+extern "C" int aisx_msk_reset(aisx_msk* h)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    const int rc = msk_init_state(h);
+    if (rc != AISX_OK)
+        return rc;
+    AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fills vs. the caller's non-blocking streams)
+    return AISX_OK;
+}
 
 static void msk_fill_common(aisx_msk* h, MskParams& p)
 {
@@ -936,7 +1047,8 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     h->cur ^= 1;
     if (d_bits) {
         // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
-        const int max_out = std::min<long>(p.out_cap, (long)((n + aisx_msk::carry_cap) / (2.0 * h->d_sps * 0.97)) * h->osps + 16);
+        const double wmin = (double)h->d_sps - fabs((double)h->limit);
+        const int max_out = std::min<long>(p.out_cap, (long)ceil((n + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16);
         hipStream_t ts = (hipStream_t)stream;
         if (h->tail_on) { // the bit tail has no part in the recurrence: let the next call start
             AISX_HIPCHK(hipEventRecord(h->ev_msk, (hipStream_t)stream));

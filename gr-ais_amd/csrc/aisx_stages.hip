@@ -52,6 +52,10 @@ struct aisx_freqsync {
     cf* d_wtab = nullptr;
     int* d_maxpos = nullptr;
     float* d_phase = nullptr;
+    // GNU Radio path staging (aisx_freqest_work_host)
+    cf* d_st_vec = nullptr;
+    float* d_st_out = nullptr;
+    int st_cap = 0;
 };
 
 extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, double bits_per_sec, int fftlen, int nchan,
@@ -121,6 +125,8 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
     dev_free(h->d_wtab);
     dev_free(h->d_maxpos);
     dev_free(h->d_phase);
+    dev_free(h->d_st_vec);
+    dev_free(h->d_st_out);
     delete h;
     return AISX_OK;
 }
@@ -130,6 +136,7 @@ extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
     if (!h)
         return AISX_ERR_INVALID;
     AISX_HIPCHK(hipMemset(h->d_phase, 0, sizeof(float) * h->nchan));
+    AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fill vs. the caller's non-blocking streams)
     h->npend = 0;
     h->cur = 0;
     return AISX_OK;
@@ -209,10 +216,42 @@ extern "C" int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long
     return AISX_OK;
 }
 
+// freqest::work(noutput_items, input_items, output_items) as the scheduler calls it
+// (lib/freqest_impl.h:39-41, lib/freqest_impl.cc:57-88): input_items[0] = noutput_items vectors of
+// fftlen gr_complex (item size 8 * fftlen, :43), output_items[0] = one float per vector (:44).
+extern "C" int aisx_freqest_work_host(aisx_freqsync* h, int noutput_items, const aisx_cf32* in, float* out)
+{
+    if (!h || !in || !out || noutput_items < 0)
+        return AISX_ERR_INVALID;
+    if (h->nchan != 1) {
+        set_err("aisx_freqest_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
+        return AISX_ERR_INVALID;
+    }
+    if (noutput_items == 0)
+        return 0;
+    int rc;
+    if (noutput_items > h->st_cap) {
+        dev_free(h->d_st_vec);
+        dev_free(h->d_st_out);
+        h->st_cap = 0;
+        if ((rc = dev_alloc(&h->d_st_vec, (size_t)noutput_items * h->fftlen, false)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_st_out, noutput_items, false)) != AISX_OK)
+            return rc;
+        h->st_cap = noutput_items;
+    }
+    const size_t nitems = (size_t)noutput_items * h->fftlen;
+    AISX_HIPCHK(hipMemcpy(h->d_st_vec, in, sizeof(cf) * nitems, hipMemcpyHostToDevice));
+    if ((rc = aisx_freqest_work(h, (const aisx_cf32*)h->d_st_vec, (long)nitems, h->d_st_out, noutput_items, noutput_items,
+                                nullptr)) != AISX_OK)
+        return rc;
+    AISX_HIPCHK(hipMemcpy(out, h->d_st_out, sizeof(float) * noutput_items, hipMemcpyDeviceToHost));
+    return noutput_items; // :87 return noutput_items
+}
+
 // ---------------------------------------------------------------------------
 struct aisx_agc {
     int nchan = 0, W = 0, max_items = 0;
-    float reference = 0;
+    float reference = 0, floor_env = AGC_FLOOR_DEFAULT;
     cf* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
 };
@@ -243,7 +282,24 @@ extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, in
         aisx_agc_destroy(h);
         return rc;
     }
+    // dev_alloc's zero fill runs on the null stream; callers launch on their own (non-blocking)
+    // streams, which do not order against it
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_err("aisx_agc_create: device synchronisation failed");
+        aisx_agc_destroy(h);
+        return AISX_ERR_HIP;
+    }
     *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
+{
+    if (!h || !(floor_env > 0.f)) {
+        set_err("aisx_agc_set_floor: the floor must be positive");
+        return AISX_ERR_INVALID;
+    }
+    h->floor_env = floor_env;
     return AISX_OK;
 }
 
@@ -263,6 +319,7 @@ extern "C" int aisx_agc_reset(aisx_agc* h)
         return AISX_ERR_INVALID;
     AISX_HIPCHK(hipMemset(h->d_hist[0], 0, sizeof(cf) * (size_t)h->nchan * h->W));
     AISX_HIPCHK(hipMemset(h->d_hist[1], 0, sizeof(cf) * (size_t)h->nchan * h->W));
+    AISX_HIPCHK(hipDeviceSynchronize());
     h->cur = 0;
     return AISX_OK;
 }
@@ -284,6 +341,7 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.n = n;
     p.W = h->W;
     p.reference = h->reference;
+    p.floor_env = h->floor_env;
     p.ntiles = (n + AGC_TL - 1) / AGC_TL;
     if (agc8_applies(p.W))
         hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);

@@ -1,6 +1,9 @@
 // k_agc.h -- analog.feedforward_agc_cc(nsamples, reference) as the reference chain
 // uses it (python/ais_demod.py:35,56).  [GR] feedforward_agc_cc_impl::work:
-//   out[i] = reference / max(1e-12, max_{j<nsamples} envelope(in[i+j])) * in[i]
+//   out[i] = reference / max(floor, max_{j<nsamples} envelope(in[i+j])) * in[i]
+// (floor = 1e-4, AGC_FLOOR_DEFAULT: GNU Radio 3.7/3.8 "float max_env = 1e-4; // avoid divide by
+// zero, indirectly set max gain"; the 1e-12 of the line upstream has commented out stays
+// reachable through aisx_agc_set_floor)
 // with history nsamples (so the output is the input delayed by nsamples-1 and the
 // window looks ahead), envelope(x) = max(|re|,|im|) + 0.4*min(|re|,|im|) in double.
 // The sliding maximum is computed exactly (max is associative) with a doubling
@@ -26,8 +29,11 @@ struct AgcParams {
     const cf* hist_in; cf* hist_out; // [nchan][W-1]
     int n, W;
     float reference;
+    float floor_env; // the initial max_env of [GR] feedforward_agc_cc_impl::work
     int ntiles;
 };
+
+constexpr float AGC_FLOOR_DEFAULT = 1e-4f;
 
 AISX_HD float agc_envelope(cf x)
 {
@@ -37,7 +43,7 @@ AISX_HD float agc_envelope(cf x)
         e = (float)((double)r_abs + 0.4 * (double)i_abs);
     else
         e = (float)((double)i_abs + 0.4 * (double)r_abs);
-    // std::max(max_env, e) never selects a NaN; 0 is below the 1e-12 floor
+    // std::max(max_env, e) never selects a NaN; 0 is below any positive floor
     return (e != e) ? 0.0f : e;
 }
 
@@ -101,7 +107,7 @@ AISX_DI void agc_body(Ctx& cx, const AgcParams& p)
         if (i < nout) {
             const float a = src[i], b = src[i + shift];
             float max_env = a < b ? b : a;
-            max_env = (1e-12f < max_env) ? max_env : 1e-12f;
+            max_env = (p.floor_env < max_env) ? max_env : p.floor_env;
             const float gain = fdiv_rn(p.reference, max_env);
             xout[base + i] = mk(gain * own[m].re, gain * own[m].im);
         }
@@ -180,7 +186,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         float e[AGC8_G];
 #pragma unroll
         for (int k = 0; k < AGC8_G; k++)
-            e[k] = (g * AGC8_G + k < E) ? agc_envelope(v[k]) : 0.f; // (0 never wins: floor 1e-12)
+            e[k] = (g * AGC8_G + k < E) ? agc_envelope(v[k]) : 0.f; // (0 never wins: the floor is positive)
         float run = e[0];
         float pfx[AGC8_G];
         pfx[0] = run;
@@ -247,7 +253,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 const float pe = pf[k - 1];
                 mx = mx < pe ? pe : mx;
             }
-            mx = (1e-12f < mx) ? mx : 1e-12f;
+            mx = (p.floor_env < mx) ? mx : p.floor_env;
             const float gain = fdiv_rn(p.reference, mx);
             o[k] = mk(gain * own[k].re, gain * own[k].im);
         }

@@ -48,6 +48,10 @@ struct CorrParams {
     unsigned long long* abits; long abits_stride; // 1 bit per output item: !(mag <= thresh)
     int n, N, L, nseg, tiles_per_seg;
     float thresh;
+    // first call after set_symbols(): the reference's FFT filter starts from a zeroed tail
+    // ([GR] fft_filter_ccc::set_taps), i.e. the correlation sees zeros before this call's first
+    // item, while the delayed pass-through still comes from the block's history (:180-184)
+    int corr_hist_zero;
 };
 
 // The rare path of the main kernels' epilogue: this wave has at least one value above the
@@ -219,6 +223,12 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
                 if (i < L && k0 + i < n)
                     xout[k0 + i] = x[n1];
             }
+            if (p.corr_hist_zero) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++)
+                    if (k0 - N + t + CF_T * n1 < 0)
+                        x[n1] = mk(0.f, 0.f);
+            }
         }
         cf_forward(cx, x, p.wtab, ldsX, ldsT, v);
         // spectrum x H, inverse radix-8
@@ -309,6 +319,7 @@ struct ResolveParams {
     int L; // outputs per tile of the main kernel (its FFT size is L + N)
     const cf* in; long in_stride;
     const cf* hist_in; // history the correlation of this call started from
+    int corr_hist_zero; // ... or zeros (first call after set_symbols, see CorrParams)
     const cf* taps;    // d_symbols as stored (reversed conjugate), N entries
     int n, N, isps;
     unsigned mark_delay;
@@ -336,12 +347,16 @@ AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk,
             const int s0 = pk - 1 - j, s2 = pk + 1 - j;
             const cf tv = p.taps[j];
             if (W0) {
-                const cf xv = (s0 >= 0) ? xin[s0] : hist[p.N + s0];
+                cf xv = (s0 >= 0) ? xin[s0] : hist[p.N + s0];
+                if (s0 < 0 && p.corr_hist_zero)
+                    xv = mk(0.f, 0.f);
                 ar0 += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
                 ai0 += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
             }
             if (W2) {
-                const cf xv = (s2 >= 0) ? xin[s2] : hist[p.N + s2];
+                cf xv = (s2 >= 0) ? xin[s2] : hist[p.N + s2];
+                if (s2 < 0 && p.corr_hist_zero)
+                    xv = mk(0.f, 0.f);
                 ar2 += (double)tv.re * (double)xv.re - (double)tv.im * (double)xv.im;
                 ai2 += (double)tv.re * (double)xv.im + (double)tv.im * (double)xv.re;
             }

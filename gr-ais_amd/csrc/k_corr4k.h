@@ -204,6 +204,12 @@ AISX_DI void corr4_main_body(Ctx& cx, const CorrParams& p)
                 if (i < L && k0 + i < n)
                     xout[k0 + i] = x[n1];
             }
+            if (p.corr_hist_zero) {
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++)
+                    if (k0 - N + t + CF4_T * n1 < 0)
+                        x[n1] = mk(0.f, 0.f);
+            }
         }
         cf4_forward(cx, x, wp, ldsX, ldsT);
         // spectrum x H (position order, 128 contiguous bytes per thread), inverse radix-16

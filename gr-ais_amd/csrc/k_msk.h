@@ -38,7 +38,14 @@
 
 namespace aisx {
 
-enum { MSK_ST_INTERP_RANGE = 1, MSK_ST_CARRY_OVERFLOW = 2, MSK_ST_TAGCARRY_OVERFLOW = 4, MSK_ST_OUT_FULL = 8 };
+enum {
+    MSK_ST_INTERP_RANGE = 1,
+    MSK_ST_CARRY_OVERFLOW = 2,
+    MSK_ST_TAGCARRY_OVERFLOW = 4,
+    MSK_ST_OUT_FULL = 8,
+    MSK_ST_TAGS_TRUNCATED = 16 // the producer's tag list was longer than its buffer: tags are missing
+};
+constexpr int MSK_CTN_TRUNC = 0x40000000; // flag bit in ct_n: tagprep_body saw a truncated list
 
 constexpr int MSK_T = 64;    // lanes of a wave
 constexpr int MSK_RING = 256;   // slots per lane (power of two)
@@ -199,6 +206,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // the time_est tags visible to this call (carried ones first), already compacted
     const msk_ctag* ctl = p.ct + (long)cc * p.ct_cap;
     int ntot = p.ct_n[cc];
+    if (ntot & MSK_CTN_TRUNC) {
+        status |= MSK_ST_TAGS_TRUNCATED;
+        ntot &= MSK_CTN_TRUNC - 1;
+    }
     if (ntot > p.ct_cap)
         ntot = p.ct_cap;
     // They are queued in LDS: the loop must not pay global-memory latency when a tag fires.
@@ -920,18 +931,23 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
             w += aisx_popc64(m);
         }
     };
+    bool trunc = false;
     int nc = p.ctag_n_in[c];
     if (nc > p.ctag_cap)
         nc = p.ctag_cap;
     scan(p.ctag_in + (long)c * p.ctag_cap, nc);
     if (p.tags) {
         int nn = p.tag_count[c];
-        if (nn > p.tag_cap)
+        if (nn > p.tag_cap) { // the producer (corr_est) ran out of room: the list is incomplete
             nn = p.tag_cap;
+            trunc = true;
+        }
         scan(p.tags + (long)c * p.tag_cap, nn);
     }
+    if (w > p.ct_cap)
+        trunc = true;
     if (l == 0)
-        p.ct_n[c] = w < p.ct_cap ? w : p.ct_cap;
+        p.ct_n[c] = (w < p.ct_cap ? w : p.ct_cap) | (trunc ? MSK_CTN_TRUNC : 0);
 }
 
 // Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)

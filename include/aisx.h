@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AISX_VERSION 100
+#define AISX_VERSION 200
 
 /* gr_complex = std::complex<float>: interleaved re, im */
 typedef struct aisx_cf32 { float re, im; } aisx_cf32;
@@ -77,9 +77,11 @@ int aisx_corr_create(aisx_corr** h, const aisx_cf32* symbols, int nsym, float sp
 int aisx_corr_destroy(aisx_corr* h);
 /* symbols() (corr_est_cc.h:105): d_symbols as stored (reversed conjugate) */
 int aisx_corr_symbols(const aisx_corr* h, aisx_cf32* out, int cap);
-/* set_symbols() (corr_est_cc.h:106, impl :132-162); keeps the reference's quirk:
- * taps stored as given (no conjugate/reverse), threshold not recomputed.
- * nsym must equal the current template length. */
+/* set_symbols() (corr_est_cc.h:106, impl :132-162); keeps the reference's quirks:
+ * taps stored as given (no conjugate/reverse), threshold not recomputed, the FFT
+ * filter restarts from a zeroed tail.  A different length re-sizes history, output
+ * multiple and mark_delay as :143-161 do (up to 2048 samples).  Must not be called
+ * while a call on this handle is in flight (the reference holds d_setlock, :135). */
 int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int nsym);
 int aisx_corr_history(const aisx_corr* h);         /* history() = nsym + 1   (:95)  */
 int aisx_corr_output_multiple(const aisx_corr* h); /* fft_filter nsamples    (:84-85) */
@@ -138,6 +140,9 @@ float aisx_msk_get_gain(const aisx_msk* h);     /* :86-88 */
 int aisx_msk_set_limit(aisx_msk* h, float limit); /* :90-92 */
 float aisx_msk_get_limit(const aisx_msk* h);      /* :94-96 */
 int aisx_msk_set_sps(aisx_msk* h, float sps);     /* :69-74 (d_sps = sps/2, omega reset) */
+/* set_sps / set_limit / set_gain return AISX_ERR_INVALID for values outside what the kernel's
+ * rings are sized for (sps/2 - |limit| >= 0.5, sps <= ~47, 2 (sps/2 + |limit|) + 3 |gain| <= 32);
+ * after set_sps / set_limit ask aisx_msk_out_capacity() again. */
 float aisx_msk_get_sps(const aisx_msk* h);        /* :76-78 returns d_sps */
 int aisx_msk_forecast(const aisx_msk* h, int noutput_items); /* :98-105 */
 int aisx_msk_out_capacity(const aisx_msk* h);     /* items per channel the output arrays must hold */
@@ -156,7 +161,18 @@ int aisx_msk_reset(aisx_msk* h);
 int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_tag* d_tags,
                             const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms, float* d_err, float* d_mu,
                             uint8_t* d_bits, long out_stride, int* d_produced, void* stream);
-/* status word per channel of the last call, or-ed over channels (0 = clean) */
+/* status word per channel of the last call, or-ed over channels (0 = clean):
+ * 1 interpolator index out of range (upstream throws), 2 carry buffer overflow,
+ * 4 carried-tag buffer overflow, 8 output rows full (results truncated),
+ * 16 the tag list handed over was truncated by its producer (corr_est ran out of
+ * max_tags_per_chan): tags are missing */
+enum {
+    AISX_MSK_ST_INTERP_RANGE = 1,
+    AISX_MSK_ST_CARRY_OVERFLOW = 2,
+    AISX_MSK_ST_TAGCARRY_OVERFLOW = 4,
+    AISX_MSK_ST_OUT_FULL = 8,
+    AISX_MSK_ST_TAGS_TRUNCATED = 16
+};
 int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
 /* The NRZI bit tail (quadrature demod .. invert, python/ais_demod.py:48-52) has no part in
  * the timing recurrence.  With a tail stream set (enable != 0) aisx_msk_process_stream
@@ -198,6 +214,13 @@ int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, long in_strid
  * d_vecs [nchan][nvec*fftlen] (fft-shifted spectra), d_out [nchan][nvec]. */
 int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long vec_stride, float* d_out, long out_stride,
                       int nvec, void* stream);
+/* GNU Radio path (nchan == 1), HOST pointers exactly as the scheduler hands them to
+ * freqest_impl::work (include/ais/freqest.h:36-49, lib/freqest_impl.h:39-41,
+ * lib/freqest_impl.cc:57-88): in = input_items[0], noutput_items vectors of fftlen
+ * gr_complex (item size 8*fftlen, :43); out = output_items[0], one float per vector.
+ * maxpos is initialised once per call, as the reference's local is (:68 vs :74).
+ * Returns noutput_items (:87) or a negative status. */
+int aisx_freqest_work_host(aisx_freqsync* h, int noutput_items, const aisx_cf32* in, float* out);
 
 /* ------------------------------------------------------------------------ */
 /* analog.feedforward_agc_cc(nsamples, reference) (python/ais_demod.py:35)   */
@@ -206,6 +229,10 @@ typedef struct aisx_agc aisx_agc;
 int aisx_agc_create(aisx_agc** h, int nsamples, float reference, int nchan, int max_items);
 int aisx_agc_destroy(aisx_agc* h);
 int aisx_agc_reset(aisx_agc* h);
+/* the initial max_env of [GR] feedforward_agc_cc_impl::work: 1e-4 (default; GNU Radio 3.7/3.8
+ * "float max_env = 1e-4; // avoid divide by zero, indirectly set max gain") or the 1e-12 of the
+ * line upstream has commented out.  Not part of the GNU Radio API. */
+int aisx_agc_set_floor(aisx_agc* h, float floor_env);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
 

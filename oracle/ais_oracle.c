@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -195,7 +196,23 @@ void orc_det_sincos(float phase, float *s, float *c)
 #define ORC_MAX_FFT_CACHE 8
 static struct { int n; orc_cf *tw; int *rev; } g_fft_cache[ORC_MAX_FFT_CACHE];
 
+/* the cpu_baseline leg of bench.py runs channels on several threads: entries are
+ * created under a lock and published by writing .n last; nothing is evicted while
+ * fewer than ORC_MAX_FFT_CACHE sizes are in use (the chain uses three) */
+static pthread_mutex_t g_fft_lock = PTHREAD_MUTEX_INITIALIZER;
+static int fft_cache_fill(int n);
 static int fft_cache_get(int n)
+{
+    for (int i = 0; i < ORC_MAX_FFT_CACHE; i++)
+        if (__atomic_load_n(&g_fft_cache[i].n, __ATOMIC_ACQUIRE) == n)
+            return i;
+    pthread_mutex_lock(&g_fft_lock);
+    int i = fft_cache_fill(n);
+    pthread_mutex_unlock(&g_fft_lock);
+    return i;
+}
+
+static int fft_cache_fill(int n)
 {
     int i;
     for (i = 0; i < ORC_MAX_FFT_CACHE; i++)
@@ -206,10 +223,10 @@ static int fft_cache_get(int n)
             break;
     if (i == ORC_MAX_FFT_CACHE) {
         i = 0;
+        g_fft_cache[0].n = 0;
         free(g_fft_cache[0].tw);
         free(g_fft_cache[0].rev);
     }
-    g_fft_cache[i].n = n;
     g_fft_cache[i].tw = (orc_cf *)malloc(sizeof(orc_cf) * (n / 2 + 1));
     g_fft_cache[i].rev = (int *)malloc(sizeof(int) * n);
     for (int k = 0; k < n / 2; k++) {
@@ -227,6 +244,7 @@ static int fft_cache_get(int n)
                 r |= 1 << (bits - 1 - b);
         g_fft_cache[i].rev[k] = r;
     }
+    __atomic_store_n(&g_fft_cache[i].n, n, __ATOMIC_RELEASE);
     return i;
 }
 
@@ -613,10 +631,17 @@ static inline float agc_envelope(orc_cf x)
         return (float)(i_abs + 0.4 * r_abs);
 }
 
-void orc_feedforward_agc(int nsamples, float reference, int noutput_items, const orc_cf *in, orc_cf *out)
+/* [GR] feedforward_agc_cc_impl::work as published in GNU Radio 3.7 / 3.8:
+ *     // float max_env = 1e-12;   // avoid divide by zero
+ *     float max_env = 1e-4;       // avoid divide by zero, indirectly set max gain
+ * i.e. the live floor is 1e-4 (ORC_AGC_FLOOR); the older 1e-12 is kept reachable
+ * through orc_feedforward_agc_floor for the tests.  The two differ only where a
+ * whole window's envelope maximum lies in (0, 1e-4). */
+void orc_feedforward_agc_floor(int nsamples, float reference, float floor_env, int noutput_items, const orc_cf *in,
+                               orc_cf *out)
 {
     for (int i = 0; i < noutput_items; i++) {
-        float max_env = 1e-12f;
+        float max_env = floor_env;
         for (int j = 0; j < nsamples; j++) {
             float e = agc_envelope(in[i + j]);
             max_env = max_env < e ? e : max_env; /* std::max(max_env, e) */
@@ -625,6 +650,11 @@ void orc_feedforward_agc(int nsamples, float reference, int noutput_items, const
         out[i].re = gain * in[i].re;
         out[i].im = gain * in[i].im;
     }
+}
+
+void orc_feedforward_agc(int nsamples, float reference, int noutput_items, const orc_cf *in, orc_cf *out)
+{
+    orc_feedforward_agc_floor(nsamples, reference, ORC_AGC_FLOOR, noutput_items, in, out);
 }
 
 /* ------------------------------------------------------------------ */

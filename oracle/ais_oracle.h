@@ -72,7 +72,11 @@ int orc_freqsync_process(orc_freqsync *h, const orc_cf *in, int n, orc_cf *out, 
 
 /* ---- analog.feedforward_agc_cc (3rd party, python/ais_demod.py:35) ---- */
 /* `in` has nsamples-1 history items then noutput new ones */
+#define ORC_AGC_FLOOR 1e-4f /* [GR] 3.7/3.8 "float max_env = 1e-4; // avoid divide by zero, indirectly set max gain" */
 void orc_feedforward_agc(int nsamples, float reference, int noutput_items, const orc_cf *in, orc_cf *out);
+/* the same with an explicit floor (1e-12f = the line upstream has commented out) */
+void orc_feedforward_agc_floor(int nsamples, float reference, float floor_env, int noutput_items, const orc_cf *in,
+                               orc_cf *out);
 
 /* ---- msk_timing_recovery_cc (lib/msk_timing_recovery_cc_impl.cc) ---- */
 typedef struct orc_msk orc_msk;

@@ -281,11 +281,11 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.Hpos = h->Hpos.data(); p.wtab = h->wtab.data();
     p.abits = h->abits.data(); p.abits_stride = astride;
-    p.n = n; p.N = h->N; p.L = h->L; p.nseg = nseg; p.tiles_per_seg = tps; p.thresh = h->cs.thresh;
+    p.n = n; p.N = h->N; p.L = h->L; p.nseg = nseg; p.tiles_per_seg = tps; p.thresh = h->cs.thresh; p.corr_hist_zero = 0;
     emu_corr_main(&p, h->nchan, h->F);
     ResolveParams r;
     r.abits = p.abits; r.abits_stride = astride; r.L = h->L; r.corr = p.corr; r.corr_stride = p.corr_stride; r.dense_corr = p.dense_corr;
-    r.in = in; r.in_stride = in_stride; r.hist_in = p.hist_in; r.taps = h->cs.symbols.data();
+    r.in = in; r.in_stride = in_stride; r.hist_in = p.hist_in; r.corr_hist_zero = 0; r.taps = h->cs.symbols.data();
     r.n = n; r.N = h->N; r.isps = h->cs.isps; r.mark_delay = h->cs.mark_delay; r.written = h->written;
     r.emit_port1 = corr ? 1 : 0; r.tags = tags; r.tag_cap = tag_cap; r.tag_count = tag_count; r.atan_tab = aisx_atan_table;
     emu_corr_resolve(&r, h->nchan);
@@ -493,7 +493,7 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     AgcParams p;
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
-    p.n = n; p.W = h->W; p.reference = h->ref; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
     if (agc8_applies(p.W))
         run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else

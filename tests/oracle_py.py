@@ -62,6 +62,7 @@ def lib():
         L.orc_freqsync_process.restype = i32
         L.orc_freqsync_process.argtypes = [vp, vp, i32, vp, vp]
         L.orc_feedforward_agc.argtypes = [i32, f32, i32, vp, vp]
+        L.orc_feedforward_agc_floor.argtypes = [i32, f32, f32, i32, vp, vp]
         L.orc_msk_create.restype = vp
         L.orc_msk_create.argtypes = [f32, f32, f32, i32, pi32]
         L.orc_msk_destroy.argtypes = [vp]
@@ -159,6 +160,17 @@ class CorrEst:
         lib().orc_corr_taps(self.h, _ptr(out))
         return out
 
+    def set_symbols(self, symbols):
+        """set_symbols() (lib/corr_est_cc_impl.cc:132-162).  The scheduler's history follows
+        set_history(N + 1): the N items before the next new one (zeros before the stream start)."""
+        s = _c64(symbols)
+        lib().orc_corr_set_symbols(self.h, _ptr(s), s.size)
+        keep = min(self.N, s.size)
+        hist = np.zeros(s.size, dtype=np.complex64)
+        if keep:
+            hist[s.size - keep:] = self.hist[self.N - keep:]
+        self.hist, self.N = hist, s.size
+
     def work(self, x, want_corr=False):
         """One work() call on len(x) new items.  Returns (out, corr|None, tags)."""
         x = _c64(x)
@@ -211,15 +223,18 @@ class FreqSync:
 
 
 class Agc:
-    def __init__(self, nsamples=512, reference=2.0):
-        self.ns, self.ref = nsamples, reference
+    def __init__(self, nsamples=512, reference=2.0, floor=None):
+        self.ns, self.ref, self.floor = nsamples, reference, floor
         self.hist = np.zeros(nsamples - 1, dtype=np.complex64)
 
     def work(self, x):
         x = _c64(x)
         buf = np.concatenate([self.hist, x])
         out = np.zeros(x.size, dtype=np.complex64)
-        lib().orc_feedforward_agc(self.ns, self.ref, x.size, _ptr(buf), _ptr(out))
+        if self.floor is None:
+            lib().orc_feedforward_agc(self.ns, self.ref, x.size, _ptr(buf), _ptr(out))
+        else:
+            lib().orc_feedforward_agc_floor(self.ns, self.ref, self.floor, x.size, _ptr(buf), _ptr(out))
         self.hist = buf[x.size:].copy()
         return out
 
