@@ -1,44 +1,113 @@
-// aisx_framing.cpp -- host-side tail of the receive chain:
-// digital.hdlc_deframer_bp(length_min, length_max) as python/radio.py:64 uses it
-// ([GR] gr-digital hdlc_deframer_bp_impl::work: flag 0x7E search, bit unstuffing,
-// bytes packed LSB first, CRC-16/X.25) and ais.pdu_to_nmea
-// (lib/pdu_to_nmea_impl.cc:63-131: 6-bit unpack, ASCII armouring, 56-character
-// fragments, XOR checksum).  Per-packet, bytes-per-second work: plain host C++,
-// no GPU involved.
+// aisx_framing.cpp -- host-side tail of the receive chain, plain C++:
+//
+//   aisx_hdlc_*      what digital.hdlc_deframer_bp(length_min, length_max) does for
+//                    python/radio.py:64: HDLC bit de-stuffing, frames delimited by six
+//                    consecutive ones, octets filled LSB first, CRC-16/X.25 over all but the
+//                    last two octets, which carry the FCS low byte first;
+//   aisx_pdu_to_nmea the sentence format of ais.pdu_to_nmea (observable behaviour of
+//                    lib/pdu_to_nmea_impl.cc:63-131): ITU-R M.1371 / NMEA 0183 six-bit
+//                    armouring, 56 payload characters per !AIVDM fragment, XOR checksum.
+//
+// Per-packet, bytes-per-second work: no GPU involved.  Written from the protocol rules; the
+// reference's observable quirks that a consumer could depend on are kept and named below.
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
-#include <string>
 #include <vector>
 
 #include "../../include/aisx.h"
 
-struct aisx_hdlc {
-    int length_min, length_max;
-    std::vector<unsigned char> pktbuf;
-    int ones = 0, bitctr = 0, bytectr = 0;
+namespace {
+
+// CRC-16/X.25: polynomial 0x1021 reflected (0x8408), preset 0xFFFF, complemented result
+class X25Fcs {
+public:
+    X25Fcs()
+    {
+        for (unsigned v = 0; v < 256; v++) {
+            unsigned r = v;
+            for (int k = 0; k < 8; k++)
+                r = (r >> 1) ^ ((r & 1u) ? 0x8408u : 0u);
+            table_[v] = (uint16_t)r;
+        }
+    }
+    uint16_t operator()(const uint8_t* octets, size_t count) const
+    {
+        unsigned reg = 0xFFFFu;
+        for (size_t k = 0; k < count; k++)
+            reg = (reg >> 8) ^ table_[(reg ^ octets[k]) & 0xFFu];
+        return (uint16_t)(~reg & 0xFFFFu);
+    }
+
+private:
+    uint16_t table_[256];
 };
 
-static unsigned short crc_ccitt(const unsigned char* data, size_t len)
+const X25Fcs& fcs()
 {
-    const unsigned POLY = 0x8408; // reflected 0x1021
-    unsigned short crc = 0xFFFF;
-    for (size_t i = 0; i < len; i++) {
-        crc ^= data[i];
-        for (int j = 0; j < 8; j++)
-            crc = (crc & 0x01) ? (unsigned short)((crc >> 1) ^ POLY) : (unsigned short)(crc >> 1);
-    }
-    return crc ^ 0xFFFF;
+    static const X25Fcs f;
+    return f;
 }
+
+} // namespace
+
+// Receiver state: the run of ones seen so far (the de-stuffer), the octet being filled and the
+// octets of the frame under way.
+struct aisx_hdlc {
+    int min_octets = 0, max_octets = 0;
+    unsigned ones_run = 0;
+    unsigned shift = 0;   // octet under construction, filled from the top and shifted down
+    int nshift = 0;       // bits in it
+    std::vector<uint8_t> frame;
+
+    void drop_frame()
+    {
+        frame.clear();
+        shift = 0;
+        nshift = 0;
+    }
+    void data_bit(unsigned bit)
+    {
+        // a frame that has outgrown length_max is abandoned as soon as one more data bit shows
+        // up (the opening bits of the closing flag count: a frame of length_max + 1 octets never
+        // survives, one of exactly length_max does)
+        if ((int)frame.size() > max_octets) {
+            drop_frame();
+            return;
+        }
+        shift = (shift >> 1) | (bit ? 0x80u : 0u); // first bit received ends up as bit 0
+        if (++nshift == 8) {
+            frame.push_back((uint8_t)shift);
+            shift = 0;
+            nshift = 0;
+        }
+    }
+    // six ones in a row: end of frame (or an abort / idle flags when nothing was collected).
+    // Whole octets only; the flag's own leading bits sit in the partial octet and go with it.
+    template <class Sink>
+    void delimiter(Sink&& deliver)
+    {
+        const int got = (int)frame.size();
+        if (got >= min_octets) {
+            const int payload = got - 2;
+            const unsigned sent = (unsigned)frame[payload] | ((unsigned)frame[payload + 1] << 8);
+            if (fcs()(frame.data(), (size_t)payload) == sent)
+                deliver(frame.data(), payload);
+        }
+        drop_frame();
+    }
+};
 
 extern "C" int aisx_hdlc_create(aisx_hdlc** h, int length_min, int length_max)
 {
-    if (!h || length_min < 0 || length_max < length_min)
+    // a frame is its payload plus the two FCS octets: anything shorter has no payload to check
+    if (!h || length_min < 2 || length_max < length_min)
         return AISX_ERR_INVALID;
     aisx_hdlc* d = new aisx_hdlc();
-    d->length_min = length_min;
-    d->length_max = length_max;
-    d->pktbuf.assign(length_max + 2, 0);
+    d->min_octets = length_min;
+    d->max_octets = length_max;
+    d->frame.reserve((size_t)length_max + 2);
     *h = d;
     return AISX_OK;
 }
@@ -54,99 +123,142 @@ extern "C" int aisx_hdlc_work(aisx_hdlc* h, const uint8_t* bits, int nbits, uint
 {
     if (!h || !bits || nbits < 0 || !npdus || (max_pdus > 0 && (!pdu_offsets || !pdu_bytes)))
         return AISX_ERR_INVALID;
-    int np = 0, used = 0, rc = AISX_OK;
+    int found = 0, fill = 0, status = AISX_OK;
     if (max_pdus > 0)
         pdu_offsets[0] = 0;
-    for (int i = 0; i < nbits; i++) {
-        const unsigned char bit = bits[i];
-        if (h->ones >= 5) {
-            if (bit) { // six ones: frame delimiter
-                if (h->bytectr >= h->length_min) {
-                    const int len = h->bytectr - 2;
-                    const unsigned short crc = crc_ccitt(h->pktbuf.data(), len);
-                    const unsigned short pktcrc = (unsigned short)(h->pktbuf[len + 1] << 8 | h->pktbuf[len]);
-                    if (crc == pktcrc) {
-                        if (np < max_pdus && used + len <= pdu_cap) {
-                            memcpy(pdu_bytes + used, h->pktbuf.data(), len);
-                            used += len;
-                            pdu_offsets[np + 1] = used;
-                        } else {
-                            rc = AISX_ERR_OVERFLOW;
-                        }
-                        np++;
-                    }
-                    h->pktbuf.assign(h->length_max + 2, 0);
-                }
-                h->bitctr = 0;
-                h->bytectr = 0;
-            } // else: a stuffed zero, dropped
+    auto deliver = [&](const uint8_t* octets, int count) {
+        if (found < max_pdus && fill + count <= pdu_cap) {
+            memcpy(pdu_bytes + fill, octets, (size_t)count);
+            fill += count;
+            pdu_offsets[found + 1] = fill;
         } else {
-            if (h->bytectr > h->length_max) { // overran the packet buffer
-                h->bitctr = 0;
-                h->bytectr = 0;
-                h->pktbuf.assign(h->length_max + 2, 0);
-            } else {
-                h->pktbuf[h->bytectr] >>= 1;
-                if (bit)
-                    h->pktbuf[h->bytectr] |= 0x80;
-                h->bitctr++;
-                if (h->bitctr == 8) {
-                    h->bitctr = 0;
-                    h->bytectr++;
-                }
-            }
+            status = AISX_ERR_OVERFLOW;
         }
-        h->ones = bit ? h->ones + 1 : 0;
+        found++;
+    };
+    for (const uint8_t *b = bits, *end = bits + nbits; b != end; ++b) {
+        const unsigned bit = *b ? 1u : 0u;
+        if (h->ones_run < 5)
+            h->data_bit(bit);
+        else if (bit)
+            h->delimiter(deliver);
+        // (else: the zero the transmitter stuffed behind five ones -- not data)
+        h->ones_run = bit ? h->ones_run + 1 : 0;
     }
-    *npdus = np;
-    return rc;
+    *npdus = found;
+    return status;
 }
 
-// lib/pdu_to_nmea_impl.cc:63-131
+namespace {
+
+// one payload character from a six-bit value: 0..39 -> '0'..'W', 40..63 -> '`'..'w'.
+// Quirk kept from the reference (lib/pdu_to_nmea_impl.cc:81-88 compares a plain `char`): the
+// padded last group can exceed 63, and a value of 128 or more counts as negative there.
+inline char armour(unsigned group)
+{
+    const int as_char = (int)(int8_t)(uint8_t)group;
+    return (char)(as_char + (as_char > 39 ? 56 : 48));
+}
+
+// bounded text sink that keeps the NMEA checksum (XOR of everything between '!' and '*')
+class SentenceWriter {
+public:
+    SentenceWriter(char* dst, int cap) : dst_(dst), cap_(cap) {}
+    void raw(char c)
+    {
+        if (used_ < cap_)
+            dst_[used_] = c;
+        used_++;
+    }
+    void put(char c)
+    {
+        sum_ ^= (uint8_t)c;
+        raw(c);
+    }
+    void put(const char* s)
+    {
+        while (*s)
+            put(*s++);
+    }
+    void put_number(int v)
+    {
+        char tmp[16];
+        snprintf(tmp, sizeof tmp, "%d", v);
+        put(tmp);
+    }
+    void open()
+    {
+        raw('!');
+        sum_ = 0;
+    }
+    void close()
+    {
+        static const char hex[] = "0123456789ABCDEF";
+        const uint8_t s = sum_;
+        raw('*');
+        raw(hex[s >> 4]);
+        raw(hex[s & 15]);
+    }
+    int used() const { return used_; }
+
+private:
+    char* dst_;
+    int cap_, used_ = 0;
+    uint8_t sum_ = 0;
+};
+
+} // namespace
+
 extern "C" int aisx_pdu_to_nmea(const char* designator, const uint8_t* pdu, int len, char* out, int cap)
 {
     if (!designator || !pdu || len < 1 || !out || cap < 1)
         return AISX_ERR_INVALID;
-    // unpack_bits (:63-79)
-    const int nbits = len * 8;
-    const int npad = (6 - (nbits % 6)) % 6;
-    std::vector<unsigned char> up((nbits + npad) / 6, 0);
-    for (int i = 0; i < nbits; i++) {
-        const unsigned char bit = (pdu[i / 8] >> (7 - (i % 8))) & 1;
-        up[i / 6] |= (unsigned char)(bit << (5 - (i % 6)));
+    // payload: the PDU's bits, most significant first, in groups of six
+    const int fill_bits = (6 - (len * 8) % 6) % 6;
+    std::vector<char> payload;
+    payload.reserve((size_t)(len * 8 + fill_bits) / 6);
+    unsigned window = 0;
+    int held = 0;
+    for (int k = 0; k < len; k++) {
+        window = ((window << 8) | pdu[k]) & 0xFFFFu;
+        held += 8;
+        while (held >= 6) {
+            held -= 6;
+            payload.push_back(armour((window >> held) & 63u));
+        }
     }
-    for (int i = 0; i < npad; i++)
-        up[nbits / 6] <<= 1;
-    // to_ascii (:81-88)
-    std::string ascii(up.begin(), up.end());
-    for (size_t i = 0; i < ascii.size(); i++) {
-        if (ascii[i] > 39)
-            ascii[i] += 8;
-        ascii[i] += char(48);
+    if (held > 0) {
+        // Quirk kept from the reference (lib/pdu_to_nmea_impl.cc:70-78): the left-over bits are
+        // placed at the top of their group and the group is then shifted up by the fill count
+        // once more, in eight bits -- with 4 fill bits the group always comes out as 0
+        const unsigned top_aligned = (window & ((1u << held) - 1u)) << (6 - held);
+        payload.push_back(armour((top_aligned << fill_bits) & 0xFFu));
     }
-    // to_sentence (:99-124)
-    const int nmea_max = 56;
-    const int num_frags = 1 + (((int)ascii.length() - 1) / nmea_max);
-    std::string ret;
-    int frag_id = 1;
-    size_t frag_offset = 0;
-    while (frag_id <= num_frags) {
-        if (frag_id > 1)
-            ret += "\n";
-        std::string s = "!AIVDM," + std::to_string(num_frags) + "," + std::to_string(frag_id++) + ",," + designator + ",";
-        std::string frag = ascii.substr(frag_offset, nmea_max);
-        frag_offset += frag.length();
-        s += frag + "," + std::to_string(npad);
-        unsigned char sum = 0; // get_checksum (:90-96)
-        for (size_t i = (s[0] == '!') ? 1 : 0; i < s.length(); i++)
-            sum ^= (unsigned char)s[i];
-        char wat[3];
-        snprintf(wat, 3, "%02X", sum);
-        s += "*" + std::string(wat);
-        ret += s;
+    // fragments of at most 56 payload characters; every fragment reports the fill count (:113)
+    const int per_fragment = 56;
+    const int total = (int)payload.size();
+    const int fragments = (total + per_fragment - 1) / per_fragment;
+    SentenceWriter w(out, cap - 1);
+    for (int f = 0; f < fragments; f++) {
+        if (f)
+            w.raw('\n');
+        w.open();
+        w.put("AIVDM,");
+        w.put_number(fragments);
+        w.put(',');
+        w.put_number(f + 1);
+        w.put(",,");
+        w.put(designator);
+        w.put(',');
+        const int first = f * per_fragment, last = first + per_fragment < total ? first + per_fragment : total;
+        for (int k = first; k < last; k++)
+            w.put(payload[(size_t)k]);
+        w.put(',');
+        w.put_number(fill_bits);
+        w.close();
     }
-    if ((int)ret.size() + 1 > cap)
+    if (w.used() > cap - 1)
         return AISX_ERR_OVERFLOW;
-    memcpy(out, ret.c_str(), ret.size() + 1);
-    return (int)ret.size();
+    out[w.used()] = '\0';
+    return w.used();
 }

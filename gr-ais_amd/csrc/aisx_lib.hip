@@ -12,7 +12,6 @@
 #include "aisx_plan.h"
 #include "aisx_tables.h"
 #include "k_corr.h"
-#include "k_msk.h"
 #include <cstdlib>
 
 using namespace aisx;
@@ -77,55 +76,6 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
     __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
     DevCtx cx{ (char*)atab };
     corr_resolve_body(cx, p);
-}
-
-template <bool AUX, bool OSPS2, int LPW>
-__global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk(MskParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevCtx cx{ smem };
-    // the recurrence is latency-bound and issues little: its waves go first on their SIMDs, ahead
-    // of the throughput kernels of the other stream that share them
-    __builtin_amdgcn_s_setprio(3);
-    msk_body<DevCtx, AUX, OSPS2, LPW>(cx, p);
-}
-
-__global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
-{
-    __shared__ __attribute__((aligned(16))) char smem[260 * 4];
-    DevCtx cx{ smem };
-    bittail_body(cx, p);
-}
-
-__global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
-{
-    DevCtx cx{ nullptr };
-    tagprep_body(cx, p);
-}
-
-// launch the timing-recovery build for (err/mu ports connected, osps == 2, channels per wave)
-static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
-{
-    typedef void (*kfn)(MskParams);
-    static const kfn fns[20] = {
-        k_msk<false, false, 16>, k_msk<false, true, 16>, k_msk<true, false, 16>, k_msk<true, true, 16>,
-        k_msk<false, false, 32>, k_msk<false, true, 32>, k_msk<true, false, 32>, k_msk<true, true, 32>,
-        k_msk<false, false, 64>, k_msk<false, true, 64>, k_msk<true, false, 64>, k_msk<true, true, 64>,
-        k_msk<false, false, 8>,  k_msk<false, true, 8>,  k_msk<true, false, 8>,  k_msk<true, true, 8>,
-        k_msk<false, false, 4>,  k_msk<false, true, 4>,  k_msk<true, false, 4>,  k_msk<true, true, 4>,
-    };
-    static bool big_lds[20] = { false };
-    const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : (p.lpw == 64 ? 2 : (p.lpw == 8 ? 3 : 4)));
-    const int v = li * 4 + (((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0));
-    const int lds = msk_lds_bytes(p.lpw);
-    if (!big_lds[v]) {
-        AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        big_lds[v] = true;
-    }
-    // a workgroup = msk_waves(lpw) waves with lpw channels each
-    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(64 * msk_waves(p.lpw)), lds, st, p);
-    AISX_HIPCHK(hipGetLastError());
-    return AISX_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -603,603 +553,3 @@ extern "C" int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32*
     return aisx_corr_read_tags(h, tags, tag_cap, ntags, nullptr);
 }
 
-// ---------------------------------------------------------------------------
-// msk_timing_recovery_cc
-// ---------------------------------------------------------------------------
-struct aisx_msk {
-    int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
-    int lpw = 64; // channels per wave of the timing-recovery kernel
-    float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
-    static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
-    float *d_mu = nullptr, *d_omega = nullptr;
-    int* d_div = nullptr;
-    cf *d_dly1 = nullptr, *d_dly2 = nullptr, *d_diff1 = nullptr;
-    // bit tail state (previous symbol, previous sliced bit): read from [tcur], written to [tcur ^ 1]
-    cf* d_tprev[2] = { nullptr, nullptr };
-    unsigned char* d_tbit[2] = { nullptr, nullptr };
-    int tcur = 0;
-    // symbols for the bit tail when the caller takes bits only; two, alternating, so that the
-    // bit tail of call k may still read one while call k+1 writes the other (tail stream)
-    cf* d_symscratch[2] = { nullptr, nullptr };
-    size_t symscratch_len[2] = { 0, 0 };
-    int callpar = 0;
-    // optional: the bit tail on a stream of its own (aisx_msk_set_tail_stream)
-    bool tail_on = false;
-    hipStream_t tail_stream = nullptr;
-    hipEvent_t ev_msk = nullptr, ev_tail[2] = { nullptr, nullptr };
-    bool ev_tail_set[2] = { false, false };
-    int* d_produced2 = nullptr; // second internal `produced` array (alternates with d_produced)
-    unsigned long long* d_nread = nullptr;
-    cf* d_carry[2] = { nullptr, nullptr };
-    int* d_carry_len[2] = { nullptr, nullptr };
-    tag_rec* d_ctag[2] = { nullptr, nullptr };
-    int* d_ctag_n[2] = { nullptr, nullptr };
-    msk_ctag* d_ct = nullptr; // this call's time_est tags, compacted (k_msk_tagprep)
-    int* d_ct_n = nullptr;
-    int ct_cap = 0;
-    int cur = 0;
-    int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
-    float *d_mmse = nullptr, *d_atan = nullptr;
-    // GNU Radio path staging
-    cf *d_st_in = nullptr, *d_st_sym = nullptr;
-    float *d_st_err = nullptr, *d_st_mu = nullptr;
-    unsigned char* d_st_bits = nullptr;
-    tag_rec* d_st_tags = nullptr;
-    int* d_st_tagn = nullptr;
-    int st_in_cap = 0, st_out_cap = 0, st_tag_cap = 0;
-};
-
-// What the kernel's LDS rings and the carry buffer are sized for (k_msk.h): one general_work call
-// of a single output must fit the carry (forecast(1) + the pre-item), a pair of iterations must
-// stay well inside a 64-sample chunk, and omega must stay positive under the clip of :182
-// (omega in [d_sps - |limit|, d_sps + |limit|], `limit` is absolute).
-static int msk_check_geometry(float d_sps, float gain, float limit)
-{
-    const float wmin = d_sps - fabsf(limit), wmax = d_sps + fabsf(limit);
-    if (!(wmin >= 0.5f) || msk_forecast(d_sps, 1) + 1 > aisx_msk::carry_cap || !(2.f * wmax + 3.f * fabsf(gain) <= 32.f)) {
-        set_err("msk_timing_recovery: sps/2 = %g with limit %g and gain %g is outside what the gfx950 kernel is sized for "
-                "(sps/2 - |limit| >= 0.5, forecast(1) < %d items, 2 (sps/2 + |limit|) + 3 |gain| <= 32)",
-                d_sps, limit, gain, aisx_msk::carry_cap);
-        return AISX_ERR_INVALID;
-    }
-    return AISX_OK;
-}
-// items per channel one call can produce at most: every output consumes at least
-// 2 (d_sps - |limit|) input items (osps = 1; half of that for osps = 2)
-static int msk_out_cap(const aisx_msk* h)
-{
-    const double wmin = (double)h->d_sps - fabs((double)h->limit);
-    return (int)ceil((h->max_items + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16;
-}
-
-static int msk_init_state(aisx_msk* h)
-{
-    const int nc = h->nchan;
-    std::vector<float> mu(nc, 0.5f), om(nc, h->d_sps); // impl :49-56, :71
-    AISX_HIPCHK(hipMemcpy(h->d_mu, mu.data(), sizeof(float) * nc, hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemcpy(h->d_omega, om.data(), sizeof(float) * nc, hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemset(h->d_div, 0, sizeof(int) * nc));
-    AISX_HIPCHK(hipMemset(h->d_dly1, 0, sizeof(cf) * nc));
-    AISX_HIPCHK(hipMemset(h->d_dly2, 0, sizeof(cf) * nc));
-    AISX_HIPCHK(hipMemset(h->d_diff1, 0, sizeof(cf) * nc));
-    for (int k = 0; k < 2; k++) {
-        AISX_HIPCHK(hipMemset(h->d_tprev[k], 0, sizeof(cf) * nc));
-        AISX_HIPCHK(hipMemset(h->d_tbit[k], 0, nc));
-    }
-    h->tcur = 0;
-    AISX_HIPCHK(hipMemset(h->d_nread, 0, sizeof(unsigned long long) * nc));
-    for (int k = 0; k < 2; k++) {
-        AISX_HIPCHK(hipMemset(h->d_carry[k], 0, sizeof(cf) * (size_t)nc * aisx_msk::carry_cap));
-        AISX_HIPCHK(hipMemset(h->d_carry_len[k], 0, sizeof(int) * nc));
-        AISX_HIPCHK(hipMemset(h->d_ctag_n[k], 0, sizeof(int) * nc));
-    }
-    h->cur = 0;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limit, int osps, int nchan, int max_items)
-{
-    if (!out)
-        return AISX_ERR_INVALID;
-    *out = nullptr;
-    if (nchan < 1 || max_items < 1 || !(sps > 0)) {
-        set_err("aisx_msk_create: bad argument");
-        return AISX_ERR_INVALID;
-    }
-    if (!(gain > 0)) { // impl :82
-        set_err("Gain must be positive");
-        return AISX_ERR_OUT_OF_RANGE;
-    }
-    if (osps != 1 && osps != 2) { // impl :61
-        set_err("osps must be 1 or 2");
-        return AISX_ERR_OUT_OF_RANGE;
-    }
-    int rc = require_device();
-    if (rc != AISX_OK)
-        return rc;
-    if ((rc = msk_check_geometry(msk_setup(sps, gain).d_sps, gain, limit)) != AISX_OK)
-        return rc;
-    aisx_msk* h = new aisx_msk();
-    h->nchan = nchan;
-    h->max_items = max_items;
-    h->osps = osps;
-    h->limit = limit;
-    h->d_sps = msk_setup(sps, gain).d_sps; // :70
-    h->gain = gain;
-    h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
-    h->out_cap = msk_out_cap(h);
-    {
-        // 8 channels per wave, four waves (one per SIMD), 32 channels and ~84 KB of LDS per
-        // workgroup: fewer lanes per wave = fewer events of other lanes to wait for (a tag costs
-        // the whole wave a general pass), and half of each CU's LDS stays free for the stages
-        // that run beside this kernel on the other stream.  Measured on the whole flowgraph:
-        // 7.2 / 6.3 / 5.5 ms per launch at 16 / 8 / 4 channels per wave; 8 gives the shortest
-        // step (at 4 the kernel sits on all 256 CUs and slows the bandwidth-bound stages more)
-        h->lpw = 8;
-        if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
-            const int v = atoi(e);
-            if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
-                h->lpw = v;
-        }
-    }
-#define CK(e)               \
-    do {                    \
-        rc = (e);           \
-        if (rc != AISX_OK) { \
-            aisx_msk_destroy(h); \
-            return rc;      \
-        }                   \
-    } while (0)
-    CK(dev_alloc(&h->d_mu, nchan));
-    CK(dev_alloc(&h->d_omega, nchan));
-    CK(dev_alloc(&h->d_div, nchan));
-    CK(dev_alloc(&h->d_dly1, nchan));
-    CK(dev_alloc(&h->d_dly2, nchan));
-    CK(dev_alloc(&h->d_diff1, nchan));
-    for (int k = 0; k < 2; k++) {
-        CK(dev_alloc(&h->d_tprev[k], nchan));
-        CK(dev_alloc(&h->d_tbit[k], nchan));
-    }
-    CK(dev_alloc(&h->d_nread, nchan));
-    for (int k = 0; k < 2; k++) {
-        CK(dev_alloc(&h->d_carry[k], (size_t)nchan * aisx_msk::carry_cap));
-        CK(dev_alloc(&h->d_carry_len[k], nchan));
-        CK(dev_alloc(&h->d_ctag[k], (size_t)nchan * aisx_msk::ctag_cap));
-        CK(dev_alloc(&h->d_ctag_n[k], nchan));
-    }
-    CK(dev_alloc(&h->d_produced, nchan));
-    CK(dev_alloc(&h->d_produced2, nchan));
-    CK(dev_alloc(&h->d_consumed, nchan));
-    CK(dev_alloc(&h->d_status, nchan));
-    CK(dev_alloc(&h->d_mmse, 129 * 8));
-    CK(dev_alloc(&h->d_atan, 257));
-    if (hipMemcpy(h->d_mmse, aisx_mmse_taps, sizeof(float) * 129 * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
-        set_err("aisx_msk_create: table upload failed");
-        aisx_msk_destroy(h);
-        return AISX_ERR_HIP;
-    }
-    CK(msk_init_state(h));
-    // the compacted tag list for the usual hand-over capacity; grown on demand
-    h->ct_cap = aisx_msk::ctag_cap + 1024;
-    CK(dev_alloc(&h->d_ct, (size_t)nchan * (size_t)h->ct_cap));
-    CK(dev_alloc(&h->d_ct_n, nchan));
-    if (hipDeviceSynchronize() != hipSuccess) {
-        aisx_msk_destroy(h);
-        return AISX_ERR_HIP;
-    }
-#undef CK
-    *out = h;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_destroy(aisx_msk* h)
-{
-    if (!h)
-        return AISX_OK;
-    dev_free(h->d_mu);
-    dev_free(h->d_omega);
-    dev_free(h->d_div);
-    dev_free(h->d_dly1);
-    dev_free(h->d_dly2);
-    dev_free(h->d_diff1);
-    for (int k = 0; k < 2; k++) {
-        dev_free(h->d_tprev[k]);
-        dev_free(h->d_tbit[k]);
-    }
-    dev_free(h->d_symscratch[0]);
-    dev_free(h->d_symscratch[1]);
-    dev_free(h->d_produced2);
-    if (h->ev_msk)
-        (void)hipEventDestroy(h->ev_msk);
-    for (int k = 0; k < 2; k++)
-        if (h->ev_tail[k])
-            (void)hipEventDestroy(h->ev_tail[k]);
-    dev_free(h->d_ct);
-    dev_free(h->d_ct_n);
-    dev_free(h->d_nread);
-    for (int k = 0; k < 2; k++) {
-        dev_free(h->d_carry[k]);
-        dev_free(h->d_carry_len[k]);
-        dev_free(h->d_ctag[k]);
-        dev_free(h->d_ctag_n[k]);
-    }
-    dev_free(h->d_produced);
-    dev_free(h->d_consumed);
-    dev_free(h->d_status);
-    dev_free(h->d_mmse);
-    dev_free(h->d_atan);
-    dev_free(h->d_st_in);
-    dev_free(h->d_st_sym);
-    dev_free(h->d_st_err);
-    dev_free(h->d_st_mu);
-    dev_free(h->d_st_bits);
-    dev_free(h->d_st_tags);
-    dev_free(h->d_st_tagn);
-    delete h;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_set_gain(aisx_msk* h, float gain)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    h->gain = gain; // the reference stores first, then throws (:81-82)
-    if (!(gain > 0)) {
-        set_err("Gain must be positive");
-        return AISX_ERR_OUT_OF_RANGE;
-    }
-    h->gain_omega = (float)(gain * gain * 0.25);
-    return msk_check_geometry(h->d_sps, gain, h->limit);
-}
-extern "C" float aisx_msk_get_gain(const aisx_msk* h) { return h ? h->gain : 0.f; }
-extern "C" int aisx_msk_set_limit(aisx_msk* h, float limit)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    const int rc = msk_check_geometry(h->d_sps, h->gain, limit);
-    if (rc != AISX_OK)
-        return rc; // (the reference accepts any value, :90-92; this build is sized, see msk_check_geometry)
-    h->limit = limit;
-    h->out_cap = msk_out_cap(h); // callers size their outputs by aisx_msk_out_capacity(): ask again
-    return AISX_OK;
-}
-extern "C" float aisx_msk_get_limit(const aisx_msk* h) { return h ? h->limit : 0.f; }
-extern "C" int aisx_msk_set_sps(aisx_msk* h, float sps)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    const int rc = msk_check_geometry((float)(sps / 2.0), h->gain, h->limit);
-    if (rc != AISX_OK)
-        return rc;
-    h->d_sps = (float)(sps / 2.0); // :70
-    h->out_cap = msk_out_cap(h);
-    std::vector<float> om(h->nchan, h->d_sps); // :71 d_omega = d_sps
-    AISX_HIPCHK(hipMemcpy(h->d_omega, om.data(), sizeof(float) * h->nchan, hipMemcpyHostToDevice));
-    return AISX_OK;
-}
-extern "C" float aisx_msk_get_sps(const aisx_msk* h) { return h ? h->d_sps : 0.f; }
-extern "C" int aisx_msk_forecast(const aisx_msk* h, int noutput_items)
-{
-    return h ? msk_forecast(h->d_sps, noutput_items) : AISX_ERR_INVALID;
-}
-extern "C" int aisx_msk_out_capacity(const aisx_msk* h) { return h ? h->out_cap : AISX_ERR_INVALID; }
-extern "C" int aisx_msk_reset(aisx_msk* h)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    const int rc = msk_init_state(h);
-    if (rc != AISX_OK)
-        return rc;
-    AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fills vs. the caller's non-blocking streams)
-    return AISX_OK;
-}
-
-static void msk_fill_common(aisx_msk* h, MskParams& p)
-{
-    p.nchan = h->nchan;
-    p.d_sps = h->d_sps;
-    p.gain = h->gain;
-    p.gain_omega = h->gain_omega;
-    p.limit = h->limit;
-    p.osps = h->osps;
-    p.mu = h->d_mu;
-    p.omega = h->d_omega;
-    p.div = h->d_div;
-    p.dly1 = h->d_dly1;
-    p.dly2 = h->d_dly2;
-    p.diff1 = h->d_diff1;
-    p.nread = h->d_nread;
-    p.carry_in = h->d_carry[h->cur];
-    p.carry_out = h->d_carry[h->cur ^ 1];
-    p.carry_len_in = h->d_carry_len[h->cur];
-    p.carry_len_out = h->d_carry_len[h->cur ^ 1];
-    p.carry_cap = aisx_msk::carry_cap;
-    p.ctag_out = h->d_ctag[h->cur ^ 1];
-    p.ctag_n_out = h->d_ctag_n[h->cur ^ 1];
-    p.ctag_cap = aisx_msk::ctag_cap;
-    p.ct = h->d_ct;
-    p.ct_n = h->d_ct_n;
-    p.ct_cap = h->ct_cap;
-    p.consumed = h->d_consumed;
-    p.status = h->d_status;
-    p.mmse = h->d_mmse;
-    p.lds_tab_off = msk_lds_taboff(h->lpw);
-    p.lpw = h->lpw;
-    p.lds_wave_stride = msk_lds_wave(h->lpw);
-    p.tq_stride = h->lpw;
-    p.tq_private = 0;
-}
-
-// compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows
-static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_tag_counts, int tag_cap, hipStream_t st)
-{
-    const int need = aisx_msk::ctag_cap + (d_tags ? tag_cap : 0);
-    int rc;
-    if (need > h->ct_cap || !h->d_ct) {
-        AISX_HIPCHK(hipStreamSynchronize(st));
-        dev_free(h->d_ct);
-        h->d_ct = nullptr;
-        h->ct_cap = 0;
-        if ((rc = dev_alloc(&h->d_ct, (size_t)h->nchan * (size_t)need)) != AISX_OK)
-            return rc;
-        h->ct_cap = need;
-        if (!h->d_ct_n && (rc = dev_alloc(&h->d_ct_n, h->nchan)) != AISX_OK)
-            return rc;
-        // dev_alloc's zero fill runs on the null stream: it must not trail into the kernels on `st`
-        AISX_HIPCHK(hipDeviceSynchronize());
-    }
-    TagPrepParams t;
-    t.nchan = h->nchan;
-    t.ctag_in = h->d_ctag[h->cur];
-    t.ctag_n_in = h->d_ctag_n[h->cur];
-    t.ctag_cap = aisx_msk::ctag_cap;
-    t.tags = d_tags;
-    t.tag_count = d_tag_counts;
-    t.tag_cap = tag_cap;
-    t.nread = h->d_nread;
-    t.ct = h->d_ct;
-    t.ct_n = h->d_ct_n;
-    t.ct_cap = h->ct_cap;
-    hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 3) / 4), dim3(256), 0, st, t); // a wave per channel
-    AISX_HIPCHK(hipGetLastError());
-    return AISX_OK;
-}
-
-// the NRZI bit tail over the symbols the timing-recovery kernel just wrote
-static int msk_launch_bittail(aisx_msk* h, const cf* syms, long sym_stride, const int* produced, uint8_t* bits,
-                              long bit_stride, int max_out, hipStream_t st)
-{
-    BitTailParams b;
-    b.nchan = h->nchan;
-    b.syms = syms;
-    b.sym_stride = sym_stride;
-    b.produced = produced;
-    b.bits = bits;
-    b.bit_stride = bit_stride;
-    b.prev_sym_in = h->d_tprev[h->tcur];
-    b.prev_bit_in = h->d_tbit[h->tcur];
-    b.prev_sym_out = h->d_tprev[h->tcur ^ 1];
-    b.prev_bit_out = h->d_tbit[h->tcur ^ 1];
-    b.atan_tab = h->d_atan;
-    const int nseg = std::max(1, (max_out + BT_SEG - 1) / BT_SEG);
-    hipLaunchKernelGGL(k_bittail, dim3(nseg, h->nchan), dim3(BT_T), 0, st, b);
-    AISX_HIPCHK(hipGetLastError());
-    h->tcur ^= 1;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
-                                       const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
-                                       float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
-                                       void* stream)
-{
-    if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n || (d_tags && (!d_tag_counts || tag_cap < 1))) {
-        set_err("aisx_msk_process_stream: bad argument");
-        return AISX_ERR_INVALID;
-    }
-    if (out_stride < 1) {
-        set_err("aisx_msk_process_stream: out_stride < 1");
-        return AISX_ERR_INVALID;
-    }
-    int rc;
-    if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, (hipStream_t)stream)) != AISX_OK)
-        return rc;
-    MskParams p;
-    msk_fill_common(h, p);
-    p.in = (const cf*)d_in;
-    p.in_stride = in_stride;
-    p.n = n;
-    p.stream_mode = 1;
-    p.gr_ninput = 0;
-    p.gr_noutput = 0;
-    cf* syms = (cf*)d_syms;
-    if (out_stride >= (1L << 23)) {
-        set_err("aisx_msk_process_stream: out_stride %ld too large (the 64 rows of a wave must lie within 4 GiB)", out_stride);
-        return AISX_ERR_INVALID;
-    }
-    const int par = h->callpar;
-    h->callpar ^= 1;
-    if (h->tail_on && h->ev_tail_set[par]) // the bit tail of two calls ago may still read this parity's buffers
-        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[par], 0));
-    if (!syms) { // the kernel always writes symbols (the bit tail reads them back): give them a home
-        const size_t need = (size_t)h->nchan * (size_t)out_stride;
-        if (need > h->symscratch_len[par]) {
-            AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-            dev_free(h->d_symscratch[par]);
-            h->d_symscratch[par] = nullptr;
-            h->symscratch_len[par] = 0;
-            if ((rc = dev_alloc(&h->d_symscratch[par], need)) != AISX_OK)
-                return rc;
-            AISX_HIPCHK(hipDeviceSynchronize()); // (the zero fill runs on the null stream)
-            h->symscratch_len[par] = need;
-        }
-        syms = h->d_symscratch[par];
-    }
-    p.syms = syms;
-    p.err = d_err;
-    p.mu_out = d_mu;
-    p.out_stride = out_stride;
-    p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
-    p.produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
-    if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), (hipStream_t)stream)) != AISX_OK)
-        return rc;
-    h->cur ^= 1;
-    if (d_bits) {
-        // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
-        const double wmin = (double)h->d_sps - fabs((double)h->limit);
-        const int max_out = std::min<long>(p.out_cap, (long)ceil((n + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16);
-        hipStream_t ts = (hipStream_t)stream;
-        if (h->tail_on) { // the bit tail has no part in the recurrence: let the next call start
-            AISX_HIPCHK(hipEventRecord(h->ev_msk, (hipStream_t)stream));
-            AISX_HIPCHK(hipStreamWaitEvent(h->tail_stream, h->ev_msk, 0));
-            ts = h->tail_stream;
-        }
-        if ((rc = msk_launch_bittail(h, syms, out_stride, p.produced, d_bits, out_stride, max_out, ts)) != AISX_OK)
-            return rc;
-        if (h->tail_on) {
-            AISX_HIPCHK(hipEventRecord(h->ev_tail[par], h->tail_stream));
-            h->ev_tail_set[par] = true;
-        }
-    }
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_set_tail_stream(aisx_msk* h, void* tail_stream, int enable)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (!enable) {
-        h->tail_on = false;
-        return AISX_OK;
-    }
-    if (!h->ev_msk)
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_msk, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++)
-        if (!h->ev_tail[k])
-            AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_tail[k], hipEventDisableTiming));
-    h->tail_stream = (hipStream_t)tail_stream;
-    h->tail_on = true;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_wait_tail(aisx_msk* h, void* stream)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (h->tail_on)
-        for (int k = 0; k < 2; k++)
-            if (h->ev_tail_set[k])
-                AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[k], 0));
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_last_status(aisx_msk* h, int* status, void* stream)
-{
-    if (!h || !status)
-        return AISX_ERR_INVALID;
-    std::vector<int> st(h->nchan);
-    AISX_HIPCHK(hipMemcpyAsync(st.data(), h->d_status, sizeof(int) * h->nchan, hipMemcpyDeviceToHost,
-                               (hipStream_t)stream));
-    AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    int acc = 0;
-    for (int v : st)
-        acc |= v;
-    *status = acc;
-    return AISX_OK;
-}
-
-extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ninput_items, const aisx_cf32* in,
-                                          aisx_cf32* out, float* out_err, float* out_mu, uint8_t* out_bits,
-                                          const aisx_tag* tags, int ntags, uint64_t nitems_read,
-                                          int in_has_lookahead, int* consumed, int* produced)
-{
-    if (!h || !in || !out || !consumed || !produced || noutput_items < 0 || ninput_items < 0 || ntags < 0)
-        return AISX_ERR_INVALID;
-    if (h->nchan != 1) {
-        set_err("aisx_msk_general_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
-        return AISX_ERR_INVALID;
-    }
-    *consumed = 0;
-    *produced = 0;
-    if (ninput_items == 0 || noutput_items == 0)
-        return AISX_OK;
-    int rc;
-    // the interpolator reads up to in[ninput_items] (one past): stage one spare item
-    const int nin = ninput_items + 1;
-    if (nin > h->st_in_cap) {
-        dev_free(h->d_st_in);
-        if ((rc = dev_alloc(&h->d_st_in, nin)) != AISX_OK)
-            return rc;
-        h->st_in_cap = nin;
-    }
-    if (noutput_items > h->st_out_cap) {
-        dev_free(h->d_st_sym);
-        dev_free(h->d_st_err);
-        dev_free(h->d_st_mu);
-        dev_free(h->d_st_bits);
-        if ((rc = dev_alloc(&h->d_st_sym, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_err, noutput_items)) != AISX_OK ||
-            (rc = dev_alloc(&h->d_st_mu, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_bits, noutput_items)) != AISX_OK)
-            return rc;
-        h->st_out_cap = noutput_items;
-    }
-    if (ntags + 1 > h->st_tag_cap) {
-        dev_free(h->d_st_tags);
-        dev_free(h->d_st_tagn);
-        if ((rc = dev_alloc(&h->d_st_tags, ntags + 1)) != AISX_OK || (rc = dev_alloc(&h->d_st_tagn, 1)) != AISX_OK)
-            return rc;
-        h->st_tag_cap = ntags + 1;
-    }
-    AISX_HIPCHK(hipMemcpy(h->d_st_in, in, sizeof(cf) * (in_has_lookahead ? nin : ninput_items), hipMemcpyHostToDevice));
-    if (!in_has_lookahead)
-        AISX_HIPCHK(hipMemset(h->d_st_in + ninput_items, 0, sizeof(cf)));
-    if (ntags > 0)
-        AISX_HIPCHK(hipMemcpy(h->d_st_tags, tags, sizeof(tag_rec) * ntags, hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemcpy(h->d_st_tagn, &ntags, sizeof(int), hipMemcpyHostToDevice));
-    unsigned long long R = nitems_read;
-    AISX_HIPCHK(hipMemcpy(h->d_nread, &R, sizeof(R), hipMemcpyHostToDevice));
-    const int zero = 0;
-    AISX_HIPCHK(hipMemcpy(h->d_carry_len[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemcpy(h->d_ctag_n[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
-    if ((rc = msk_launch_tagprep(h, h->d_st_tags, h->d_st_tagn, ntags + 1, 0)) != AISX_OK)
-        return rc;
-    MskParams p;
-    msk_fill_common(h, p);
-    p.in = h->d_st_in;
-    p.in_stride = nin;
-    p.n = ninput_items;
-    p.stream_mode = 0;
-    p.gr_ninput = ninput_items;
-    p.gr_noutput = noutput_items;
-    p.syms = h->d_st_sym;
-    p.err = h->d_st_err;
-    p.mu_out = h->d_st_mu;
-    p.out_stride = noutput_items;
-    p.out_cap = noutput_items;
-    p.produced = h->d_produced;
-    if ((rc = msk_launch(p, 1, 0)) != AISX_OK)
-        return rc;
-    h->cur ^= 1;
-    if ((rc = msk_launch_bittail(h, h->d_st_sym, noutput_items, h->d_produced, h->d_st_bits, noutput_items,
-                                 noutput_items, 0)) != AISX_OK)
-        return rc;
-    int st = 0;
-    AISX_HIPCHK(hipMemcpy(produced, h->d_produced, sizeof(int), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(consumed, h->d_consumed, sizeof(int), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
-    const int np = *produced;
-    if (np > 0) {
-        AISX_HIPCHK(hipMemcpy(out, h->d_st_sym, sizeof(cf) * np, hipMemcpyDeviceToHost));
-        if (out_err)
-            AISX_HIPCHK(hipMemcpy(out_err, h->d_st_err, sizeof(float) * np, hipMemcpyDeviceToHost));
-        if (out_mu)
-            AISX_HIPCHK(hipMemcpy(out_mu, h->d_st_mu, sizeof(float) * np, hipMemcpyDeviceToHost));
-        if (out_bits)
-            AISX_HIPCHK(hipMemcpy(out_bits, h->d_st_bits, np, hipMemcpyDeviceToHost));
-    }
-    if (st & MSK_ST_INTERP_RANGE) {
-        set_err("mmse_fir_interpolator_cc: imu out of bounds."); // upstream std::runtime_error
-        return AISX_ERR_RUNTIME;
-    }
-    return AISX_OK;
-}

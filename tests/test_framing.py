@@ -93,3 +93,22 @@ def test_end_to_end_decode_on_the_oracle_chain_bits():
     for p in pdus:
         s = nm.msg_to_sentence(p)
         assert s.startswith("!AIVDM,1,1,,A,") and s == orc.pdu_to_nmea("A", p)
+
+
+def test_hdlc_rejects_frames_without_room_for_the_fcs_and_nmea_padding_quirk():
+    import pytest
+
+    # a frame is payload + two FCS octets: length_min < 2 would check a CRC over a negative length
+    with pytest.raises(ValueError):
+        ais_amd.hdlc_deframer_bp(1, 64)
+    with pytest.raises(ValueError):
+        ais_amd.hdlc_deframer_bp(20, 10)
+    # lib/pdu_to_nmea_impl.cc:70-78: with 4 fill bits (len % 3 == 1) the last group loses its two
+    # data bits to the second shift and always armours to '0'; with 2 fill bits a group >= 0x80
+    # skips the +8 step (signed char compare)
+    for last in (0x00, 0x01, 0x02, 0x03, 0xFF):
+        s = ais_amd.pdu_to_nmea("A").msg_to_sentence(bytes([0x12, 0x34, 0x56, last]))
+        body = s.split(",")[5]
+        assert len(body) == 6 and body[-1] == "0" and s.split(",")[6].startswith("4*")
+    s = ais_amd.pdu_to_nmea("A").msg_to_sentence(bytes([0xFF, 0xFF]))
+    assert s.split(",")[5] == "ww" + chr((0xF0 - 256 + 48) & 0xFF) and s.split(",")[6].startswith("2*")
