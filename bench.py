@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- complex MS/s through the demod hot path on MI355X, with the
-corr_est_cc kernel's HBM-roofline fraction and a CPU baseline.
+corr_est_cc kernel's HBM-roofline fraction, parity gates against the CPU oracle
+and a CPU baseline.
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -8,7 +9,9 @@ One "step" = one pass of the chain over one batch: CHANNELS_PER_GPU channels x
 SAMPLES complex samples per GPU, already resident in HBM.  Weak scaling: every
 rank owns its own channels, no data-path collective (channels are independent,
 SURVEY.md section 8e); torch.distributed (RCCL) is used only for the timing
-barrier and the max-over-ranks reduction.
+barrier and the max-over-ranks reduction.  With --gpus N > 1 and no launcher
+environment the script starts its N ranks itself (torch.distributed.run on
+127.0.0.1), one process per GPU.
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 4096
 batched channels, 65536 samples each, sps = 4, stock template (N = 896, SURVEY
@@ -16,11 +19,20 @@ D4).  The default chain is the whole flowgraph of python/ais_demod.py:56:
 freq_sync (square -> FFT -> freqest -> NCO mix) -> feedforward agc -> corr_est
 -> msk_timing_recovery -> NRZI bit tail; `value` is its throughput.  The same
 run also times `--chain core` (corr_est -> msk_timing only, the two blocks the
-metric string names) and reports it under "corr_est_to_msk_only".
+metric string names) and the correlator alone at BASELINE config 2's shapes
+(256 and 4096 channels, N = 896 and 112) and reports them under
+"corr_est_to_msk_only" and "corr_only".  BASELINE config 4 (65536 channels on
+8 GPUs) is `--gpus 8 --channels-per-gpu 8192`.
+
+After the timed region the last step of PARITY_CHANNELS channels is compared with
+the CPU oracle replaying the same steps on the same samples ("parity": tag
+offsets, peak magnitudes, time_est, decoded bursts -- BASELINE.md section 3).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +45,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CORR_BYTES_PER_SAMPLE = 16  # 8 B read + 8 B delayed pass-through write
+NUNIQ = 32  # CPU-generated channels the device input is built from
+METRIC = "complex MS/s through corr_est->msk_timing chain; corr_est %HBM roofline"
+CHAIN_TEXT = {"core": "corr_est->msk_timing+NRZI tail (no freq_sync / agc in front)",
+              "stock": "freq_sync(freqest)->agc->corr_est->msk_timing+NRZI tail (python/ais_demod.py:56)",
+              "corr": "corr_est only"}
 
 
 def make_template(family, sps):
@@ -44,22 +61,25 @@ def make_template(family, sps):
     return synth.gmsk_waveform(np.array(lv, float), sps)[: len(lv) * sps].astype(np.complex64)
 
 
+def input_params(family, stock):
+    return dict(amp=0.3 if stock else 1.0, cfo_max=500.0 if stock else (15.0 if family == "P" else 3.0))
+
+
 def make_input(nchan, T, family, sps, device, rank, stock):
-    """Synthetic IQ resident on the device: `nuniq` CPU-generated channels
+    """Synthetic IQ resident on the device: NUNIQ CPU-generated channels
     (seeded) replicated with a per-channel carrier phase, plus
     per-sample device-generated noise so that no two channels are equal."""
     import torch
     from ais_amd import synth
 
-    nuniq = 32
-    amp = 0.3 if stock else 1.0
-    cfo = 500.0 if stock else (15.0 if family == "P" else 3.0)
-    base = np.stack([synth.make_channel(synth.SEED0 + 1000 * rank + c, T, family, sps, amp=amp, cfo_max=cfo,
-                                        noise=False)[0] for c in range(nuniq)])
+    ip = input_params(family, stock)
+    amp = ip["amp"]
+    base = np.stack([synth.make_channel(synth.SEED0 + 1000 * rank + c, T, family, sps, amp=amp, cfo_max=ip["cfo_max"],
+                                        noise=False)[0] for c in range(NUNIQ)])
     g = torch.Generator(device=device)
     g.manual_seed(synth.SEED0 + rank)
     b = torch.as_tensor(base).to(device)
-    reps = (nchan + nuniq - 1) // nuniq
+    reps = (nchan + NUNIQ - 1) // NUNIQ
     x = b.repeat(reps, 1)[:nchan].contiguous()
     ph = torch.rand(nchan, generator=g, device=device) * (2 * np.pi)
     x *= torch.polar(torch.ones_like(ph), ph).to(torch.complex64).view(-1, 1)
@@ -69,44 +89,144 @@ def make_input(nchan, T, family, sps, device, rank, stock):
     return x
 
 
+def burst_infos(c, T, family, sps, rank, stock):
+    """What was transmitted in device channel c (= base channel c % NUNIQ)."""
+    from ais_amd import synth
+
+    ip = input_params(family, stock)
+    return synth.make_channel(synth.SEED0 + 1000 * rank + (c % NUNIQ), T, family, sps, amp=ip["amp"], cfo_max=ip["cfo_max"],
+                              noise=False)[1]
+
+
 def pmc_traffic(nchan, T, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     summary (collected in separate --pmc passes, see profiles/), if it was taken on
-    this workload; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_corr_main_pmc.json")
+    this workload; (None, None) otherwise."""
+    for name in ("r02_corr_main_pmc.json", "r01_corr_main_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {})
+        if (w.get("channels"), w.get("samples"), w.get("template_len")) == (nchan, T, N):
+            return d.get("hbm_bytes_per_launch"), "profiles/%s (kernel %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % (
+                name, d.get("kernel"))
+    return None, None
+
+
+def cpu_model():
     try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    w = d.get("workload", {})
-    if (w.get("channels"), w.get("samples"), w.get("template_len")) != (nchan, T, N):
-        return None
-    return d.get("hbm_bytes_per_launch")
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(chain, family, sps, T, budget_s=12.0, max_ch=512):
-    """The CPU oracle (a plain-C port of the reference's algorithm, single thread) on a bounded
-    sample of the same workload: whole channels of T samples, one after the other, until about
-    `budget_s` seconds of CPU work are done."""
+def cpu_baseline(chain, family, sps, T, budget_s=7.0, max_ch=4096):
+    """The CPU oracle (a plain-C port of the reference's algorithm: the reference's VOLK path
+    needs GNU Radio, absent here) on a bounded sample of the same workload, on this host:
+      B1  one thread, whole channels of T samples one after the other (the like-for-like of one
+          GNU Radio block thread chain), ~budget_s seconds of CPU work;
+      B2  all cores: one worker thread per core (the oracle releases the GIL inside ctypes), each
+          running whole channels, ~budget_s seconds of wall time.
+    `value` is B2, `cores` the threads it used; B1 is reported next to it."""
     import oracle_py as orc
     from ais_amd import synth
 
     tmpl = make_template(family, sps)
     stock = chain == "stock"
-    warm = orc.Demod(sps, tmpl, stages=3 if stock else 0)
-    warm.step(synth.make_channel(synth.SEED0, 4096, family, sps)[0])  # warm the FFT plan cache
+    ip = dict(amp=0.3 if stock else 1.0, cfo_max=500.0 if stock else 15.0)
+    stages = 3 if stock else 0
+    orc.Demod(sps, tmpl, stages=stages).step(synth.make_channel(synth.SEED0, 4096, family, sps)[0])  # FFT plan cache
+    xs = [synth.make_channel(synth.SEED0 + c, T, family, sps, **ip)[0] for c in range(8)]
+
+    def one(c):
+        dem = orc.Demod(sps, tmpl, stages=stages)
+        t0 = time.perf_counter()
+        dem.step(xs[c % len(xs)])
+        return time.perf_counter() - t0
+
     spent, nch = 0.0, 0
     while spent < budget_s and nch < max_ch:
-        x = synth.make_channel(synth.SEED0 + nch, T, family, sps, amp=0.3 if stock else 1.0,
-                               cfo_max=500.0 if stock else 15.0)[0]
-        dem = orc.Demod(sps, tmpl, stages=3 if stock else 0)
-        t0 = time.perf_counter()
-        dem.step(x)
-        spent += time.perf_counter() - t0
+        spent += one(nch)
         nch += 1
-    return dict(value=nch * T / spent / 1e6, unit="complex MS/s", cores=1, kind="port",
-                sample="%d channels x %d samples (%.1f s of CPU work), chain=%s, oracle/ais_oracle.c single thread"
-                       % (nch, T, spent, chain))
+    b1 = nch * T / spent / 1e6
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    # (the workers are C threads inside the oracle library: no interpreter in the timed loop)
+    done, wall = orc.demod_bench_mt(ncores, sps, tmpl, stages, np.stack(xs), budget_s)
+    b2 = done * T / wall / 1e6
+    return dict(value=b2, unit="complex MS/s", cores=ncores, kind="port",
+                sample="B2: %d channels x %d samples on %d threads in %.1f s wall; B1: %d channels on one thread (%.1f s); chain=%s; "
+                       "oracle/ais_oracle.c (gcc -O2, radix-2 FFT standing in for FFTW/VOLK)" % (done, T, ncores, wall, nch, spent, chain),
+                single_thread_value=b1, cpu_model=cpu_model(), nproc=os.cpu_count(),
+                reference_volk_path="unavailable (no GNU Radio / VOLK in the image)")
+
+
+def oracle_replay(chain, tmpl, sps, xk, nsteps):
+    """The oracle stepping `nsteps` times over the same samples (one row of xk per channel), as the
+    benchmark does; returns, per channel, the last step's (bits, tags).  One thread per channel."""
+    import concurrent.futures as cf
+
+    import oracle_py as orc
+
+    orc.lib()
+
+    def run(c):
+        if chain == "corr":
+            o = orc.CorrEst(tmpl, float(sps), 1, 0.9)
+            for _ in range(nsteps):
+                _, _, tags = o.work(xk[c])
+            return None, tags
+        dem = orc.Demod(sps, tmpl, stages=3 if chain == "stock" else 0)
+        for _ in range(nsteps):
+            bits, _, tags = dem.step(xk[c])
+        return bits, tags
+
+    with cf.ThreadPoolExecutor(min(len(xk), os.cpu_count() or 1)) as ex:
+        return list(ex.map(run, range(len(xk))))
+
+
+def parity_gates(chain, tmpl, sps, T, family, rank, xk, nsteps, gpu_tags, gpu_bits, gpu_prod, thresh):
+    """the last step of the channels in xk, HIP path vs oracle."""
+    from parity import compare_bursts, compare_detections
+
+    t0 = time.perf_counter()
+    ref = oracle_replay(chain, tmpl, sps, xk, nsteps)
+    K = len(xk)
+    tot = dict(detections=0, matched=0, offsets_equal=0, lone=0, lone_near_threshold=0)
+    mag = tim = 0.0
+    ncmp = same = near = 0
+    count_equal = 0
+    for c in range(K):
+        obits, otags = ref[c]
+        r = compare_detections(gpu_tags[gpu_tags["chan"] == c], otags, thresh)
+        for k in tot:
+            tot[k] += r[k]
+        mag = max(mag, r["mag_rel_max"])
+        tim = max(tim, r["time_est_abs_max"])
+        if obits is not None:
+            gb = gpu_bits[c, : gpu_prod[c]]
+            count_equal += int(gpu_prod[c] == len(obits))
+            a, b, d = compare_bursts(gb, obits, burst_infos(c, T, family, sps, rank, chain == "stock"))
+            ncmp, same, near = ncmp + a, same + b, near + d
+    out = {"channels": K, "steps_replayed": nsteps,
+           "detections": tot["detections"], "detections_matched_within_1": tot["matched"], "offsets_equal": tot["offsets_equal"],
+           "tags_within_1": bool(tot["lone"] == tot["lone_near_threshold"]),
+           "seen_by_one_side_only": tot["lone"], "of_which_within_2e-5_of_threshold": tot["lone_near_threshold"],
+           "mag_rtol_max": mag, "time_est_abs_max": tim,
+           "mag_gate_1e-5": bool(mag <= 1e-5), "time_est_gate_1e-4": bool(tim <= 1e-4),
+           "oracle_seconds": round(time.perf_counter() - t0, 2)}
+    if chain != "corr":
+        out.update(bursts_compared=ncmp, bursts_identical=near, bursts_identical_same_position=same,
+                   symbol_counts_equal=count_equal)
+    return out
 
 
 def bench_wideband(args, torch, device):
@@ -156,33 +276,86 @@ def bench_wideband(args, torch, device):
         "realtime_factor": n * args.steps / el / 25e6}))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--channels-per-gpu", type=int, default=4096)
+    ap.add_argument("--channels-per-gpu", type=int, default=4096,
+                    help="channels each rank owns (weak scaling); BASELINE config 4 = --gpus 8 --channels-per-gpu 8192")
     ap.add_argument("--samples", type=int, default=65536)
     ap.add_argument("--template", choices=["S", "P"], default="S", help="S: stock 896-sample template; P: 112-sample preamble")
     ap.add_argument("--chain", choices=["core", "stock", "corr", "wideband"], default="stock",
                     help="stock = the whole ais_demod.py flowgraph (freq_sync with freqest, agc, corr_est, msk timing "
                          "recovery, NRZI tail); core = corr_est -> msk only; corr = corr_est only; wideband = BASELINE "
                          "config 5: one 25 MS/s stream -> 1024-lane polyphase channelizer -> core chain")
-    ap.add_argument("--single-chain", action="store_true", help="do not add the corr_est->msk-only timing to a stock run")
+    ap.add_argument("--single-chain", action="store_true",
+                    help="only the chain asked for: no corr_est->msk-only and correlator-only side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--parity-channels", type=int, default=8, help="channels of the last step compared with the oracle (0: off)")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher check without a GPU: the ranks rendezvous over gloo, shard the channels and rank 0 "
+                         "prints the line with value 0 (tests/test_multiproc.py)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks of this script, one per GPU, on this node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if launched and world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
+    sps, T, nchan = 4, args.samples, args.channels_per_gpu
+    from ais_amd.shard import max_over_ranks, shard_channels
+
+    if args.dry:
+        if launched:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+        first, cnt = shard_channels(nchan * world, world, rank)
+        assert cnt == nchan and first == rank * nchan
+        if launched:
+            dist.barrier()
+        el = max_over_ranks(1e-3 * (1 + rank))
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "complex MS/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "none", "dry": True,
+                              "config": {"workload": "dry run: %d ranks x %d channels, nothing computed" % (world, nchan),
+                                         "channels_per_gpu": nchan, "parallelism": "channel-sharded x%d, no collective" % world},
+                              "max_over_ranks_check": el}))
+        if launched:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libaisx has no CPU path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    use_dist = launched
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
@@ -191,19 +364,18 @@ def main():
 
     if args.chain == "wideband":
         return bench_wideband(args, torch, device)
-    sps, T, nchan = 4, args.samples, args.channels_per_gpu
     tmpl = make_template(args.template, sps)
     opts = dict(samples_per_symbol=sps, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
-    from ais_amd.shard import max_over_ranks
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(chain):
+    def measure(chain, want_parity):
         """K timed steps of `chain` on this rank's channel shard; returns the wall time (max over
-        ranks) and the correlator kernel's per-launch times inside the timed region."""
+        ranks), the correlator kernel's per-launch times inside the timed region and (rank 0) the
+        parity gates of the last step."""
         stock = chain == "stock"
         x = make_input(nchan, T, args.template, sps, device, rank, stock)
         dem = ais_amd.ais_demod(opts, nchan=nchan, max_items=T, stages="stock" if stock else "core",
@@ -261,6 +433,24 @@ def main():
         # per-launch duration of the dominant kernel over the timed region: hipEvents
         # recorded around it on its launch stream in every step, read back only now
         kern_ms = corr.kernel_ms_history()[-args.steps:]
+        res = dict(kern_ms=kern_ms, st=0, ndet=0, parity=None, tag_overflow=False)
+        if rank == 0:
+            # the last step's results, before anything else touches the handles
+            res["st"] = dem.clockrec.last_status() if chain != "corr" else 0
+            try:
+                tags = corr.tags()
+            except OverflowError:
+                res["tag_overflow"] = True
+                tags = corr.tags(allow_overflow=True)
+            res["ndet"] = int((tags["key"] == 2).sum())
+            K = min(args.parity_channels, nchan) if want_parity else 0
+            if K > 0:
+                last = (state["k"] - 1) % NBUF
+                gbits = outs[last]["bits"][:K].cpu().numpy() if chain != "corr" else None
+                gprod = outs[last]["produced"][:K].cpu().numpy() if chain != "corr" else None
+                res["parity"] = parity_gates(chain, tmpl, sps, T, args.template, rank, x[:K].cpu().numpy(),
+                                             args.warmup + args.steps, tags[tags["chan"] < K], gbits, gprod, corr.threshold())
+        barrier()
         # the same kernel with the chip to itself (no timing-recovery kernel alongside)
         iso = []
         for _ in range(3):
@@ -268,30 +458,54 @@ def main():
                 corr.work(x if not stock else y_corr[0], out=y_corr[1])
             iso.append(corr.last_kernel_ms())
         torch.cuda.synchronize()
-        el = max_over_ranks(el, device=device)
-        res = dict(el=el, kern_ms=kern_ms, iso=iso, st=0, ndet=0)
-        if rank == 0:
-            res["st"] = dem.clockrec.last_status() if chain != "corr" else 0
-            tags = corr.tags(allow_overflow=True)
-            res["ndet"] = int((tags["key"] == 2).sum())
+        res["el"] = max_over_ranks(el, device=device)
+        res["iso"] = iso
         del dem, x, y_corr, outs
         torch.cuda.empty_cache()
         return res
 
-    CHAIN_TEXT = {"core": "corr_est->msk_timing+NRZI tail (no freq_sync / agc in front)",
-                  "stock": "freq_sync(freqest)->agc->corr_est->msk_timing+NRZI tail (python/ais_demod.py:56)",
-                  "corr": "corr_est only"}
-    r = measure(args.chain)
+    def measure_corr_only(nch, family):
+        """corr_est alone (BASELINE config 2's shape when nch = 256): kernel time by hipEvents."""
+        tm = make_template(family, sps)
+        x = make_input(nch, T, family, sps, device, rank, False)
+        blk = ais_amd.corr_est_cc(tm, float(sps), 1, 0.9, nchan=nch, max_items=T)
+        blk.set_profiling(True)
+        out = torch.empty_like(x)
+        for _ in range(3):
+            blk.work(x, out=out)
+        torch.cuda.synchronize()
+        blk.set_profiling(True)
+        t0 = time.perf_counter()
+        nrun = 20
+        for _ in range(nrun):
+            blk.work(x, out=out)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / nrun
+        kms = float(np.mean(blk.kernel_ms_history()[-nrun:]))
+        nbytes = CORR_BYTES_PER_SAMPLE * float(nch) * T
+        r = dict(channels=nch, template_len=int(tm.size), kernel="k_corr4_main" if tm.size > 512 else "k_corr_main",
+                 kernel_ms=kms, call_ms=wall * 1e3, achieved_GBs=nbytes / (kms * 1e-3) / 1e9,
+                 frac=nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, complex_MSs=float(nch) * T / wall / 1e6)
+        del blk, x, out
+        torch.cuda.empty_cache()
+        return r
+
+    r = measure(args.chain, True)
     el, kern_ms, iso, st = r["el"], r["kern_ms"], r["iso"], r["st"]
-    # the default run also times the two-block chain the metric string names, for reference
-    extra = measure("core") if (args.chain == "stock" and not args.single_chain) else None
+    side = not args.single_chain
+    # the default run also times the two-block chain the metric string names, and the correlator alone
+    extra = measure("core", False) if (args.chain == "stock" and side) else None
+    corr_only = None
+    if side and world == 1:
+        corr_only = [measure_corr_only(c, f) for c in (256, 4096) for f in ("S", "P")]
 
     if rank == 0:
         total_samples = float(nchan) * T * world * args.steps
         kms = float(np.mean(kern_ms))
         achieved = CORR_BYTES_PER_SAMPLE * float(nchan) * T / (kms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(nchan, T, int(tmpl.size))
         line = {
-            "metric": "complex MS/s through corr_est->msk_timing chain; corr_est %HBM roofline",
+            "metric": METRIC,
             "value": total_samples / el / 1e6,
             "unit": "complex MS/s",
             "n_gpus": world,
@@ -320,8 +534,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(nchan, T, int(tmpl.size)),
-                "traffic_source": "profiles/r01_corr_main_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": kms,
                 "kernel_ms_alone": float(np.mean(iso)),
                 "frac_alone": CORR_BYTES_PER_SAMPLE * float(nchan) * T / (float(np.mean(iso)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -329,7 +543,9 @@ def main():
                         "previous step shares the chip; *_alone = same launch with nothing else running",
                 "algorithmic_bytes_per_launch": CORR_BYTES_PER_SAMPLE * float(nchan) * T,
             },
+            "parity": r["parity"],
             "detections_last_step": r["ndet"],
+            "tag_overflow": r["tag_overflow"],
             "msk_status": int(st),
         }
         if extra is not None:
@@ -340,7 +556,10 @@ def main():
                 "ms_per_step": extra["el"] / args.steps * 1e3,
                 "corr_kernel_ms": float(np.mean(extra["kern_ms"])),
                 "detections_last_step": extra["ndet"],
+                "msk_status": int(extra["st"]),
             }
+        if corr_only is not None:
+            line["corr_only"] = corr_only
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.chain if args.chain != "corr" else "core", args.template, sps, T)
         print(json.dumps(line))

@@ -1264,3 +1264,86 @@ int orc_firdes_low_pass(double gain, double fs, double cutoff, double transition
         taps[i] = (float)(taps[i] * gain);
     return ntaps;
 }
+
+/* ------------------------------------------------------------------ */
+/* CPU baseline B2: all cores, the  */
+/* channels split across threads.  Every worker runs whole channels of */
+/* nx samples through its own chain (orc_demod_create / _step /        */
+/* _destroy, no shared state but the read-only FFT plans) until        */
+/* budget_s seconds have passed.  Returns the channels completed;      */
+/* *wall_s = the wall time they took.  Timing harness only.            */
+/* ------------------------------------------------------------------ */
+#include <time.h>
+
+typedef struct {
+    float sps;
+    const orc_cf *symbols;
+    int nsym, stages;
+    const orc_cf *x;
+    int nx, nsets, index;
+    double budget_s, t0;
+    long done;
+} orc_bench_job;
+
+static double orc_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *orc_bench_worker(void *arg)
+{
+    orc_bench_job *j = (orc_bench_job *)arg;
+    unsigned char *bits = (unsigned char *)malloc((size_t)j->nx + 64);
+    long k = 0;
+    while (orc_now() - j->t0 < j->budget_s) {
+        orc_demod *d = orc_demod_create(j->sps, 9600.0f, 0.04f, 0.01f, 1024, j->symbols, j->nsym, j->stages);
+        if (!d)
+            break;
+        orc_demod_step(d, j->x + (size_t)((j->index + k) % j->nsets) * (size_t)j->nx, j->nx, bits, j->nx + 64, NULL, NULL, 0, NULL);
+        orc_demod_destroy(d);
+        k++;
+    }
+    free(bits);
+    j->done = k;
+    return NULL;
+}
+
+long orc_demod_bench_mt(int nthreads, float sps, const orc_cf *symbols, int nsym, int stages, const orc_cf *x, int nx,
+                        int nsets, double budget_s, double *wall_s)
+{
+    if (nthreads < 1 || nsets < 1 || nx < 1)
+        return 0;
+    { /* create the FFT plans before the workers start */
+        orc_demod *d = orc_demod_create(sps, 9600.0f, 0.04f, 0.01f, 1024, symbols, nsym, stages);
+        unsigned char *bits = (unsigned char *)malloc((size_t)nx + 64);
+        int warm = nx < 8192 ? nx : 8192;
+        if (d) {
+            orc_demod_step(d, x, warm, bits, nx + 64, NULL, NULL, 0, NULL);
+            orc_demod_destroy(d);
+        }
+        free(bits);
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    orc_bench_job *jobs = (orc_bench_job *)calloc((size_t)nthreads, sizeof(orc_bench_job));
+    const double t0 = orc_now();
+    for (int i = 0; i < nthreads; i++) {
+        orc_bench_job j = { sps, symbols, nsym, stages, x, nx, nsets, i, budget_s, t0, 0 };
+        jobs[i] = j;
+        if (pthread_create(&th[i], NULL, orc_bench_worker, &jobs[i]) != 0) {
+            nthreads = i;
+            break;
+        }
+    }
+    long total = 0;
+    for (int i = 0; i < nthreads; i++) {
+        pthread_join(th[i], NULL);
+        total += jobs[i].done;
+    }
+    if (wall_s)
+        *wall_s = orc_now() - t0;
+    free(th);
+    free(jobs);
+    return total;
+}

@@ -131,6 +131,12 @@ void orc_freq_xlating_fir(const float *taps, int ntaps, int decim, double center
                           long nx, long k0, int nout, orc_cf *out);
 int orc_firdes_low_pass(double gain, double fs, double cutoff, double transition, float *taps, int cap);
 
+/* CPU baseline B2: `nthreads` workers each run whole channels of nx samples (taken round robin
+ * from the nsets rows of x) through a chain of their own for ~budget_s seconds.  Returns the
+ * channels completed, *wall_s the wall time.  Timing harness for bench.py's cpu_baseline. */
+long orc_demod_bench_mt(int nthreads, float sps, const orc_cf *symbols, int nsym, int stages, const orc_cf *x, int nx,
+                        int nsets, double budget_s, double *wall_s);
+
 #ifdef __cplusplus
 }
 #endif

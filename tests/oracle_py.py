@@ -90,6 +90,8 @@ def lib():
         L.orc_demod_destroy.argtypes = [vp]
         L.orc_demod_step.restype = i32
         L.orc_demod_step.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, pi32]
+        L.orc_demod_bench_mt.restype = C.c_long
+        L.orc_demod_bench_mt.argtypes = [i32, f32, vp, i32, i32, vp, i32, i32, f64, C.POINTER(C.c_double)]
         L.orc_hdlc_init.argtypes = [vp, i32, i32]
         L.orc_hdlc_work.restype = i32
         L.orc_hdlc_work.argtypes = [vp, vp, i32, vp, i32, vp, i32]
@@ -365,6 +367,17 @@ class Demod:
         nb = lib().orc_demod_step(self.h, _ptr(x), x.size, _ptr(bits), maxb, _ptr(syms) if want_syms else None,
                                   _ptr(tags), maxt, C.byref(nt))
         return bits[:nb].copy(), (syms[:nb].copy() if want_syms else None), tags[: min(nt.value, maxt)].copy()
+
+
+def demod_bench_mt(nthreads, sps, symbols, stages, xs, budget_s):
+    """CPU baseline B2: (channels completed, wall seconds) of `nthreads` C threads running whole
+    channels (rows of xs) through the oracle chain for ~budget_s seconds."""
+    s = _c64(symbols)
+    x = np.ascontiguousarray(xs, dtype=np.complex64)
+    wall = C.c_double(0)
+    done = lib().orc_demod_bench_mt(int(nthreads), float(sps), _ptr(s), s.size, int(stages), _ptr(x), x.shape[1], x.shape[0],
+                                    float(budget_s), C.byref(wall))
+    return int(done), wall.value
 
 
 class Hdlc(C.Structure):

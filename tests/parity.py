@@ -86,5 +86,64 @@ def assert_decoded_bursts_identical(got_bits, want_bits, infos, min_frac_equal=0
             ncmp += 1
     if want_bits.size:
         frac = float(np.mean(got_bits == want_bits))
+        print("    bits equal to the oracle's: %.5f of %d" % (frac, want_bits.size))
         assert frac >= min_frac_equal, "only %.4f of the bits agree" % frac
     return ncmp, len(infos)
+
+
+def compare_detections(got, want, thr=None):
+    """Non-asserting comparison of two tag lists of one channel and one call (the gates of
+    BASELINE.md section 3, as numbers): detection groups are paired when their corr_start offsets
+    are within +-1 sample; a group present on one side only is `lone` (and `lone_near_threshold`
+    if its peak is within 2e-5 relative of the correlator's threshold: both correlators agree to
+    ~3e-7, so only such a peak can be seen by one and not by the other)."""
+    g, w = tag_groups(got), tag_groups(want)
+    r = dict(detections=len(w), matched=0, offsets_equal=0, lone=0, lone_near_threshold=0, mag_rel_max=0.0,
+             time_est_abs_max=0.0, phase_abs_max=0.0)
+    i = j = 0
+    while i < len(g) or j < len(w):
+        a = g[i] if i < len(g) else None
+        b = w[j] if j < len(w) else None
+        if a is not None and b is not None and abs(a["start"] - b["start"]) <= 1:
+            r["matched"] += 1
+            r["mag_rel_max"] = max(r["mag_rel_max"], abs(a["mag"] - b["mag"]) / max(abs(b["mag"]), 1e-30),
+                                   abs(a["est"] - b["est"]) / max(abs(b["est"]), 1e-30))
+            if a["start"] == b["start"]:
+                r["offsets_equal"] += 1
+                r["time_est_abs_max"] = max(r["time_est_abs_max"], abs(a["center"] - b["center"]))
+                d = abs(a["phase"] - b["phase"])
+                r["phase_abs_max"] = max(r["phase_abs_max"], min(d, abs(d - 2 * np.pi)))
+            i += 1
+            j += 1
+            continue
+        lone = a if (b is None or (a is not None and a["start"] < b["start"])) else b
+        r["lone"] += 1
+        if thr is not None and abs(lone["mag"] - thr) <= 2e-5 * thr:
+            r["lone_near_threshold"] += 1
+        if lone is a:
+            i += 1
+        else:
+            j += 1
+    return r
+
+
+def compare_bursts(got_bits, want_bits, infos, slack=4):
+    """Every burst the reference side's bit stream holds (its HDLC-framed data bits found in
+    `want_bits`) is looked up in `got_bits`: bit for bit at the same position, or within +-slack
+    positions (a detection seen by one chain only re-times the loop and can move the symbol count
+    by one in the noise before the burst).  Returns (compared, identical_in_place, identical_within_slack)."""
+    from ais_amd import synth
+
+    got_bits = np.asarray(got_bits, dtype=np.uint8)
+    want_bits = np.asarray(want_bits, dtype=np.uint8)
+    ncmp = same = near = 0
+    for inf in infos:
+        pat = np.asarray(inf["data_bits"], dtype=np.uint8)
+        for pos in synth.find_bits(want_bits, pat):
+            ncmp += 1
+            if np.array_equal(got_bits[pos:pos + pat.size], pat):
+                same += 1
+                near += 1
+            elif any(np.array_equal(got_bits[max(pos + d, 0):max(pos + d, 0) + pat.size], pat) for d in range(-slack, slack + 1)):
+                near += 1
+    return ncmp, same, near

@@ -88,3 +88,25 @@ def test_two_rank_gloo_shards_cover_all_channels():
         _, _, tags = orc.Demod(4, tmpl, stages=0).step(x)
         want.append(int((tags["key"] == 2).sum()))
     assert allc == want and tmax == 2.0
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself
+    (torch.distributed.run on 127.0.0.1) and report n_gpus = 2; --dry keeps the ranks on the CPU
+    (gloo rendezvous, channel sharding, max-over-ranks), nothing is computed."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--channels-per-gpu", "8192"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry"] is True and line["scaling"] == "weak"
+    assert line["config"]["channels_per_gpu"] == 8192 and line["max_over_ranks_check"] == 2e-3
+    # one rank, no launcher
+    out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry"], env=env, capture_output=True, text=True,
+                          timeout=300)
+    assert out1.returncode == 0 and json.loads(out1.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -16,9 +16,10 @@ __device__ __forceinline__ void dma16(v4i rsrc, unsigned voff, unsigned lds_dst)
                  : "memory");
 }
 
-__global__ void k_probe(const float* src, unsigned nbytes, unsigned start_byte, float* out)
+__global__ void k_probe(const float* src, unsigned nbytes, unsigned start_byte, float* out, unsigned lds_shift)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem0[];
+    char* smem = smem0 + lds_shift; // (destinations beyond 64 KiB: M0 must carry more than 16 address bits)
     const int t = threadIdx.x;
     // poison
     for (int i = t; i < 4096; i += blockDim.x)
@@ -58,7 +59,9 @@ int main()
     for (int s = 0; s < 3; s++) {
         // the resource ends 100 floats before the last piece ends
         const unsigned nbytes = (unsigned)((8 * 256 - 100) * 4) + starts[s];
-        hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), 16384, 0, d, nbytes, starts[s], o);
+        const unsigned shift = (s == 2) ? 100u * 1024u : 0u;
+        (void)hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        hipLaunchKernelGGL(k_probe, dim3(1), dim3(256), 16384 + shift, 0, d, nbytes, starts[s], o, shift);
         hipError_t e = hipDeviceSynchronize();
         (void)hipMemcpy(r.data(), o, r.size() * 4, hipMemcpyDeviceToHost);
         int bad = 0, zeros = 0, poison = 0;
@@ -71,6 +74,7 @@ int main()
                 if (inr) bad += (v != (float)srcf);
                 else { zeros += (v == 0.f); bad += (v != 0.f); }
             }
+        printf("lds shift %u: ", shift);
         printf("start %u B: err=%d  bad=%d  oob-zeros=%d (expect %d)  pad-untouched=%d (expect 128)\n", starts[s], (int)e, bad, zeros,
                100 - 0, poison);
     }
