@@ -37,6 +37,39 @@ AISX_HD cf operator+(cf a, cf b) { return mk(a.re + b.re, a.im + b.im); }
 AISX_HD cf operator-(cf a, cf b) { return mk(a.re - b.re, a.im - b.im); }
 AISX_HD cf cconj(cf a) { return mk(a.re, -a.im); }
 
+// LDS / global accesses whose alignment the compiler cannot see for itself (pointers that
+// alternate between two images): one item as a 64-bit access, two neighbours as a 128-bit one.
+// The caller guarantees the alignment (8 resp. 16 bytes).
+struct alignas(8) cf_a8 { float re, im; };
+struct alignas(16) cf_a16 { float re0, im0, re1, im1; };
+AISX_HD cf ld8(const cf* p)
+{
+    const cf_a8 v = *reinterpret_cast<const cf_a8*>(p);
+    return mk(v.re, v.im);
+}
+AISX_HD void st8(cf* p, cf v)
+{
+    cf_a8 t;
+    t.re = v.re;
+    t.im = v.im;
+    *reinterpret_cast<cf_a8*>(p) = t;
+}
+AISX_HD void ld16(const cf* p, cf& a, cf& b)
+{
+    const cf_a16 v = *reinterpret_cast<const cf_a16*>(p);
+    a = mk(v.re0, v.im0);
+    b = mk(v.re1, v.im1);
+}
+AISX_HD void st16(cf* p, cf a, cf b)
+{
+    cf_a16 t;
+    t.re0 = a.re;
+    t.im0 = a.im;
+    t.re1 = b.re;
+    t.im1 = b.im;
+    *reinterpret_cast<cf_a16*>(p) = t;
+}
+
 // std::complex<float> product as libstdc++ evaluates it: (ac - bd, ad + bc),
 // every operation rounded to float, no fusing.  Used on the bit-exact paths
 // (timing recovery, NCO mix, AGC).

@@ -122,6 +122,63 @@ struct DevCtx {
     __device__ __forceinline__ int readlane_i32(int v, int lane) const { return __builtin_amdgcn_readlane(v, lane); }
     __device__ __forceinline__ int ctz64(unsigned long long v) const { return __ffsll((long long)v) - 1; }
     __device__ __forceinline__ void atomic_or64(unsigned long long* p, unsigned long long v) const { atomicOr(p, v); }
+
+    // ---- raw buffers and LDS-DMA (k_corr4d.h) ------------------------------------------------
+    // A raw buffer: wave-uniform base + byte count; an access whose byte offset (the VGPR part)
+    // lies beyond the count is dropped (stores) or returns zeros (loads) by the hardware.
+    struct Buf {
+        const void* base;
+        unsigned nbytes;
+    };
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ int wave_id() const { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+    __device__ __forceinline__ Buf make_buf(const void* base, unsigned nbytes) const
+    {
+        // (descriptor inputs made provably wave-uniform: they must end up in scalar registers)
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)base);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)base >> 32));
+        Buf b;
+        b.base = (const void*)(((size_t)hi << 32) | (size_t)lo);
+        b.nbytes = __builtin_amdgcn_readfirstlane(nbytes);
+        return b;
+    }
+    // LDS byte address of a pointer into the workgroup's LDS (what the DMA takes as destination)
+    __device__ __forceinline__ unsigned lds_addr(const void* p) const { return (unsigned)(size_t)p; }
+    // Asynchronous global -> LDS copy, 16 bytes per lane: lane l of the wave writes LDS bytes
+    // [lds_dst + 16 l, +16) with buffer bytes [byte_off, +16) (zeros where that is out of range).
+    // `buffer_load_dwordx4 ... lds`: the data never passes through VGPRs, M0 carries the
+    // wave-uniform destination.  The compiler does not see the transfer: it completes with
+    // wait_dma() (vmcnt), and a barrier makes it visible to the other waves.
+    __device__ __forceinline__ void dma16(const Buf& b, unsigned byte_off, unsigned lds_dst) const
+    {
+        v4i w;
+        w.x = (int)(unsigned)(size_t)b.base;
+        w.y = (int)(unsigned)(((size_t)b.base >> 32) & 0xffffu);
+        w.z = (int)b.nbytes;
+        w.w = 0x00020000;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(byte_off), "s"(w), "s"(dst)
+                     : "memory");
+    }
+    // all of this wave's vector-memory operations (DMA included) have completed
+    __device__ __forceinline__ void wait_dma() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
+    // outstanding global stores or for DMA still in flight
+    __device__ __forceinline__ void lds_barrier() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    // one complex item to buffer byte offset voff + soff; range-checked on voff only (the scalar
+    // part is added after the check)
+    __device__ __forceinline__ void buf_store64(const Buf& b, unsigned voff, unsigned soff, cf v) const
+    {
+        v2u d;
+        d.x = __float_as_uint(v.re);
+        d.y = __float_as_uint(v.im);
+        __builtin_amdgcn_raw_buffer_store_b64(d, __builtin_amdgcn_make_buffer_rsrc((void*)b.base, 0, (int)b.nbytes, 0x00020000),
+                                              (int)voff, (int)soff, 0);
+    }
 };
 
 // The same context with the butterfly primitives left to the compiler (plain C++ complex

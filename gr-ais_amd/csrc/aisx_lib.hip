@@ -71,6 +71,26 @@ __global__ __launch_bounds__(CF4_T, 3) void k_corr4_main(CorrParams p)
     corr4_main_body(cx, p);
 }
 
+// the F = 4096 correlator with the next tile's window prefetched by LDS-DMA (k_corr4d.h): two
+// workgroups per CU (two 34 KB window images each), up to 256 VGPRs
+template <int NC>
+__global__ __launch_bounds__(CF4_T, 2) void k_corr4d_main(CorrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4d_main_body<DevCtx, NC>(cx, p);
+}
+// builds with the template length folded in: the stock template at 4 and at 5 samples per symbol
+// (224 symbols, python/ais_demod.py:36-38); every other length runs the <0> build
+static void (*corr4d_pick(int N))(CorrParams)
+{
+    switch (N) {
+    case 896: return k_corr4d_main<896>;
+    case 1120: return k_corr4d_main<1120>;
+    default: return k_corr4d_main<0>;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
     __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
@@ -84,6 +104,8 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 struct aisx_corr {
     int nchan = 0, N = 0, max_items = 0, tag_cap = 0, L = 0, isps = 0, out_multiple = 0;
     int F = CF_F; // FFT build serving this template length
+    bool dma = true; // F = 4096: the k_corr4d.h build (AISX_CORR_DMA=0 selects k_corr4k.h's)
+    const void* dma_attr_set = nullptr; // build whose dynamic-LDS limit has been raised
     float sps = 0, thresh = 0;
     unsigned mark_delay = 0;
     std::vector<cf> symbols; // d_symbols
@@ -157,6 +179,8 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->sps = sps;
     h->F = corr_pick_fft(nsym);
     h->L = h->F - nsym;
+    if (const char* e = getenv("AISX_CORR_DMA")) // (experiments, and the tests of the other build)
+        h->dma = atoi(e) != 0;
     // constructor maths of lib/corr_est_cc_impl.cc:58-85 (aisx_plan.h)
     CorrSetup cs = corr_setup((const cf*)symbols, nsym, sps, mark_delay, threshold);
     h->symbols = cs.symbols;
@@ -346,8 +370,9 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    const bool dma = h->dma && h->F == CF4_F;
     int nseg, tps;
-    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps);
+    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, dma ? 2 : 0);
 
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;
@@ -374,10 +399,18 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
-    if (h->F == CF_F)
+    if (h->F == CF_F) {
         hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
-    else
+    } else if (dma) {
+        void (*kern)(CorrParams) = corr4d_pick(h->N);
+        if (h->dma_attr_set != (const void*)kern) {
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES));
+            h->dma_attr_set = (const void*)kern;
+        }
+        hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(CF4_T), CD_LDS_BYTES, st, p);
+    } else {
         hipLaunchKernelGGL(k_corr4_main, dim3(nseg, h->nchan), dim3(CF4_T), CF4_LDS_BYTES, st, p);
+    }
     AISX_HIPCHK(hipGetLastError());
     if (h->prof) {
         AISX_HIPCHK(hipEventRecord(h->ev1[evi], st));

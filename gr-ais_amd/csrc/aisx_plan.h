@@ -10,6 +10,7 @@
 #include "aisx_common.h"
 #include "k_corr.h"
 #include "k_corr4k.h"
+#include "k_corr4d.h"
 
 namespace aisx {
 
@@ -68,10 +69,12 @@ inline std::vector<cf> corr_padded_taps(const std::vector<cf>& stored, int F)
 // that the grid is close to a whole number of full-chip rounds (256 CUs x 6
 // resident workgroups of the F = 2048 build at 154 VGPRs / 18 KB LDS, 2 of the F = 4096 build): a ragged last round is pure loss
 // for a kernel whose workgroups all take the same time.
-inline void corr_grid(int nchan, int n, int L, int F, int* nseg, int* tiles_per_seg)
+inline void corr_grid(int nchan, int n, int L, int F, int* nseg, int* tiles_per_seg, int wg_per_cu = 0)
 {
     const int ntiles = (n + L - 1) / L;
-    const long slots = 256L * (F == CF_F ? 6 : 3); // resident workgroups per CU of the two builds
+    // resident workgroups per CU: 6 (F = 2048), 3 (F = 4096, k_corr4k.h), 2 (F = 4096 with the
+    // window prefetched by DMA, k_corr4d.h: two LDS images per workgroup)
+    const long slots = 256L * (wg_per_cu > 0 ? wg_per_cu : (F == CF_F ? 6 : 3));
     int best = 1;
     double best_cost = 1e30;
     for (int ns = 1; ns <= 16; ns++) {

@@ -62,7 +62,13 @@ constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
 // a workgroup is msk_waves(lpw) waves with lpw channels each: 64 channels for lpw >= 16, four
 // waves (one per SIMD) of 8 or 4 channels below; every wave has its own rings and tag queue, the
 // tap table behind them is shared
-constexpr int msk_waves(int lpw) { return lpw >= 16 ? 64 / lpw : 4; }
+// (measured, round 2: 4 channels per wave with EIGHT waves per workgroup -- two per SIMD on the
+// same 128 CUs -- is slower than 8 channels on four waves: 7.6 against 6.55 ms per step of the
+// whole flowgraph, 6.3 against 4.45 on corr_est -> msk; -DMSK_WAVES_LPW4=8 rebuilds that variant)
+#ifndef MSK_WAVES_LPW4
+#define MSK_WAVES_LPW4 4
+#endif
+constexpr int msk_waves(int lpw) { return lpw >= 16 ? 64 / lpw : (lpw == 4 ? MSK_WAVES_LPW4 : 4); }
 constexpr int msk_wg_channels(int lpw) { return msk_waves(lpw) * lpw; }
 constexpr int msk_lds_wave(int lpw) { return msk_lds_ring(lpw) + MSK_TAGQ * lpw * 8; }
 constexpr int msk_lds_taboff(int lpw) { return msk_waves(lpw) * msk_lds_wave(lpw); }

@@ -137,6 +137,34 @@ struct EmuCtx {
     int readlane_i32(int v, int lane) const { return xchg(v, lane); }
     int ctz64(unsigned long long v) const { return __builtin_ctzll(v); }
     void atomic_or64(unsigned long long* p, unsigned long long v) const { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+    // raw buffers and LDS-DMA (model of DevCtx's: the copy is done on the spot)
+    struct Buf {
+        const void* base;
+        unsigned nbytes;
+    };
+    int wave_id() const { return tid_ >> 6; }
+    Buf make_buf(const void* base, unsigned nbytes) const { return Buf{ base, nbytes }; }
+    unsigned lds_addr(const void* p) const { return (unsigned)((const char*)p - sh->lds.data()); }
+    void dma16(const Buf& b, unsigned byte_off, unsigned lds_dst) const
+    {
+        char* d = sh->lds.data() + lds_dst + 16 * (tid_ & 63);
+        for (int k = 0; k < 4; k++) { // dword granularity of the range check
+            const unsigned o = byte_off + 4u * k;
+            // (an access that starts out of range is taken as out of range altogether, also where
+            // its 32-bit offset would wrap back into the buffer: the pessimistic reading)
+            if (byte_off < b.nbytes && o < b.nbytes && o + 4u <= b.nbytes)
+                memcpy(d + 4 * k, (const char*)b.base + o, 4);
+            else
+                memset(d + 4 * k, 0, 4);
+        }
+    }
+    void wait_dma() const {}
+    void lds_barrier() const { sync(); }
+    void buf_store64(const Buf& b, unsigned voff, unsigned soff, cf v) const
+    {
+        if (voff < b.nbytes && voff + 8u <= b.nbytes)
+            memcpy((char*)b.base + voff + soff, &v, 8);
+    }
 };
 
 template <class Body>
@@ -184,12 +212,23 @@ void emu_corr_inith(const cf* taps_scaled, const cf* wtab, cf* Hpos, int F)
         run_grid(1, 1, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_inith_body(cx, p); });
 }
 
+// which F = 4096 build runs: 0 = k_corr4k.h, 1 = k_corr4d.h (the length-specialised build where
+// there is one, as the product picks), 2 = k_corr4d.h's run-time-length build
+static int g_corr_dma = 1;
+void emu_corr_set_dma(int mode) { g_corr_dma = mode; }
+
 void emu_corr_main(const CorrParams* p, int nchan, int F)
 {
     if (F == CF_F)
         run_grid(p->nseg, nchan, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_main_body(cx, *p); });
-    else
+    else if (g_corr_dma == 0)
         run_grid(p->nseg, nchan, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_main_body(cx, *p); });
+    else if (g_corr_dma == 1 && p->N == 896)
+        run_grid(p->nseg, nchan, CF4_T, CD_LDS_BYTES, [&](EmuCtx& cx) { corr4d_main_body<EmuCtx, 896>(cx, *p); });
+    else if (g_corr_dma == 1 && p->N == 1120)
+        run_grid(p->nseg, nchan, CF4_T, CD_LDS_BYTES, [&](EmuCtx& cx) { corr4d_main_body<EmuCtx, 1120>(cx, *p); });
+    else
+        run_grid(p->nseg, nchan, CF4_T, CD_LDS_BYTES, [&](EmuCtx& cx) { corr4d_main_body<EmuCtx, 0>(cx, *p); });
 }
 
 void emu_corr_resolve(const ResolveParams* p, int nchan)
@@ -266,7 +305,7 @@ int emu_corr_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
 {
     EmuCorr* h = (EmuCorr*)hv;
     int nseg, tps;
-    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps);
+    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, (h->F == CF4_F && g_corr_dma) ? 2 : 0);
     if (force_nseg > 0) {
         const int ntiles = (n + h->L - 1) / h->L;
         tps = (ntiles + force_nseg - 1) / force_nseg;

@@ -28,6 +28,7 @@ def lib():
         L.emu_corr_create.restype = vp
         L.emu_corr_create.argtypes = [vp, i32, f32, u32, f32, i32]
         L.emu_corr_destroy.argtypes = [vp]
+        L.emu_corr_set_dma.argtypes = [i32]
         L.emu_corr_threshold.restype = f32
         L.emu_corr_threshold.argtypes = [vp]
         L.emu_corr_output_multiple.restype = i32

@@ -100,3 +100,40 @@ def test_emul_corr_sps_rounding_and_mark_delay_clamp():
         _, _, tags, _, _ = e.work(x)
         _, _, ot = o.work(x[0])
         assert_tags_match(tags[0], ot)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("N", [896, 1120, 640, 513, 2047, 2048])
+def test_emul_corr_f4096_builds(mode, N):
+    # the three F = 4096 builds -- k_corr4k.h (0), k_corr4d.h with the template length folded in
+    # where such a build exists (1) and with it at run time (2): several tiles per segment (the
+    # window images alternate, the overlap is copied across, the next window arrives by "DMA"),
+    # several segments, a ragged last tile, calls with carried history, a peak on a call edge
+    emu.lib().emu_corr_set_dma(mode)
+    try:
+        rng = np.random.default_rng(31 * N + mode)
+        tmpl = unit_template(rng, N)
+        L = 4096 - N
+        lens = [3 * L + 517, 40, 2 * L + 1]
+        total = sum(lens)
+        e0 = lens[0]
+        pos = [[300, e0 - N, e0 + 30, total - N - 2], [L - 5, 2 * L + 100, e0 - N // 2]]
+        xs = planted(rng, 2, total, tmpl, pos, noise=0.03)
+        for nseg in (1, 2):
+            e = emu.CorrEst(tmpl, 4.0, 1, 0.9, nchan=2)
+            o = [orc.CorrEst(tmpl, 4.0, 1, 0.9) for _ in range(2)]
+            k = ndet = 0
+            for i, Ln in enumerate(lens):
+                chunk = xs[:, k:k + Ln]
+                dense = (i == 2)
+                out, corr, tags, cnt, _ = e.work(chunk, want_corr=dense, force_nseg=nseg)
+                for c in range(2):
+                    oo, oc, ot = o[c].work(chunk[c], want_corr=dense)
+                    assert np.array_equal(out[c], oo), (mode, N, nseg, i, c)
+                    if dense:
+                        assert np.max(np.abs(corr[c] - oc)) / (np.max(np.abs(oc)) + 1e-30) < 2e-6
+                    ndet += assert_tags_match(tags[c], ot)
+                k += Ln
+            assert ndet >= 6
+    finally:
+        emu.lib().emu_corr_set_dma(1)

@@ -137,6 +137,12 @@ int main(int argc, char** argv)
     int ntags[2] = { 0, 0 };
     const char* paths[2] = { libp, refp };
     for (int v = 0; v < (refp ? 2 : 1); v++) {
+        // "--ref same": the reference run is the same library with AISX_CORR_DMA=0 (the k_corr4k.h build)
+        if (refp && !strcmp(refp, "same")) {
+            paths[1] = libp;
+            if (v == 1)
+                setenv("AISX_CORR_DMA", "0", 1);
+        }
         Lib L;
         L.open(paths[v]);
         aisx_corr* h = nullptr;
