@@ -216,6 +216,49 @@ extern "C" int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long
     return AISX_OK;
 }
 
+// square_and_fft_sync_cc as one GNU Radio block (python/gmsk_sync.py:14-37 is a hier block of
+// stock blocks around ais.freqest): host pointers, nchan == 1.  `in` = n new items; `out`
+// receives every complete fftlen-vector's worth (pending items are kept in the handle, as
+// stream_to_vector does); returns the items written.
+extern "C" int aisx_freqsync_work_host(aisx_freqsync* h, const aisx_cf32* in, int n, aisx_cf32* out, int out_cap,
+                                       float* fhat, int fhat_cap)
+{
+    if (!h || !in || !out || n < 1 || n > h->max_items)
+        return AISX_ERR_INVALID;
+    if (h->nchan != 1) {
+        set_err("aisx_freqsync_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
+        return AISX_ERR_INVALID;
+    }
+    const int nvec = (h->npend + n) / h->fftlen;
+    if (out_cap < nvec * h->fftlen || (fhat && fhat_cap < nvec)) {
+        set_err("aisx_freqsync_work_host: output buffer too small for %d vectors", nvec);
+        return AISX_ERR_INVALID;
+    }
+    cf *d_in = nullptr, *d_out = nullptr;
+    float* d_fh = nullptr;
+    int rc = dev_alloc(&d_in, n, false);
+    if (rc == AISX_OK)
+        rc = dev_alloc(&d_out, (size_t)nvec * h->fftlen + 1, false);
+    if (rc == AISX_OK && fhat)
+        rc = dev_alloc(&d_fh, nvec + 1, false);
+    int nout = 0;
+    if (rc == AISX_OK && hipMemcpy(d_in, in, sizeof(cf) * n, hipMemcpyHostToDevice) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    if (rc == AISX_OK)
+        rc = aisx_freqsync_process(h, (const aisx_cf32*)d_in, n, n, (aisx_cf32*)d_out, (long)nvec * h->fftlen + 1, d_fh, nvec + 1,
+                                   &nout, nullptr);
+    if (rc == AISX_OK && nout > 0 && hipMemcpy(out, d_out, sizeof(cf) * nout, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    if (rc == AISX_OK && fhat && nvec > 0 && hipMemcpy(fhat, d_fh, sizeof(float) * nvec, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    if (rc == AISX_OK && hipDeviceSynchronize() != hipSuccess)
+        rc = AISX_ERR_HIP;
+    dev_free(d_in);
+    dev_free(d_out);
+    dev_free(d_fh);
+    return rc == AISX_OK ? nout : rc;
+}
+
 // freqest::work(noutput_items, input_items, output_items) as the scheduler calls it
 // (lib/freqest_impl.h:39-41, lib/freqest_impl.cc:57-88): input_items[0] = noutput_items vectors of
 // fftlen gr_complex (item size 8 * fftlen, :43), output_items[0] = one float per vector (:44).
@@ -350,6 +393,36 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
     return AISX_OK;
+}
+
+// feedforward_agc_cc::work as the scheduler calls it ([GR] sync_block with set_history(nsamples)):
+// `in` = input_items[0] = nsamples - 1 old items followed by noutput_items new ones, host pointers,
+// nchan == 1.  Returns noutput_items.
+extern "C" int aisx_agc_work_host(aisx_agc* h, int noutput_items, const aisx_cf32* in, aisx_cf32* out)
+{
+    if (!h || !in || !out || noutput_items < 1 || noutput_items > h->max_items)
+        return AISX_ERR_INVALID;
+    if (h->nchan != 1) {
+        set_err("aisx_agc_work_host: handle has %d channels, the GNU Radio path needs 1", h->nchan);
+        return AISX_ERR_INVALID;
+    }
+    const int H = h->W - 1, n = noutput_items;
+    cf *d_in = nullptr, *d_out = nullptr;
+    int rc = dev_alloc(&d_in, n, false);
+    if (rc == AISX_OK)
+        rc = dev_alloc(&d_out, n, false);
+    // the block's history comes from the scheduler's buffer, not from the handle
+    if (rc == AISX_OK && H > 0 && hipMemcpy(h->d_hist[h->cur], in, sizeof(cf) * H, hipMemcpyHostToDevice) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    if (rc == AISX_OK && hipMemcpy(d_in, in + H, sizeof(cf) * n, hipMemcpyHostToDevice) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    if (rc == AISX_OK)
+        rc = aisx_agc_process(h, (const aisx_cf32*)d_in, n, (aisx_cf32*)d_out, n, n, nullptr);
+    if (rc == AISX_OK && hipMemcpy(out, d_out, sizeof(cf) * n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = AISX_ERR_HIP;
+    dev_free(d_in);
+    dev_free(d_out);
+    return rc == AISX_OK ? n : rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -210,6 +210,12 @@ int aisx_freqsync_reset(aisx_freqsync* h);
  * [nchan][fhat_stride]. */
 int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out,
                           long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream);
+/* The hier block as ONE GNU Radio block (nchan == 1, HOST pointers): in = n new items, out
+ * receives every complete fftlen-vector's worth of mixed items (pending ones stay in the
+ * handle, as stream_to_vector keeps them), fhat (optional) one estimate per vector.  Returns the
+ * items written (a multiple of fftlen) or a negative status. */
+int aisx_freqsync_work_host(aisx_freqsync* h, const aisx_cf32* in, int n, aisx_cf32* out, int out_cap, float* fhat,
+                            int fhat_cap);
 /* freqest::work on already transformed vectors (lib/freqest_impl.cc:57-88):
  * d_vecs [nchan][nvec*fftlen] (fft-shifted spectra), d_out [nchan][nvec]. */
 int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long vec_stride, float* d_out, long out_stride,
@@ -235,6 +241,10 @@ int aisx_agc_reset(aisx_agc* h);
 int aisx_agc_set_floor(aisx_agc* h, float floor_env);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
+/* GNU Radio path (nchan == 1, HOST pointers): in = input_items[0] as the scheduler passes it to
+ * a sync_block with set_history(nsamples): nsamples - 1 old items, then noutput_items new ones.
+ * Returns noutput_items or a negative status. */
+int aisx_agc_work_host(aisx_agc* h, int noutput_items, const aisx_cf32* in, aisx_cf32* out);
 
 /* ------------------------------------------------------------------------ */
 /* wideband front end (BASELINE config 5; reference analogue: one             */

@@ -85,10 +85,24 @@ def assert_decoded_bursts_identical(got_bits, want_bits, infos, min_frac_equal=0
             assert np.array_equal(got_bits[pos:pos + pat.size], pat), "burst at bit %d differs" % pos
             ncmp += 1
     if want_bits.size:
+        # achieved (round 2, 112 channel runs of ~12 300 bits): 108 channels 1.0, worst 0.973 -- one
+        # symbol slip in the noise before a burst shifts everything up to the next tag reset
         frac = float(np.mean(got_bits == want_bits))
-        print("    bits equal to the oracle's: %.5f of %d" % (frac, want_bits.size))
+        FRACTIONS.append(frac)
         assert frac >= min_frac_equal, "only %.4f of the bits agree" % frac
     return ncmp, len(infos)
+
+
+FRACTIONS = []  # per-channel agreement of the last calls (callers assert on the aggregate)
+
+
+def assert_aggregate_agreement(min_mean=0.9985, min_exact_share=0.9):
+    """Over the channels compared since the last call: mean bit agreement and the share of
+    channels whose whole bit stream is identical (achieved per 24-channel test: means 1.0 /
+    0.99887 / 0.99990, identical streams 24 / 23 / 22 of 24)."""
+    f = np.array(FRACTIONS)
+    del FRACTIONS[:]
+    assert f.size and f.mean() >= min_mean and np.mean(f == 1.0) >= min_exact_share, (f.mean(), np.mean(f == 1.0), f.min())
 
 
 def compare_detections(got, want, thr=None):

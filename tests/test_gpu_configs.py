@@ -95,7 +95,7 @@ def test_config2_256_channels_corr_est_only(ais, family):
         cnt = np.bincount(tags["chan"][tags["key"] == 2], minlength=nchan).reshape(nchan // nu, nu)
         mism = int((cnt != cnt[0]).any(axis=1).sum())
         print("config 2 (%s) call %d: replica groups whose detection counts differ from group 0: %d of %d" % (family, s, mism, nchan // nu))
-        assert mism <= 2
+        assert mism <= 1  # (achieved: 0)
     print("config 2 (%s, N = %d): %d detections identical to the oracle on %d channels x 2 calls" % (family, N, ndet, nu))
     assert ndet > 20 * nu and blk.nitems_written() == 2 * T
 
@@ -170,7 +170,8 @@ def _stock_chain_against_oracle(ais, nchan, K, steps, seed0, base_noise_free=Fal
     assert tot["lone"] == tot["lone_near_threshold"], "a detection away from the threshold is missing on one side"
     assert tot["lone"] <= max(2, tot["matched"] // 500)
     assert mag <= 1e-5 and tim <= 1e-4
-    assert ncmp > 8 * K * steps and near >= ncmp - tot["lone"] and same >= int(0.5 * ncmp)
+    # (achieved at 4096 x 2 steps: 3685 of 3685 detections, 453 of 453 bursts identical in place)
+    assert ncmp > 8 * K * steps and near >= ncmp - tot["lone"] and same >= ncmp - 2 * max(1, tot["lone"])
     return dem
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_py as orc
-from parity import assert_decoded_bursts_identical, assert_tags_match, planted, unit_template
+from parity import assert_aggregate_agreement, assert_decoded_bursts_identical, assert_tags_match, planted, unit_template
 
 pytestmark = pytest.mark.gpu
 
@@ -416,7 +416,11 @@ def test_core_chain_corr_to_msk_bits_identical(ais, family):
         nburst += b
     print("core chain %s: %d bits, %d detections within tolerance, %d decoded bursts bit-identical (of %d sent)"
           % (family, nbits, ntags, ncmp, nburst))
-    assert ntags > nchan // 2 and nbits > nchan * T * steps // sps - nchan * 64 and ncmp > nburst // 3
+    assert_aggregate_agreement()
+    # (achieved: P 638 detections, 429 of 446 sent bursts decoded by the oracle and bit-identical on
+    # the GPU; S 277 detections, 219 of 277)
+    assert ntags >= (600 if family == "P" else 260) and nbits > nchan * T * steps // sps - nchan * 64
+    assert ncmp >= int((0.95 if family == "P" else 0.78) * nburst)
 
 
 def test_full_size_properties(ais):
@@ -448,7 +452,7 @@ def test_full_size_properties(ais):
     mism = sum(int(not np.array_equal(cnt[k * nuniq:(k + 1) * nuniq], ref)) for k in range(nchan // nuniq))
     # (a peak sitting within rounding of the threshold may flip in a rotated replica)
     print("full size: replica groups with differing detection counts: %d of %d" % (mism, nchan // nuniq))
-    assert mism <= nchan // nuniq // 8, "replica detection counts differ in %d groups" % mism
+    assert mism <= 1, "replica detection counts differ in %d groups" % mism  # (achieved: 0 of 256)
     prod = r["produced"].cpu().numpy()
     assert prod.min() > T // sps - 64 and msk.last_status() == 0
     # the first nuniq channels (rotation 0) against the oracle chain

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_py as orc
-from parity import assert_decoded_bursts_identical, assert_tags_match
+from parity import assert_aggregate_agreement, assert_decoded_bursts_identical, assert_tags_match
 
 pytestmark = pytest.mark.gpu
 
@@ -132,7 +132,9 @@ def test_stock_chain_bits_identical(ais, family, nchan, T, steps):
         nburst += b
     print("stock chain %s: %d bits, %d detections within tolerance, %d decoded bursts bit-identical (of %d sent)"
           % (family, nbits, ntags, ncmp, nburst))
-    assert ntags > nchan and ncmp > nburst // 3
+    assert_aggregate_agreement()
+    # (achieved: P 2191 detections, 415 of 463 sent bursts; S 2030 detections, 237 of 295)
+    assert ntags >= 2000 and ncmp >= int((0.88 if family == "P" else 0.79) * nburst)
 
 
 def _match_detections_near_threshold(got, want, thr):
@@ -240,4 +242,6 @@ def test_stock_chain_full_length_steps(ais):
     print("full-length stock chain: %d symbols bit-exact given equal tags, %d detections within tolerance "
           "(%d at the threshold seen by one side only), %d decoded bursts found in place, %d not (of %d sent)"
           % (nsym, ntags, nlone, ncmp, nmiss, nburst))
-    assert ntags > 50 * nchan and nlone <= ntags // 500 and ncmp > nburst // 3
+    # (achieved: 15946 detections, 1 of them seen by one side only, 1894 of 2309 sent bursts decoded
+    # by the oracle's chain, every one of them found in the GPU's stream)
+    assert ntags > 15000 and nlone <= 3 and nmiss <= nlone and ncmp >= int(0.8 * nburst)
