@@ -316,6 +316,27 @@ class square_and_fft_sync_cc:
         return out[:, :m], (fh[:, : m // self.fftlen] if want_fhat else None)
 
 
+def freq_sync_agc(freq_sync, agc, x, want_fhat=False, stream=None, out=None):
+    """freq_sync -> agc (the first two blocks of python/ais_demod.py:56) in one pass: the same
+    result, bit for bit, as agc.work(freq_sync.work(x)[0]), without the hier block's output being
+    stored (aisx_freqsync_agc_process).  Returns (agc output, fhat | None)."""
+    x = _dev_c64(x, freq_sync.nchan)
+    n = x.shape[1]
+    cap = n + freq_sync.fftlen
+    if out is None:
+        out = torch.empty((freq_sync.nchan, cap), dtype=torch.complex64, device=x.device)
+    elif out.shape[0] != freq_sync.nchan or out.shape[1] < cap or out.dtype != torch.complex64 or out.stride(1) != 1:
+        raise ValueError("out must be a (nchan, >= n + fftlen) complex64 buffer")
+    nv = cap // freq_sync.fftlen + 1
+    fh = torch.empty((freq_sync.nchan, nv), dtype=torch.float32, device=x.device) if want_fhat else None
+    nout = C.c_int(0)
+    check(_lib.lib().aisx_freqsync_agc_process(freq_sync._h, agc._h, x.data_ptr(), x.stride(0), n, out.data_ptr(),
+                                               out.stride(0), fh.data_ptr() if want_fhat else None, nv if want_fhat else 0,
+                                               C.byref(nout), _stream_ptr(stream)), "freq_sync_agc")
+    m = nout.value
+    return out[:, :m], (fh[:, : m // freq_sync.fftlen] if want_fhat else None)
+
+
 class freqest:
     """ais.freqest(sample_rate, data_rate, fftlen) (include/ais/freqest.h:49): consumes
     fft-shifted spectra, one float estimate per vector."""
@@ -418,10 +439,9 @@ class ais_demod:
         """One chain step on x[nchan][n].  Returns dict(bits, produced[, syms])."""
         y = _dev_c64(x, self.nchan)
         if self.stages == "stock":
-            y, _ = self.freq_sync.work(y, stream=stream)
+            y, _ = freq_sync_agc(self.freq_sync, self.agc, y, stream=stream)
             if y.shape[1] == 0:
                 return dict(bits=None, produced=None, syms=None)
-            y = self.agc.work(y, stream=stream)
         y, _ = self.preamble_detect.work(y, stream=stream)
         r = self.clockrec.work(y, tags_from=self.preamble_detect, want_syms=want_syms, stream=stream)
         return r

@@ -24,6 +24,12 @@ __global__ __launch_bounds__(FSM_T) void k_fs_mix(FsMixParams p)
     DevCtx cx{ smem };
     fs_mix_body(cx, p);
 }
+__global__ __launch_bounds__(FSW_T) void k_fs_walk(FsWalkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    fs_walk_body(cx, p);
+}
 __global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
 {
     DevCtx cx{ nullptr };
@@ -52,6 +58,10 @@ struct aisx_freqsync {
     cf* d_wtab = nullptr;
     int* d_maxpos = nullptr;
     float* d_phase = nullptr;
+    // the walked NCO phases of one call, [nchan][phases_stride] (fused front end only; allocated
+    // on first use: 4 bytes per sample)
+    float* d_phases = nullptr;
+    long phases_stride = 0;
     // GNU Radio path staging (aisx_freqest_work_host)
     cf* d_st_vec = nullptr;
     float* d_st_out = nullptr;
@@ -125,6 +135,7 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
     dev_free(h->d_wtab);
     dev_free(h->d_maxpos);
     dev_free(h->d_phase);
+    dev_free(h->d_phases);
     dev_free(h->d_st_vec);
     dev_free(h->d_st_out);
     delete h;
@@ -386,12 +397,104 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.reference = h->reference;
     p.floor_env = h->floor_env;
     p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    p.phases = nullptr;
+    p.phases_stride = 0;
+    p.pend_in = nullptr;
+    p.pend_out = nullptr;
+    p.npend = 0;
+    p.n_raw = 0;
     if (agc8_applies(p.W))
         hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
     h->cur ^= 1;
+    return AISX_OK;
+}
+
+// The first two blocks of python/ais_demod.py:56 in one pass over the samples: the frequency
+// estimates (fs_est_body) and the NCO phase walk (fs_walk_body) as in aisx_freqsync_process, the
+// mixing done where feedforward_agc_cc reads its input (agc8_body): square_and_fft_sync_cc's
+// output is never stored.  Results are those of aisx_freqsync_process followed by
+// aisx_agc_process on its output, bit for bit; both handles advance as if those had been called.
+extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const aisx_cf32* d_in, long in_stride, int n,
+                                         aisx_cf32* d_out, long out_stride, float* d_fhat, long fhat_stride, int* n_out,
+                                         void* stream)
+{
+    if (!h || !a || !d_in || !d_out || !n_out || n < 1 || n > h->max_items || in_stride < n || a->nchan != h->nchan) {
+        set_err("aisx_freqsync_agc_process: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if (!agc8_applies(a->W)) {
+        set_err("aisx_freqsync_agc_process: the fused front end serves AGC windows that are a multiple of 8 in [16, %d] "
+                "(the stock 512 is); use aisx_freqsync_process + aisx_agc_process for %d", AGC_MAXW, a->W);
+        return AISX_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nvec = (h->npend + n) / h->fftlen;
+    const int total = nvec * h->fftlen;
+    if (total > a->max_items || out_stride < total || (d_fhat && fhat_stride < nvec)) {
+        set_err("aisx_freqsync_agc_process: %d output items exceed the AGC's max_items %d or the output stride", total, a->max_items);
+        return AISX_ERR_INVALID;
+    }
+    int rc;
+    if (!h->d_phases) {
+        h->phases_stride = ((long)h->max_vec * h->fftlen + 3) & ~3L;
+        if ((rc = dev_alloc(&h->d_phases, (size_t)h->nchan * (size_t)h->phases_stride, false)) != AISX_OK)
+            return rc;
+    }
+    if (nvec > 0) {
+        FsEstParams e;
+        e.in = (const cf*)d_in;
+        e.in_stride = in_stride;
+        e.pend = h->d_pend[h->cur];
+        e.npend = h->npend;
+        e.wtab = h->d_wtab;
+        e.maxpos = h->d_maxpos;
+        e.maxpos_stride = h->max_vec;
+        e.nvec = nvec;
+        e.offset = h->offset;
+        hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+        AISX_HIPCHK(hipGetLastError());
+        FsWalkParams w;
+        w.nchan = h->nchan;
+        w.maxpos = h->d_maxpos;
+        w.maxpos_stride = h->max_vec;
+        w.fhat = d_fhat;
+        w.fhat_stride = fhat_stride;
+        w.phase = h->d_phase;
+        w.phases = h->d_phases;
+        w.phases_stride = h->phases_stride;
+        w.nvec = nvec;
+        w.binsize = h->binsize;
+        w.sensitivity = h->sensitivity;
+        hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES, st, w);
+        AISX_HIPCHK(hipGetLastError());
+    }
+    AgcParams p;
+    p.in = (const cf*)d_in;
+    p.in_stride = in_stride;
+    p.out = (cf*)d_out;
+    p.out_stride = out_stride;
+    p.hist_in = a->d_hist[a->cur];
+    p.hist_out = a->d_hist[a->cur ^ 1];
+    p.n = total;
+    p.W = a->W;
+    p.reference = a->reference;
+    p.floor_env = a->floor_env;
+    p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1; // (a call without a whole vector still moves the pending items)
+    p.phases = h->d_phases;
+    p.phases_stride = h->phases_stride;
+    p.pend_in = h->d_pend[h->cur];
+    p.pend_out = h->d_pend[h->cur ^ 1];
+    p.npend = h->npend;
+    p.n_raw = n;
+    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, st, p);
+    AISX_HIPCHK(hipGetLastError());
+    h->npend = h->npend + n - total;
+    h->cur ^= 1;
+    a->cur ^= 1;
+    *n_out = total;
     return AISX_OK;
 }
 

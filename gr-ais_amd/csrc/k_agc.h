@@ -31,6 +31,13 @@ struct AgcParams {
     float reference;
     float floor_env; // the initial max_env of [GR] feedforward_agc_cc_impl::work
     int ntiles;
+    // Fused front end (agc8 only; phases == nullptr: the plain block).  The block's input is then
+    // square_and_fft_sync_cc's output WITHOUT that output ever being stored: item m of it is
+    // raw[m] * e^{j phases[m]} (python/gmsk_sync.py:26-28,33; the phases come from fs_walk_body,
+    // k_freqsync.h), raw = the pending partial vector followed by the new samples `in`.
+    const float* phases; long phases_stride; // [nchan][n]
+    const cf* pend_in; cf* pend_out;         // [nchan][1024] pending partial vector in / out
+    int npend, n_raw;                        // valid pending items; new raw samples per channel
 };
 
 constexpr float AGC_FLOOR_DEFAULT = 1e-4f;
@@ -157,8 +164,22 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
 
     const int base = tile * AGC_TL;
     const int nout = (n - base) < AGC_TL ? (n - base) : AGC_TL;
-    const int E = nout + H;                         // items of the combined stream this tile looks at
+    const int E = (nout > 0 ? nout : 0) + H;        // items of the combined stream this tile looks at
     const int ngroups = (E + AGC8_G - 1) / AGC8_G;  // <= AGC8_NG + Q
+    // fused front end: new item m is raw[m] mixed with the walked NCO phase (AgcParams)
+    const bool mixed = p.phases != nullptr;
+    const float* phi = mixed ? p.phases + (long)c * p.phases_stride : nullptr;
+    const cf* pend = mixed ? p.pend_in + (long)c * 1024 : nullptr;
+    auto mix = [&](cf raw, float ph) -> cf {
+        float sn, cs;
+        det_sincos(ph, &sn, &cs);
+        return cmul_exact(raw, mk(cs, sn)); // multiply_cc(stream, frequency_modulator_fc output)
+    };
+    auto item = [&](int m) -> cf { // item m >= 0 of the block's input
+        if (!mixed)
+            return xin[m];
+        return mix((m < p.npend) ? pend[m] : xin[m - p.npend], phi[m]);
+    };
 
     // one group: load (zero past the end), envelopes, prefix maxima to LDS, group maximum
     cf own[AGC8_G];
@@ -166,13 +187,23 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     auto do_group = [&](int g, bool keep) {
         cf v[AGC8_G];
         const int s0 = base + g * AGC8_G;
-        if (s0 >= H && g * AGC8_G + AGC8_G <= E) { // wholly inside the new items: 16-byte loads
-            const cf_pair_agc* src = (const cf_pair_agc*)(xin + (s0 - H));
+        const int m0 = s0 - H; // first item of the group in the block's input
+        if (s0 >= H && g * AGC8_G + AGC8_G <= E && (!mixed || m0 >= p.npend)) { // wholly inside the new samples: 16-byte loads
+            const cf_pair_agc* src = (const cf_pair_agc*)(xin + (m0 - (mixed ? p.npend : 0)));
 #pragma unroll
             for (int k = 0; k < AGC8_G / 2; k++) {
                 const cf_pair_agc q = src[k];
                 v[2 * k] = q.a;
                 v[2 * k + 1] = q.b;
+            }
+            if (mixed) {
+                float f[AGC8_G];
+#pragma unroll
+                for (int k = 0; k < AGC8_G; k++)
+                    f[k] = phi[m0 + k];
+#pragma unroll
+                for (int k = 0; k < AGC8_G; k++)
+                    v[k] = mix(v[k], f[k]);
             }
         } else {
 #pragma unroll
@@ -180,7 +211,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 const int j = g * AGC8_G + k, s = base + j;
                 v[k] = mk(0.f, 0.f);
                 if (j < E)
-                    v[k] = (s < H) ? hist[s] : xin[s - H];
+                    v[k] = (s < H) ? hist[s] : item(s - H);
             }
         }
         float e[AGC8_G];
@@ -240,7 +271,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         src = dst;
         dst = tmp;
     }
-    if (t * AGC8_G < nout) {
+    if (nout > 0 && t * AGC8_G < nout) {
         // whole groups t+1 .. t+Q-1
         const float w1 = src[t + 1], w2 = src[t + Q - (1 << K)];
         const float gw = w1 < w2 ? w2 : w1;
@@ -279,7 +310,15 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         cf* ho = p.hist_out + (long)c * H;
         for (int j = t; j < H; j += AGC_T) {
             const int s = n + j;
-            ho[j] = (s < H) ? hist[s] : xin[s - H];
+            ho[j] = (s < H) ? hist[s] : item(s - H);
+        }
+        if (mixed) { // stream_to_vector's pending items: the raw samples behind the last whole vector
+            cf* po = p.pend_out + (long)c * 1024;
+            const int rem = p.npend + p.n_raw - n;
+            for (int i = t; i < rem; i += AGC_T) {
+                const int m = n + i;
+                po[i] = (m < p.npend) ? pend[m] : xin[m - p.npend];
+            }
         }
     }
 }

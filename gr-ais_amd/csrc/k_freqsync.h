@@ -216,6 +216,95 @@ AISX_HD float nco_wrap_small(float ph)
 }
 
 // ---------------------------------------------------------------------------
+// The NCO phase walk on its own (fs_walk_body): the phases depend on the frequency estimates
+// only, not on the samples, so the recurrence can run apart from the mixing -- one lane per
+// channel, 64 channels per wave -- and leave phi[c][i] in memory; the mixing then has no order in
+// time any more and is done where the samples are read next (the AGC's load stage, k_agc.h).
+// The walk is what fs_mix_body's wave 0 does, statement for statement (stale-maxpos rule
+// lib/freqest_impl.cc:68 vs :74, f = (float(maxpos) - fftlen/2) * binsize / 2 (:84), [GR]
+// frequency_modulator_fc's d_phase += k f; fmod wrap).  A wave keeps 64 steps of its 64 channels
+// in LDS and flushes them row by row: 256 contiguous bytes per channel and flush.
+constexpr int FSW_T = 64;
+constexpr int FSW_BLK = 64;      // steps per flush
+constexpr int FSW_PITCH = 68;    // floats per LDS row (rows 16-byte aligned)
+constexpr int FSW_LDS_BYTES = FSW_T * FSW_PITCH * 4;
+static_assert(FS_F % FSW_BLK == 0, "whole blocks per vector");
+
+struct FsWalkParams {
+    int nchan;
+    const int* maxpos; long maxpos_stride; // [nchan][nvec] from fs_est_body
+    float* fhat; long fhat_stride;         // optional [nchan][nvec]
+    float* phase;                          // [nchan] NCO phase (d_phase), in and out
+    float* phases; long phases_stride;     // [nchan][nvec * fftlen] out; stride a multiple of 4
+    int nvec;
+    float binsize, sensitivity;
+};
+
+template <class Ctx>
+AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
+{
+    typedef float ph4 __attribute__((vector_size(16)));
+    const int l = cx.tid();
+    const int cbase = cx.bx() * FSW_T;
+    const int c = cbase + l;
+    const bool live = c < p.nchan;
+    float* R = (float*)cx.lds(); // [64][FSW_PITCH]: row = channel of the wave, column = step of the block
+    float* mine = R + l * FSW_PITCH;
+    float ph = live ? p.phase[c] : 0.f;
+    unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
+    for (int v = 0; v < p.nvec; v++) {
+        float d = 0.f;
+        if (live) {
+            const int mp = p.maxpos[(long)c * p.maxpos_stride + v];
+            if (mp >= 0)
+                maxpos = (unsigned)mp;
+            const float f = ((float)maxpos - (float)(FS_F / 2)) * p.binsize / 2.0f; // :84
+            if (p.fhat)
+                p.fhat[(long)c * p.fhat_stride + v] = f;
+            d = p.sensitivity * f;
+        }
+        // with |d| < 2 pi the fmod of the wrap is a select (nco_wrap_small); one wave-uniform
+        // decision per vector keeps the recurrence free of branches
+        const bool small = cx.ballot(!(fabsf(d) < 6.0f)) == 0ull;
+        for (int b = 0; b < FS_F / FSW_BLK; b++) {
+            if (small) {
+#pragma unroll 4
+                for (int i = 0; i < FSW_BLK; i += 4) {
+                    ph4 q;
+                    ph = nco_wrap_small(ph + d);
+                    q[0] = ph;
+                    ph = nco_wrap_small(ph + d);
+                    q[1] = ph;
+                    ph = nco_wrap_small(ph + d);
+                    q[2] = ph;
+                    ph = nco_wrap_small(ph + d);
+                    q[3] = ph;
+                    *(ph4*)(mine + i) = q;
+                }
+            } else {
+                for (int i = 0; i < FSW_BLK; i++) {
+                    ph = nco_wrap(ph + d);
+                    mine[i] = ph;
+                }
+            }
+            cx.wave_sync();
+            // flush: 16 lanes x 16 bytes cover one channel's 64 phases, four channels per pass
+            const long col = (long)v * FS_F + b * FSW_BLK + 4 * (l & 15);
+#pragma unroll 4
+            for (int pass = 0; pass < FSW_T / 4; pass++) {
+                const int r = pass * 4 + (l >> 4);
+                const ph4 q = *(const ph4*)(R + r * FSW_PITCH + 4 * (l & 15));
+                if (cbase + r < p.nchan)
+                    *(ph4*)(p.phases + (long)(cbase + r) * p.phases_stride + col) = q;
+            }
+            cx.wave_sync();
+        }
+    }
+    if (live)
+        p.phase[c] = ph;
+}
+
+// ---------------------------------------------------------------------------
 constexpr int FSM_T = 512;             // wave 0 walks the NCO phases, waves 1..7 mix
 constexpr int FSM_CPW = 16;            // channels per workgroup (256 workgroups at 4096 channels: one per CU)
 constexpr int FSM_MIXW = FSM_T / 64 - 1;

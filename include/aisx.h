@@ -241,6 +241,13 @@ int aisx_agc_reset(aisx_agc* h);
 int aisx_agc_set_floor(aisx_agc* h, float floor_env);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
+/* square_and_fft_sync_cc -> feedforward_agc_cc, the first two blocks of python/ais_demod.py:56, in
+ * ONE pass over the samples (batched device path): the mixing with the NCO is done where the AGC
+ * reads its input, the hier block's output is never stored.  Same results, bit for bit, as
+ * aisx_freqsync_process followed by aisx_agc_process on its output; both handles advance as if
+ * those had been called.  AGC windows that are a multiple of 8 (the stock 512). */
+int aisx_freqsync_agc_process(aisx_freqsync* fs, aisx_agc* agc, const aisx_cf32* d_in, long in_stride, int n,
+                              aisx_cf32* d_out, long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream);
 /* GNU Radio path (nchan == 1, HOST pointers): in = input_items[0] as the scheduler passes it to
  * a sync_block with set_history(nsamples): nsamples - 1 old items, then noutput_items new ones.
  * Returns noutput_items or a negative status. */

@@ -533,6 +533,7 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    p.phases = nullptr; p.phases_stride = 0; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
     if (agc8_applies(p.W))
         run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else
@@ -591,6 +592,38 @@ int emu_fs_process(void* hv, const cf* in, long in_stride, int n, cf* out, long 
     h->npend = h->npend + n - nvec * FS_F;
     h->cur ^= 1;
     return nvec * FS_F;
+}
+// the fused front end (aisx_freqsync_agc_process): estimates, phase walk, mixing inside the AGC
+int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, cf* out, long out_stride, float* fhat, long fhat_stride)
+{
+    EmuFs* h = (EmuFs*)fv;
+    EmuAgc* a = (EmuAgc*)av;
+    const int nvec = (h->npend + n) / FS_F, total = nvec * FS_F;
+    const long pstride = ((long)h->max_vec * FS_F + 3) & ~3L;
+    std::vector<float> phases((size_t)h->nchan * pstride);
+    if (nvec > 0) {
+        FsEstParams e;
+        e.in = in; e.in_stride = in_stride; e.pend = h->pend[h->cur].data(); e.npend = h->npend; e.wtab = h->wtab.data();
+        e.maxpos = h->maxpos.data(); e.maxpos_stride = h->max_vec; e.nvec = nvec; e.offset = h->offset;
+        run_grid((nvec + 3) / 4, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
+        FsWalkParams w;
+        w.nchan = h->nchan; w.maxpos = h->maxpos.data(); w.maxpos_stride = h->max_vec; w.fhat = fhat; w.fhat_stride = fhat_stride;
+        w.phase = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.nvec = nvec; w.binsize = h->binsize;
+        w.sensitivity = h->sens;
+        run_grid((h->nchan + FSW_T - 1) / FSW_T, 1, FSW_T, FSW_LDS_BYTES, [&](EmuCtx& cx) { fs_walk_body(cx, w); });
+    }
+    AgcParams p;
+    p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
+    p.hist_in = a->hist[a->cur].data(); p.hist_out = a->hist[a->cur ^ 1].data();
+    p.n = total; p.W = a->W; p.reference = a->ref; p.floor_env = AGC_FLOOR_DEFAULT;
+    p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1;
+    p.phases = phases.data(); p.phases_stride = pstride; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
+    p.npend = h->npend; p.n_raw = n;
+    run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
+    h->npend = h->npend + n - total;
+    h->cur ^= 1;
+    a->cur ^= 1;
+    return total;
 }
 void emu_freqest_work(void* hv, const cf* vecs, long vec_stride, float* out, long out_stride, int nvec)
 {

@@ -49,6 +49,8 @@ def lib():
         L.emu_agc_create.argtypes = [i32, f32, i32]
         L.emu_agc_destroy.argtypes = [vp]
         L.emu_agc_process.argtypes = [vp, vp, lng, vp, lng, i32]
+        L.emu_fs_agc_process.restype = i32
+        L.emu_fs_agc_process.argtypes = [vp, vp, vp, lng, i32, vp, lng, vp, lng]
         L.emu_fs_create.restype = vp
         L.emu_fs_create.argtypes = [f64, f64, i32, i32, i32]
         L.emu_fs_destroy.argtypes = [vp]
@@ -207,3 +209,15 @@ class Pfb:
         out = np.zeros((self.nstreams * 1024, nf), np.complex64)
         lib().emu_pfb_process(self.h, _p(x), n, n, _p(out), nf)
         return out
+
+
+def fs_agc_process(fs, agc, x):
+    """the fused front end under the lane model: (agc output, fhat)"""
+    x = np.ascontiguousarray(x, dtype=np.complex64).reshape(fs.nchan, -1)
+    n = x.shape[1]
+    cap = n + fs.fftlen
+    out = np.zeros((fs.nchan, cap), dtype=np.complex64)
+    nv = cap // fs.fftlen + 1
+    fh = np.zeros((fs.nchan, nv), dtype=np.float32)
+    m = lib().emu_fs_agc_process(fs.h, agc.h, _p(x), n, n, _p(out), cap, _p(fh), nv)
+    return out[:, :m].copy(), fh[:, : m // fs.fftlen].copy()

@@ -75,3 +75,29 @@ def test_emul_freqest_work_kat():
     fe = orc.FreqEst.make(38400.0, 9600, 1024)
     assert np.array_equal(out[1], fe.work(v[1]))
     assert out[1][0] == -9600.0
+
+
+def test_emul_fused_front_end_is_freq_sync_then_agc():
+    # aisx_freqsync_agc_process under the lane model: frequency estimates, the NCO phase walk on its
+    # own (fs_walk_body) and the mixing inside the AGC's load stage (agc8_body) against the oracle's
+    # freq_sync followed by its AGC, ragged calls (pending partial vectors, carried AGC history,
+    # a call without a whole vector), an all-zero stretch (stale maxpos)
+    nchan = 3
+    lens = [4096, 1000, 24, 5000, 3 * 1024 + 7, 10]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(900 + c, total, "P", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
+    xs[1, 2048:5120] = 0
+    fs, agc = emu.FreqSync(38400.0, 9600.0, 1024, nchan), emu.Agc(512, 2.0, nchan)
+    ofs = [orc.FreqSync(38400.0, 9600.0, 1024) for _ in range(nchan)]
+    oag = [orc.Agc(512, 2.0) for _ in range(nchan)]
+    k = nout = 0
+    for L in lens:
+        out, fh = emu.fs_agc_process(fs, agc, xs[:, k:k + L])
+        for c in range(nchan):
+            y, wfh = ofs[c].process(xs[c, k:k + L])
+            want = oag[c].work(y) if y.size else y
+            assert out.shape[1] == want.size and np.array_equal(fh[c], wfh)
+            assert np.array_equal(out[c].view(np.uint32), want.view(np.uint32)), (L, c)
+        nout += out.shape[1]
+        k += L
+    assert nout == (total // 1024) * 1024

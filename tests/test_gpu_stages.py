@@ -245,3 +245,40 @@ def test_stock_chain_full_length_steps(ais):
     # (achieved: 15946 detections, 1 of them seen by one side only, 1894 of 2309 sent bursts decoded
     # by the oracle's chain, every one of them found in the GPU's stream)
     assert ntags > 15000 and nlone <= 3 and nmiss <= nlone and ncmp >= int(0.8 * nburst)
+
+
+def test_fused_front_end_equals_the_two_blocks(ais):
+    # aisx_freqsync_agc_process (estimates, NCO phase walk on its own, mixing inside the AGC's load
+    # stage) against aisx_freqsync_process + aisx_agc_process on the GPU and against the oracle:
+    # bit for bit, ragged calls, 70 channels (two walk waves, the second one ragged)
+    from ais_amd import synth
+
+    nchan = 70
+    lens = [4096, 1000, 24, 5000, 30 * 1024 + 7, 10]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(1300 + c, total, "P", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
+    xs[1, 2048:5120] = 0
+    fs1 = ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens))
+    ag1 = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024)
+    fs2 = ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens))
+    ag2 = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024)
+    ofs = [orc.FreqSync(38400.0, 9600.0, 1024) for _ in range(8)]
+    oag = [orc.Agc(512, 2.0) for _ in range(8)]
+    k = nout = 0
+    for L in lens:
+        x = _dev(xs[:, k:k + L])
+        a, fa = ais.freq_sync_agc(fs1, ag1, x, want_fhat=True)
+        y, fb = fs2.work(x, want_fhat=True)
+        b = ag2.work(y) if y.shape[1] else y
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), L
+        assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy())
+        for c in range(8):
+            yo, _ = ofs[c].process(xs[c, k:k + L])
+            want = oag[c].work(yo) if yo.size else yo
+            assert np.array_equal(a[c].view(np.uint32), want.view(np.uint32)), (L, c)
+        nout += a.shape[1]
+        k += L
+    assert nout == (total // 1024) * 1024
+    with pytest.raises(ValueError):
+        ais.freq_sync_agc(fs1, ais.feedforward_agc_cc(37, 2.0, nchan=nchan, max_items=max(lens) + 1024), _dev(xs[:, :100]))
