@@ -405,11 +405,13 @@ def main():
                     s_main.wait_event(msk_done[par])  # step k-3 released y_corr[par] and its tags
                 y = x
                 if stock:
-                    if os.environ.get("AISX_BENCH_UNFUSED"):  # (A/B: the two blocks as two passes)
+                    if os.environ.get("AISX_BENCH_FUSED"):
+                        # (A/B: freq_sync -> agc in one pass over the samples, same results bit for bit;
+                        # run in series the separate NCO phase walk costs more than the pass saves)
+                        y, _ = ais_amd.freq_sync_agc(dem.freq_sync, dem.agc, y)
+                    else:
                         y, _ = dem.freq_sync.work(y)
                         y = dem.agc.work(y)
-                    else:  # freq_sync -> agc in one pass over the samples (same results, bit for bit)
-                        y, _ = ais_amd.freq_sync_agc(dem.freq_sync, dem.agc, y)
                 o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
                 tags_ptrs = corr.tags_device()
                 ready = torch.cuda.Event()

@@ -417,6 +417,9 @@ class ais_demod:
         self.fftlen = options["fftlen"]
         self.nchan = nchan
         self.stages = stages
+        # freq_sync -> agc in one pass (freq_sync_agc): same results; off by default, the separate
+        # NCO phase walk it needs is slower than fs_mix's in-kernel one when run in series
+        self.fused_front_end = False
         if stages == "stock":
             self.freq_sync = square_and_fft_sync_cc(self._samplerate, self._bits_per_sec, self.fftlen, nchan=nchan,
                                                     max_items=max_items)
@@ -439,9 +442,14 @@ class ais_demod:
         """One chain step on x[nchan][n].  Returns dict(bits, produced[, syms])."""
         y = _dev_c64(x, self.nchan)
         if self.stages == "stock":
-            y, _ = freq_sync_agc(self.freq_sync, self.agc, y, stream=stream)
+            if self.fused_front_end:
+                y, _ = freq_sync_agc(self.freq_sync, self.agc, y, stream=stream)
+            else:
+                y, _ = self.freq_sync.work(y, stream=stream)
             if y.shape[1] == 0:
                 return dict(bits=None, produced=None, syms=None)
+            if not self.fused_front_end:
+                y = self.agc.work(y, stream=stream)
         y, _ = self.preamble_detect.work(y, stream=stream)
         r = self.clockrec.work(y, tags_from=self.preamble_detect, want_syms=want_syms, stream=stream)
         return r

@@ -52,7 +52,13 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
     static bool big_lds[20] = { false };
     const int li = p.lpw == 16 ? 0 : (p.lpw == 32 ? 1 : (p.lpw == 64 ? 2 : (p.lpw == 8 ? 3 : 4)));
     const int v = li * 4 + (((p.err || p.mu_out) ? 2 : 0) | (p.osps == 2 ? 1 : 0));
-    const int lds = msk_lds_bytes(p.lpw);
+    // LDS beyond what the kernel uses keeps other streams' workgroups off this CU: a knob for how
+    // much of its SIMDs' issue the recurrence shares (AISX_MSK_LDS_PAD, KiB; experiments)
+    static const int pad = [] {
+        const char* e = getenv("AISX_MSK_LDS_PAD");
+        return e ? atoi(e) * 1024 : 0;
+    }();
+    const int lds = std::min(msk_lds_bytes(p.lpw) + pad, 160 * 1024);
     if (!big_lds[v]) {
         AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         big_lds[v] = true;
@@ -69,6 +75,7 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
 struct aisx_msk {
     int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
     int lpw = 64; // channels per wave of the timing-recovery kernel
+    int inline_tags = 1; // (AISX_MSK_INLINE_TAGS=0: every tag reset through the general steps, for A/B runs)
     float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
     static constexpr int carry_cap = MSK_CARRY_MAX, ctag_cap = 64;
     float *d_mu = nullptr, *d_omega = nullptr;
@@ -196,6 +203,8 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         // 7.2 / 6.3 / 5.5 ms per launch at 16 / 8 / 4 channels per wave; 8 gives the shortest
         // step (at 4 the kernel sits on all 256 CUs and slows the bandwidth-bound stages more)
         h->lpw = 8;
+        if (const char* e = getenv("AISX_MSK_INLINE_TAGS"))
+            h->inline_tags = atoi(e) != 0;
         if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
@@ -389,6 +398,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.lds_wave_stride = msk_lds_wave(h->lpw);
     p.tq_stride = h->lpw;
     p.tq_private = 0;
+    p.inline_tags = h->inline_tags;
 }
 
 // compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows

@@ -46,6 +46,8 @@ enum {
     MSK_ST_TAGS_TRUNCATED = 16 // the producer's tag list was longer than its buffer: tags are missing
 };
 constexpr int MSK_CTN_TRUNC = 0x40000000; // flag bit in ct_n: tagprep_body saw a truncated list
+constexpr int MSK_CTN_WILD = 0x20000000;  // ... a time_est value outside [-1, 1] (corr_est's centre of mass never is)
+constexpr int MSK_TAG_TRIPS = 6;          // pairs per run that handles tag resets in line (a burst gives 3-4 tags on consecutive pairs)
 
 constexpr int MSK_T = 64;    // lanes of a wave
 constexpr int MSK_RING = 256;   // slots per lane (power of two)
@@ -113,6 +115,7 @@ struct MskParams {
     // threads, gives each lane its own (stride msk_lds_ring(lpw) + MSK_TAGQ * 64 * 8, 64, 1).
     int lds_wave_stride, tq_stride, tq_private;
     int lpw;           // channels per wave, = the build's LPW: 4, 8, 16, 32 or 64
+    int inline_tags;   // tag resets inside the lock-step runs (0: every tag through the general steps)
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -212,10 +215,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     // the time_est tags visible to this call (carried ones first), already compacted
     const msk_ctag* ctl = p.ct + (long)cc * p.ct_cap;
     int ntot = p.ct_n[cc];
-    if (ntot & MSK_CTN_TRUNC) {
+    if (ntot & MSK_CTN_TRUNC)
         status |= MSK_ST_TAGS_TRUNCATED;
-        ntot &= MSK_CTN_TRUNC - 1;
-    }
+    // tag resets are handled inside the lock-step runs only when every value is a timing offset
+    // within one sample (then mu stays inside the interpolator's table after a reset)
+    const bool tame_tags = p.inline_tags && cx.ballot((ntot & MSK_CTN_WILD) != 0) == 0ull;
+    ntot &= MSK_CTN_WILD - 1;
     if (ntot > p.ct_cap)
         ntot = p.ct_cap;
     // They are queued in LDS: the loop must not pay global-memory latency when a tag fires.
@@ -623,6 +628,128 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                             npairs += bit;
                 }
             }
+            // ---- Tag resets in line.  No plain run is possible because some lane's time_est tag
+            // is about to fire (:140-164).  Instead of handing the wave to the general steps (one
+            // event per pass, both iterations of every lane one after the other), pairs go on in
+            // lock step with the tag tests folded in:
+            //   * before the even iteration: the front tag fires there -> mu, iidx and omega are
+            //     taken from the tag (d_div = 0 keeps the parity: the iteration is even anyway);
+            //   * before the odd iteration: if the (next) front tag fires there, the reference
+            //     runs an EVEN iteration in that place (d_div = 0) -- this channel's pair then
+            //     ends after its even half (no loop filter, state as the even iteration left it)
+            //     and the tag fires again, by the same test, before the even iteration of the
+            //     next trip.
+            // A trip moves iidx by less than pair_adv plus one tag jump (< d_sps) and one item.
+            if constexpr (NQ >= 2 && !AUX && !OSPS2) {
+              if (npairs == 0 && tame_tags) {
+                constexpr int ROW = LPW <= 16 ? 16 : 32;
+                const int chunk_lim2 = more ? (loaded_s - 8 - jump_margin + MSK_OFF - ((sb >> SLOT_SH) - iidx) + 1) : 0x7fffffff;
+                const int lim2 = ninp < chunk_lim2 ? ninp : chunk_lim2; // every bound but the tag's
+                const float room2 = lim2 > iidx ? (float)(lim2 - iidx) - (1.001f + wmax + d_sps) : -1.f;
+                int can2 = room2 >= 0.f ? (int)(room2 * (0.9999f / (pair_adv + d_sps))) + 1 : 0;
+                can2 = can2 < MSK_TAG_TRIPS ? can2 : MSK_TAG_TRIPS;
+                can2 = can2 < ocan ? can2 : ocan;
+                if (!lock_ok || !(d_mu >= 0.f && d_mu <= 1.f) || tag_trig == TRIG_FORCED)
+                    can2 = 0;
+                int ntrips = 0;
+                if (cx.ballot(can2 >= 1) == ALL) {
+                    ntrips = 1;
+                    while (ntrips < MSK_TAG_TRIPS && cx.ballot(can2 >= ntrips + 1) == ALL)
+                        ntrips++;
+                }
+                if (ntrips > 0) {
+                    const bool roleO = (cx.tid() & ROW) != 0;
+                    cf sqO = prev_sq, sqE = mk(0.f, 0.f), acc = last_interp;
+                    float nl_prev = d_dly_diff_1.re;
+                    bool last_skip = false;
+                    for (int k = 0; k < ntrips; k++) {
+#ifdef MSK_EMU_STATS
+                        if (l == 0 && q == 0) msk_stats[5]++;
+#endif
+                        // the front tag fires before this even iteration (:140-164)
+                        const bool fireE = (nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps));
+                        if (cx.ballot(fireE) != 0ull) {
+                            if (fireE) {
+                                const float center = nt_val;
+                                if (center == center) { // not NaN (:144-147)
+                                    int at = nt_rel;
+                                    float m = center;
+                                    if (m < 0) {
+                                        m++;
+                                        at--;
+                                    }
+                                    sb += (at - iidx) * SLOT_B;
+                                    iidx = at;
+                                    d_mu = m;
+                                    d_div = 0;
+                                    d_omega = d_sps;
+                                }
+                                tq_pop();
+                                nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
+                            }
+                        }
+                        const float m1 = d_mu + d_omega;                               // :199-201, m1 > 0
+                        const float muO = cx.fract(m1);
+                        const int adv1 = (int)m1;
+                        const int sb1 = sb + adv1 * SLOT_B;
+                        const int iidxO = iidx + adv1;
+                        // ... or before the odd one: that iteration then belongs to the next trip.  (A
+                        // NaN tag there is only dropped, :144-147: the odd iteration runs as it is.)
+                        const bool winO = (nt_rel >= iidxO) && ((float)nt_rel < ((float)iidxO + d_sps));
+                        const bool nanO = winO && (nt_val != nt_val);
+                        if (cx.ballot(nanO) != 0ull) {
+                            if (nanO) {
+                                tq_pop();
+                                nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
+                            }
+                        }
+                        const bool skipO = winO && !nanO;
+                        cf sv[8];
+                        float tv[8];
+                        fir_load((unsigned)(int)rintf((roleO ? muO : d_mu) * 128.0f), roleO ? sb1 : sb, sv, tv);
+                        acc = fir_sum(sv, tv);
+                        const cf sq = cmul_exact(acc, acc);                            // :171
+                        cf sE, s1;
+                        cx.template pair_rows<ROW>(sq, sE, s1);
+                        const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
+                        const float nlO = s1.re * sE.re + s1.im * sE.im;
+                        const float err = branchless_clip(nlO - nlE, 3.0f);            // :179-184
+                        float om2 = d_omega + p.gain_omega * err;
+                        om2 = d_sps + branchless_clip(om2 - d_sps, p.limit);
+                        const float mu2 = muO + p.gain * err;
+                        if (!roleO)
+                            *(cf*)(osym0 + ob) = acc;                                  // :186-191 (even iterations only)
+                        ob += 8u;
+                        const float m2 = mu2 + om2;                                    // > 0 (lock_ok)
+                        const int adv2 = (int)m2;
+                        d_mu = skipO ? muO : cx.fract(m2);
+                        sb = skipO ? sb1 : sb1 + adv2 * SLOT_B;
+                        iidx = skipO ? iidxO : iidxO + adv2;
+                        d_omega = skipO ? d_omega : om2;
+                        d_div += skipO ? 1 : 2;
+                        // the last two squares (for d_dly_conj_2 and the imaginary part of nlin_out)
+                        const cf nE = skipO ? sqO : sE, nO = skipO ? sE : s1;
+                        sqE = nE;
+                        sqO = nO;
+                        nl_prev = skipO ? nlE : nlO;
+                        last_skip = skipO;
+                    }
+                    cf accE, accO;
+                    cx.template pair_rows<ROW>(acc, accE, accO);
+                    oidx += ntrips;
+                    prev_sq = sqO;
+                    last_interp = last_skip ? accE : accO;
+                    d_dly_diff_1 = mk(nl_prev, sqO.im * sqE.re - sqO.re * sqE.im);
+                    if (!(d_mu >= 0.f && d_mu <= 1.f))
+                        status |= MSK_ST_INTERP_RANGE;
+                    E = cx.ballot((d_div & 1) == 0);
+                    bounds(sb >> SLOT_SH); // where the (new) front tag can fire, how far this lane can run
+#ifdef MSK_PROF
+                    pf_n[0] += ntrips; pf_n[1]++;
+#endif
+                }
+              }
+            }
 #ifdef MSK_PROF
             if (npairs == 0) { pf_fail += __builtin_readcyclecounter() - pf_a; pf_nfail++; }
 #endif
@@ -915,6 +1042,7 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
     const unsigned long long R = p.nread[c];
     msk_ctag* out = p.ct + (long)c * p.ct_cap;
     int w = 0; // wave-uniform
+    bool wild = false;
     auto scan = [&](const tag_rec* list, int n) {
         for (int k0 = 0; k0 < n; k0 += 64) {
             const int k = k0 + l;
@@ -925,6 +1053,9 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
             if (k < n)
                 t = list[k];
             const bool keep = (k < n) && t.key == KEY_TIME_EST && t.offset >= R;
+            const float tv = (float)t.value;
+            if (cx.ballot(keep && !(tv != tv) && !(tv >= -1.0f && tv <= 1.0f)) != 0ull)
+                wild = true;
             const unsigned long long m = cx.ballot(keep);
             const int pos = w + aisx_popc64(m & ((1ull << l) - 1ull));
             if (keep && pos < p.ct_cap) {
@@ -953,7 +1084,7 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
     if (w > p.ct_cap)
         trunc = true;
     if (l == 0)
-        p.ct_n[c] = (w < p.ct_cap ? w : p.ct_cap) | (trunc ? MSK_CTN_TRUNC : 0);
+        p.ct_n[c] = (w < p.ct_cap ? w : p.ct_cap) | (trunc ? MSK_CTN_TRUNC : 0) | (wild ? MSK_CTN_WILD : 0);
 }
 
 // Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)

@@ -7,6 +7,7 @@
 #include <barrier>
 #include <memory>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -391,6 +392,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.lds_wave_stride = msk_lds_ring(h->lpw) + MSK_TAGQ * 64 * 8;
     p.tq_stride = 64;
     p.tq_private = 1;
+    p.inline_tags = getenv("AISX_MSK_INLINE_TAGS") ? atoi(getenv("AISX_MSK_INLINE_TAGS")) : 1;
     p.lds_tab_off = msk_waves(h->lpw) * p.lds_wave_stride;
 }
 

@@ -151,3 +151,67 @@ def test_emul_msk_interp_range_is_reported():
     e2 = emu.MskStream(4.0, 0.04, 0.01, 1, nchan=1)
     tg[0, 0] = (300, 0.25, 2, 0)
     assert e2.step(x[None, :], tg, np.array([1], np.int32))["status"] == 0
+
+
+def _burst_like_tags(rng, total, chan, nclusters=12):
+    """time_est tags the way corr_est emits them: clusters of 2-5 tags, isps (or fewer) samples
+    apart, values a centre of mass in [-1, 1], now and then NaN, exactly +-1, 0, or an other key."""
+    rows = []
+    starts = np.sort(rng.choice(np.arange(40, total - 80), size=nclusters, replace=False))
+    for s0 in starts:
+        step = int(rng.choice([4, 4, 4, 1, 2, 3, 5]))
+        for j in range(int(rng.integers(2, 6))):
+            v = float(rng.uniform(-1, 1))
+            r = rng.random()
+            if r < 0.06:
+                v = float("nan")
+            elif r < 0.12:
+                v = float(rng.choice([-1.0, 1.0, 0.0, -0.0]))
+            rows.append((int(s0 + j * step), v, 2 if rng.random() > 0.05 else 1))
+    rows.sort(key=lambda t: t[0])
+    tags = np.zeros(len(rows), dtype=emu.TAG_DTYPE)
+    tags["offset"] = [r[0] for r in rows]
+    tags["value"] = [r[1] for r in rows]
+    tags["key"] = [r[2] for r in rows]
+    tags["chan"] = chan
+    return tags
+
+
+@pytest.mark.parametrize("sps,lpw", [(4.0, 8), (4.0, 4), (4.0, 16), (5.2083, 32), (5.0, 8), (4.0, 64), (4.4, 8)])
+def test_emul_msk_tag_resets_inside_the_lock_step(sps, lpw):
+    # osps = 1, err / mu ports not connected: the build whose lock-step runs handle time_est tags in
+    # line (tag before the even iteration, tag before the odd one, clusters on consecutive pairs,
+    # negative centre -> iidx - 1, NaN, +-1) -- symbols, counts and bits against the oracle
+    rng = np.random.default_rng(int(sps * 100) + lpw)
+    nchan, lens = 19, [2600, 37, 1800, 1, 900]
+    total = sum(lens)
+    xs = np.stack([_signal(150 + c, total, 4)[0] for c in range(nchan)])
+    e = emu.MskStream(sps, 0.04, 0.01, 1, nchan=nchan, lpw=lpw)
+    o = [orc.MskStream(sps, 0.04, 0.01, 1) for _ in range(nchan)]
+    bt = [orc.BitTail() for _ in range(nchan)]
+    all_tags = [_burst_like_tags(rng, total, c, nclusters=14 if c % 3 else 40) for c in range(nchan)]
+    k = nsym = 0
+    for L in lens:
+        chunk = xs[:, k:k + L]
+        cap = 256
+        tg = np.zeros((nchan, cap), dtype=emu.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        new = []
+        for c in range(nchan):
+            sel = all_tags[c][(all_tags[c]["offset"] >= k) & (all_tags[c]["offset"] < k + L)]
+            tg[c, : len(sel)] = sel
+            cnt[c] = len(sel)
+            new.append(sel)
+        r = e.step(chunk, tg, cnt, want_aux=False)
+        assert r["status"] == 0
+        for c in range(nchan):
+            ot = np.zeros(len(new[c]), dtype=orc.TAG_DTYPE)
+            ot["offset"], ot["value"], ot["key"] = new[c]["offset"], new[c]["value"], new[c]["key"]
+            out, _, _, cons = o[c].step(chunk[c], ot)
+            p = r["produced"][c]
+            assert p == len(out) and r["consumed"][c] == cons, (L, c)
+            assert np.array_equal(r["syms"][c, :p].view(np.uint32), out.view(np.uint32)), (L, c)
+            assert np.array_equal(r["bits"][c, :p], bt[c].process(out))
+            nsym += p
+        k += L
+    assert nsym > nchan * total / sps * 0.9
