@@ -21,16 +21,39 @@
 //   * barriers order LDS traffic only (s_waitcnt lgkmcnt + s_barrier): DMA and the pass-through
 //     stores stay in flight across them; one vmcnt(0) per tile, where the next window is needed;
 //   * with two workgroups per CU the register budget is 256: H (the thread's 16 spectrum
-//     positions) and the 15 first-pass twiddles stay in VGPRs for the whole kernel.
+//     positions) and both twiddle sets stay in VGPRs for the whole kernel; the tile loop is
+//     unrolled by two so that the image in hand is a compile-time constant and every LDS address
+//     a per-thread index plus an immediate.
 // HBM traffic per tile: L items read + L items written = the algorithmic 16 B per sample.
 #pragma once
+#include <type_traits>
 #include "k_corr4k.h"
 
 namespace aisx {
 
 constexpr int CD_IMG = 16 * CF4_ROW;               // complex slots per window image
-constexpr int CD_LDS_ELEMS = 2 * CD_IMG + 256;     // two images + the W_256 table
-constexpr int CD_LDS_BYTES = CD_LDS_ELEMS * 8;     // 71680 B: two workgroups per CU
+// build switches (measured variants, MI355X, 4096 x 65536, N = 896, kernel alone; the defaults
+// are what the product ships):
+//   CD_FOUR_BARRIERS  1 = four barriers per tile (overlap copy and DMA issue held back behind the
+//                     first pass's barrier), 0 = five (one at the tile's top).  Four: 1.31-1.33 ms
+//                     against 1.27-1.29: the window then has three passes to land instead of a
+//                     whole tile, and eight more VGPRs are live across the first pass.
+//   CD_UNROLL2        1 = tile loop unrolled by two, the image in hand a compile-time constant (LDS
+//                     addresses = per-thread index + immediate, ~80 VALU fewer per tile), 0 = one
+//                     loop body.  Unrolled: 1.35 ms against 1.27-1.29 (twice the code).
+//   CD_W2_REGS        1 = second / third pass twiddles in registers: 64 VGPR spills, not measured.
+#ifndef CD_FOUR_BARRIERS
+#define CD_FOUR_BARRIERS 0
+#endif
+#ifndef CD_UNROLL2
+#define CD_UNROLL2 0
+#endif
+// second / third pass twiddles W_256^{k2 n3}: 1 = in registers (30 VGPRs), 0 = a 2 KB table in LDS
+#ifndef CD_W2_REGS
+#define CD_W2_REGS 0
+#endif
+constexpr int CD_LDS_ELEMS = 2 * CD_IMG + (CD_W2_REGS ? 0 : 256); // two images (+ the W_256 table)
+constexpr int CD_LDS_BYTES = CD_LDS_ELEMS * 8;     // 69632 / 71680 B: two workgroups per CU
 constexpr int CD_PIECE = 128;                      // items per DMA wave-instruction (64 lanes x 16 B)
 
 // natural-order slot of window item i (what the DMA writes and the first pass reads)
@@ -39,6 +62,14 @@ AISX_HD int cd_nat(int i) { return (i >> 8) * CF4_ROW + (i & 255); }
 // NC: the template length as a compile-time constant (every slice predicate of the tile loop
 // then folds: which of a thread's sixteen items are pass-through outputs, overlap, correlation
 // outputs), or 0 for the run-time version that serves any length.
+//
+// Barriers per tile: five (CD_FOUR_BARRIERS = 0).  With four, the loop carries no barrier between
+// the last inverse pass of tile j (reads image A) and the first forward pass of tile j + 1 (reads
+// and rewrites image B in place):
+//   * a wave waits for its share of the next window (vmcnt) BEFORE the barrier that ends the
+//     fourth pass, so behind that barrier the whole window is in LDS;
+//   * what tile j + 1 writes into image A -- the overlap and the DMA of window j + 2 -- is held
+//     back until the barrier that ends ITS first pass: by then every wave has left tile j.
 template <class Ctx, int NC>
 AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
 {
@@ -48,9 +79,6 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     const int c = cx.by();
     const int seg = cx.bx();
     cf* lds = (cf*)cx.lds();
-    cf* A = lds;           // image of the tile in hand
-    cf* B = lds + CD_IMG;  // image of the next one
-    cf* ldsT = lds + 2 * CD_IMG;
 
     const int N = NC ? NC : p.N, L = CF4_F - N, n = p.n;
     const cf* xin = p.in + (long)c * p.in_stride;
@@ -59,16 +87,29 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     const cf* hist = p.hist_in + (long)c * N;
     unsigned long long* abits = p.abits + (long)c * p.abits_stride;
 
-    // per-thread constants of the transform, in registers for the whole kernel
+    // per-thread constants of the transform, in registers for the whole kernel: first / last pass
+    // twiddles W_4096^{k t}, second / third pass twiddles W_256^{k2 n3}, the thread's 16 positions of H
     cf w[16], H[16];
     w[0] = mk(1.f, 0.f);
 #pragma unroll
     for (int k = 1; k < 16; k++)
-        w[k] = p.wtab[(k * t) & (CF4_F - 1)]; // W_4096^{k t}
+        w[k] = p.wtab[(k * t) & (CF4_F - 1)];
+#if CD_W2_REGS
+    cf w2[16];
+    w2[0] = mk(1.f, 0.f);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        w2[k] = p.wtab[(16 * k * (t & 15)) & (CF4_F - 1)];
+    auto tw2 = [&](int k2) -> cf { return w2[k2]; };
+#else
+    cf* const ldsT = lds + 2 * CD_IMG;
+    ldsT[t] = p.wtab[(16 * (t >> 4) * (t & 15)) & (CF4_F - 1)]; // W_256^{k2 n3}, index k2*16+n3
+    const cf* const myT = ldsT + (t & 15);
+    auto tw2 = [&](int k2) -> cf { return ld8(myT + k2 * 16); };
+#endif
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++)
         H[k3] = p.Hpos[t * 16 + k3];
-    ldsT[t] = p.wtab[(16 * (t >> 4) * (t & 15)) & (CF4_F - 1)]; // W_256^{k2 n3}, index k2*16+n3
 
     unsigned vmask_int = 0; // value n1 of this thread is window item t + 256 n1: an output iff >= N
 #pragma unroll
@@ -79,7 +120,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     const auto bin = cx.make_buf(xin, (unsigned)n * 8u);
     const auto bout = cx.make_buf(xout, (unsigned)n * 8u);
     const int P0 = N / CD_PIECE; // first DMA piece that holds new items (it may hold a few old ones too)
-    const unsigned ldsA = cx.lds_addr(A), ldsB = cx.lds_addr(B);
+    const unsigned lds0 = cx.lds_addr(lds);
 
     // the new items of the window of the tile whose outputs start at k0: pieces P0 .. 31, spread
     // over the four waves; item i of the window is stream item k0 - N + i
@@ -103,7 +144,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     // (history of the block where the stream index is negative, lib/corr_est_cc_impl.cc:180-188)
     if (ntile > 0) {
         const int k0 = tile0 * L;
-        issue_window(ldsA, k0);
+        issue_window(lds0, k0);
         // (an odd N splits a 16-byte DMA pair between stream items -1 and 0 in the first window of
         // a call; what the hardware returns for the half that wraps is not relied upon: item N
         // is then written here as well)
@@ -122,15 +163,27 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
         for (int m = 0; m < 8; m++) {
             const int i = t + CF4_T * m;
             if (i < Npro)
-                st8(A + cd_nat(i), pro[m]);
+                st8(lds + cd_nat(i), pro[m]);
         }
+        cx.lds_barrier();
     }
 
-    for (int j = 0; j < ntile; j++) {
+    // one tile in image IMG (a compile-time constant: every LDS address is a per-thread index
+    // plus an immediate), the other image filling up for the next one
+    auto tile = [&](auto IMGC, int j) {
+#if CD_UNROLL2
+        constexpr int IMG = decltype(IMGC)::value;
+#else
+        const int IMG = j & 1;
+#endif
+        cf* const A = lds + IMG * CD_IMG;
+        cf* const B = lds + (1 - IMG) * CD_IMG;
+        const unsigned imgB = lds0 + (unsigned)((1 - IMG) * CD_IMG * 8);
         const int k0 = (tile0 + j) * L;
-        const unsigned imgB = (j & 1) ? ldsA : ldsB;
+#if !CD_FOUR_BARRIERS
         cx.wait_dma();    // this wave's share of the window (issued a tile ago) has landed
         cx.lds_barrier(); // ... and everybody's; everybody has left the other image
+#endif
         cf x[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++)
@@ -157,20 +210,32 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
                     cx.buf_store64(bout, (unsigned)(k0 + i) * 8u, 0u, x[n1]);
             }
         }
-        if (j + 1 < ntile) {
-            // the overlap: items [L, F) of this window are items [0, N) of the next one
+        // the overlap -- items [L, F) of this window are items [0, N) of the next one -- waits in
+        // registers until the other image is free (after the barrier below)
+        constexpr int NOV = NC ? (NC + CF4_T - 1) / CF4_T + 1 : 9; // slices that can hold items >= L
+        auto next_window = [&](const cf* src) { // src[m] = this window's item t + 256 (16 - NOV + m)
 #pragma unroll
-            for (int n1 = 0; n1 < 16; n1++) {
+            for (int m = 0; m < NOV; m++) {
+                const int n1 = 16 - NOV + m;
                 // (slices wholly below L do nothing; items at or above piece P0 arrive by DMA as
                 // well, with the same value: copying them too saves the test)
                 if (CF4_T * n1 + CF4_T - 1 >= L) {
                     const int d = t + CF4_T * n1 - L;
                     if (CF4_T * n1 >= L || d >= 0)
-                        st8(B + cd_nat(d), x[n1]);
+                        st8(B + cd_nat(d), src[m]);
                 }
             }
             issue_window(imgB, k0 + L);
-        }
+        };
+#if CD_FOUR_BARRIERS
+        cf ov[NOV];
+#pragma unroll
+        for (int m = 0; m < NOV; m++)
+            ov[m] = x[16 - NOV + m];
+#else
+        if (j + 1 < ntile)
+            next_window(&x[16 - NOV]);
+#endif
         if (p.corr_hist_zero && k0 < N) { // (first tile of a call only)
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++)
@@ -186,6 +251,10 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
         for (int k1 = 0; k1 < 16; k1++)
             st8(A + cf4_pos(k1, t), x[k1]);
         cx.lds_barrier();
+#if CD_FOUR_BARRIERS
+        if (j + 1 < ntile) // every wave has left the previous tile: its image takes the next window
+            next_window(ov);
+#endif
         {
             const int k1 = t >> 4, n3 = t & 15;
 #pragma unroll
@@ -194,7 +263,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
             dft16<false>(cx, x);
 #pragma unroll
             for (int k2 = 1; k2 < 16; k2++)
-                x[k2] = cmul_fma(x[k2], ld8(ldsT + k2 * 16 + n3));
+                x[k2] = cmul_fma(x[k2], tw2(k2));
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++)
                 st8(A + cf4_pos(k1, k2 * 16 + n3), x[k2]);
@@ -226,14 +295,17 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++) {
                 cf a = ld8(A + cf4_pos(k1, k2 * 16 + n3));
-                x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, ld8(ldsT + k2 * 16 + n3));
+                x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, tw2(k2));
             }
             dft16<true>(cx, x);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++)
                 st8(A + cf4_pos(k1, n2 * 16 + n3), x[n2]);
         }
-        cx.lds_barrier();
+#if CD_FOUR_BARRIERS
+        cx.wait_dma();    // this wave's share of the next window (issued three passes ago) has landed
+#endif
+        cx.lds_barrier(); // ... and, behind this barrier, everybody's
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) {
             cf a = ld8(A + cf4_pos(k1, t));
@@ -290,11 +362,18 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
             if (cx.ballot(hit != 0u) != 0ull)
                 corr_emit_hits(cx, p, hit, vmask, x, xcorr, abits, kb, CF4_T);
         }
-        // the image of the next tile becomes the one in hand
-        cf* tmp = A;
-        A = B;
-        B = tmp;
+    };
+
+#if CD_UNROLL2
+    for (int j = 0; j < ntile; j += 2) {
+        tile(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < ntile)
+            tile(std::integral_constant<int, 1>{}, j + 1);
     }
+#else
+    for (int j = 0; j < ntile; j++)
+        tile(0, j);
+#endif
     // carry the last N stream samples to the next call (set_history(N+1), :95)
     if (seg == p.nseg - 1) {
         cf* ho = p.hist_out + (long)c * N;
