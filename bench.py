@@ -43,6 +43,11 @@ for _p in (ROOT, os.path.join(ROOT, "gr-ais_amd"), os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
+# The pipelined step keeps four streams busy besides the default one (stream stages, timing
+# recovery, bit tail, frequency estimates one step ahead); with the runtime's default of four
+# hardware queues two of them would share a queue and run one after the other.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CORR_BYTES_PER_SAMPLE = 16  # 8 B read + 8 B delayed pass-through write
 NUNIQ = 32  # CPU-generated channels the device input is built from
@@ -391,8 +396,13 @@ def main():
         cap = dem.clockrec.out_capacity
         outs = [dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
                      produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(NBUF)]
-        s_main, s_msk = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        # (the stream stages' workgroups go first when LDS / wave slots free up: the estimates of the
+        # next step, on s_pre, take what is left)
+        hi = -1 if os.environ.get("AISX_BENCH_PRIO", "0") == "1" else 0  # (measured: no gain)
+        s_main, s_msk = torch.cuda.Stream(device=device, priority=hi), torch.cuda.Stream(device=device)
         s_tail = torch.cuda.Stream(device=device)  # the bit tail of step k runs beside the recovery of step k+1
+        s_pre = torch.cuda.Stream(device=device)   # frequency estimates + NCO phase walk, one step ahead
+        fused = stock and not os.environ.get("AISX_BENCH_UNFUSED")
         dem.clockrec.set_tail_stream(s_tail)
         msk_done = [None] * NBUF
         state = dict(k=0)
@@ -405,13 +415,24 @@ def main():
                     s_main.wait_event(msk_done[par])  # step k-3 released y_corr[par] and its tags
                 y = x
                 if stock:
-                    if os.environ.get("AISX_BENCH_FUSED"):
-                        # (A/B: freq_sync -> agc in one pass over the samples, same results bit for bit;
-                        # run in series the separate NCO phase walk costs more than the pass saves)
+                    if fused:
+                        # freq_sync -> agc in one pass over the samples (same results, bit for bit); the
+                        # frequency estimates and the NCO phase walk of THIS step were prepared on
+                        # s_pre while the previous step's passes ran
                         y, _ = ais_amd.freq_sync_agc(dem.freq_sync, dem.agc, y)
                     else:
                         y, _ = dem.freq_sync.work(y)
                         y = dem.agc.work(y)
+                if stock and fused:
+                    # for step k + 1 (this benchmark feeds the same samples again): the estimates here,
+                    # between the two sample passes (full-grid kernels of different streams take turns
+                    # anyway, and side by side they cost the correlator its second workgroup per CU),
+                    # the phase walk on s_pre beside the correlator
+                    if os.environ.get("AISX_BENCH_EST_ON_PRE"):
+                        with torch.cuda.stream(s_pre):
+                            dem.freq_sync.estimate_ahead(x)
+                    else:
+                        dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
                 o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
                 tags_ptrs = corr.tags_device()
                 ready = torch.cuda.Event()

@@ -96,6 +96,7 @@ def lib():
     sig("aisx_freqsync_work_host", i32, [vp, vp, i32, vp, i32, vp, i32])
     sig("aisx_agc_work_host", i32, [vp, i32, vp, vp])
     sig("aisx_freqsync_agc_process", i32, [vp, vp, vp, lng, i32, vp, lng, vp, lng, pi32, vp])
+    sig("aisx_freqsync_estimate_ahead", i32, [vp, vp, lng, i32, vp, vp])
     sig("aisx_agc_create", i32, [pvp, i32, f32, i32, i32])
     sig("aisx_agc_destroy", i32, [vp])
     sig("aisx_agc_reset", i32, [vp])

@@ -297,6 +297,16 @@ class square_and_fft_sync_cc:
     def reset(self):
         check(_lib.lib().aisx_freqsync_reset(self._h), "reset")
 
+    def estimate_ahead(self, x, stream=None, walk_stream=None):
+        """Prepare the frequency estimates (on `stream`) and the NCO phase walk (on `walk_stream`,
+        default: the same) of the next freq_sync_agc() call on exactly this tensor
+        (aisx_freqsync_estimate_ahead): the serial walk of step k + 1 then runs beside the sample
+        passes of step k."""
+        x = _dev_c64(x, self.nchan)
+        check(_lib.lib().aisx_freqsync_estimate_ahead(self._h, x.data_ptr(), x.stride(0), x.shape[1], _stream_ptr(stream),
+                                                      _stream_ptr(walk_stream) if walk_stream is not None else None),
+              "estimate_ahead")
+
     def work(self, x, want_fhat=False, stream=None, out=None):
         """`out`: optional preallocated (nchan, >= n + fftlen) complex64 buffer the result is a view of."""
         x = _dev_c64(x, self.nchan)

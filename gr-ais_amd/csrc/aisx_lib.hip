@@ -73,11 +73,18 @@ __global__ __launch_bounds__(CF4_T, 3) void k_corr4_main(CorrParams p)
 
 // the F = 4096 correlator with the next tile's window prefetched by LDS-DMA (k_corr4d.h): two
 // workgroups per CU (two 34 KB window images each), up to 256 VGPRs
+// (Two waves per SIMD at 256 VGPRs leave no register room for a wave of another stream's kernel on
+// that SIMD: beside the NCO phase walk (30 VGPRs, one wave on each of 64 CUs) or the timing
+// recovery (105) a CU holds one workgroup of this kernel, not two.  amdgpu_num_vgpr(240) does not
+// cap the unified file -- the compiler spills into AGPRs on top -- so this stays as it is.)
 template <int NC>
 __global__ __launch_bounds__(CF4_T, 2) void k_corr4d_main(CorrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
+#ifdef CORR_PRIO
+    __builtin_amdgcn_s_setprio(CORR_PRIO);
+#endif
     corr4d_main_body<DevCtx, NC>(cx, p);
 }
 // builds with the template length folded in: the stock template at 4 and at 5 samples per symbol

@@ -2,6 +2,7 @@
 // reference's chain (python/ais_demod.py:56): square_and_fft_sync_cc / freqest
 // (python/gmsk_sync.py, lib/freqest_impl.cc) and analog.feedforward_agc_cc.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -28,6 +29,12 @@ __global__ __launch_bounds__(FSW_T) void k_fs_walk(FsWalkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
+    // a strict recurrence on one wave per 64 channels, meant to run beside full-occupancy kernels
+    // of other streams: its few instructions go first on their SIMD (as the timing recovery's do)
+#ifndef WALK_PRIO
+#define WALK_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(WALK_PRIO);
     fs_walk_body(cx, p);
 }
 __global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
@@ -56,12 +63,30 @@ struct aisx_freqsync {
     cf* d_pend[2] = { nullptr, nullptr };
     int cur = 0, npend = 0;
     cf* d_wtab = nullptr;
-    int* d_maxpos = nullptr;
-    float* d_phase = nullptr;
-    // the walked NCO phases of one call, [nchan][phases_stride] (fused front end only; allocated
-    // on first use: 4 bytes per sample)
-    float* d_phases = nullptr;
+    int* d_maxpos = nullptr;   // = slot[0].d_maxpos (the two-pass path)
+    float* d_phase = nullptr;  // the committed NCO phase, = d_phase2[phase_cur]
+    float* d_phase2[2] = { nullptr, nullptr };
+    int phase_cur = 0;
+    // Fused front end (aisx_freqsync_agc_process).  What a call's sample pass needs from the
+    // frequency estimator -- maxpos per vector, the walked NCO phases phi[c][i] (4 bytes per sample,
+    // allocated on first use), f-hat -- lives in one of two slots, so that the estimate for call
+    // k + 1 can be prepared on another stream (aisx_freqsync_estimate_ahead) while call k's pass
+    // still reads its own.
+    struct Slot {
+        int* d_maxpos = nullptr;
+        float* d_phases = nullptr;
+        float* d_fhat = nullptr;
+        hipEvent_t ev_read = nullptr; // the last sample pass that read this slot
+        bool read_pending = false;
+    } slot[2];
     long phases_stride = 0;
+    int slot_cur = 0; // the slot the next process call uses
+    hipEvent_t ev_walk = nullptr, ev_proc = nullptr, ev_ahead = nullptr, ev_est = nullptr;
+    bool walk_pending = false, proc_pending = false;
+    bool ahead = false; // an estimate prepared ahead, for a call with exactly these arguments
+    const void* ahead_in = nullptr;
+    long ahead_stride = 0;
+    int ahead_n = 0;
     // GNU Radio path staging (aisx_freqest_work_host)
     cf* d_st_vec = nullptr;
     float* d_st_out = nullptr;
@@ -114,8 +139,11 @@ extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, doub
     CK(dev_alloc(&h->d_pend[0], (size_t)nchan * fftlen));
     CK(dev_alloc(&h->d_pend[1], (size_t)nchan * fftlen));
     CK(dev_alloc(&h->d_wtab, FS_F));
-    CK(dev_alloc(&h->d_maxpos, (size_t)nchan * h->max_vec));
-    CK(dev_alloc(&h->d_phase, nchan));
+    CK(dev_alloc(&h->slot[0].d_maxpos, (size_t)nchan * h->max_vec));
+    h->d_maxpos = h->slot[0].d_maxpos;
+    CK(dev_alloc(&h->d_phase2[0], nchan));
+    CK(dev_alloc(&h->d_phase2[1], nchan));
+    h->d_phase = h->d_phase2[0];
 #undef CK
     if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * FS_F, hipMemcpyHostToDevice) != hipSuccess) {
         set_err("aisx_freqsync_create: table upload failed");
@@ -133,9 +161,17 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
     dev_free(h->d_pend[0]);
     dev_free(h->d_pend[1]);
     dev_free(h->d_wtab);
-    dev_free(h->d_maxpos);
-    dev_free(h->d_phase);
-    dev_free(h->d_phases);
+    for (int k = 0; k < 2; k++) {
+        dev_free(h->slot[k].d_maxpos);
+        dev_free(h->slot[k].d_phases);
+        dev_free(h->slot[k].d_fhat);
+        if (h->slot[k].ev_read)
+            (void)hipEventDestroy(h->slot[k].ev_read);
+        dev_free(h->d_phase2[k]);
+    }
+    for (hipEvent_t e : { h->ev_walk, h->ev_proc, h->ev_ahead, h->ev_est })
+        if (e)
+            (void)hipEventDestroy(e);
     dev_free(h->d_st_vec);
     dev_free(h->d_st_out);
     delete h;
@@ -146,10 +182,14 @@ extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
 {
     if (!h)
         return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipDeviceSynchronize());
     AISX_HIPCHK(hipMemset(h->d_phase, 0, sizeof(float) * h->nchan));
     AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fill vs. the caller's non-blocking streams)
     h->npend = 0;
     h->cur = 0;
+    h->ahead = false;
+    h->walk_pending = h->proc_pending = false;
+    h->slot[0].read_pending = h->slot[1].read_pending = false;
     return AISX_OK;
 }
 
@@ -166,6 +206,11 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
         set_err("aisx_freqsync_process: output stride too small for %d vectors", nvec);
         return AISX_ERR_INVALID;
     }
+    h->ahead = false; // (an estimate prepared for the fused call is dropped: nothing of it was committed)
+    if (h->walk_pending)
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_walk, 0));
+    if (h->proc_pending)
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_proc, 0));
     if (nvec > 0) {
         FsEstParams e;
         e.in = (const cf*)d_in;
@@ -412,6 +457,114 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     return AISX_OK;
 }
 
+// ---- fused front end ------------------------------------------------------------------------
+static int fs_fused_prepare(aisx_freqsync* h)
+{
+    int rc;
+    if (!h->ev_walk) {
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming));
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_proc, hipEventDisableTiming));
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_ahead, hipEventDisableTiming));
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_est, hipEventDisableTiming));
+    }
+    for (int k = 0; k < 2; k++) {
+        aisx_freqsync::Slot& s = h->slot[k];
+        if (!s.ev_read)
+            AISX_HIPCHK(hipEventCreateWithFlags(&s.ev_read, hipEventDisableTiming));
+        if (!s.d_maxpos && (rc = dev_alloc(&s.d_maxpos, (size_t)h->nchan * h->max_vec)) != AISX_OK)
+            return rc;
+        if (!s.d_fhat && (rc = dev_alloc(&s.d_fhat, (size_t)h->nchan * h->max_vec)) != AISX_OK)
+            return rc;
+        if (!s.d_phases) {
+            h->phases_stride = ((long)h->max_vec * h->fftlen + 3) & ~3L;
+            if ((rc = dev_alloc(&s.d_phases, (size_t)h->nchan * (size_t)h->phases_stride, false)) != AISX_OK)
+                return rc;
+        }
+    }
+    return AISX_OK;
+}
+
+// frequency estimates (fs_est_body) and NCO phase walk (fs_walk_body) of the call that comes
+// next, into the slot it will use; the walk leaves the phase it ends on in the uncommitted copy
+static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, hipStream_t st,
+                                 hipStream_t st_walk)
+{
+    const int nvec = (h->npend + n) / h->fftlen;
+    if (nvec == 0)
+        return AISX_OK;
+    aisx_freqsync::Slot& s = h->slot[h->slot_cur];
+    // what this estimate reads or overwrites may still be in use on another stream
+    if (s.read_pending)
+        AISX_HIPCHK(hipStreamWaitEvent(st, s.ev_read, 0)); // the pass of two calls ago read this slot
+    if (h->proc_pending && h->npend > 0)
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_proc, 0)); // the last pass wrote the pending items
+    if (h->walk_pending)
+        AISX_HIPCHK(hipStreamWaitEvent(st_walk, h->ev_walk, 0)); // the last walk wrote the phase this one starts from
+    FsEstParams e;
+    e.in = (const cf*)d_in;
+    e.in_stride = in_stride;
+    e.pend = h->d_pend[h->cur];
+    e.npend = h->npend;
+    e.wtab = h->d_wtab;
+    e.maxpos = s.d_maxpos;
+    e.maxpos_stride = h->max_vec;
+    e.nvec = nvec;
+    e.offset = h->offset;
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+    AISX_HIPCHK(hipGetLastError());
+    if (st_walk != st) { // the walk on a stream of its own, behind the estimates
+        AISX_HIPCHK(hipEventRecord(h->ev_est, st));
+        AISX_HIPCHK(hipStreamWaitEvent(st_walk, h->ev_est, 0));
+        if (s.read_pending)
+            AISX_HIPCHK(hipStreamWaitEvent(st_walk, s.ev_read, 0));
+    }
+    FsWalkParams w;
+    w.nchan = h->nchan;
+    w.maxpos = s.d_maxpos;
+    w.maxpos_stride = h->max_vec;
+    w.fhat = s.d_fhat;
+    w.fhat_stride = h->max_vec;
+    w.phase_in = h->d_phase2[h->phase_cur];
+    w.phase_out = h->d_phase2[h->phase_cur ^ 1];
+    w.phases = s.d_phases;
+    w.phases_stride = h->phases_stride;
+    w.nvec = nvec;
+    w.binsize = h->binsize;
+    w.sensitivity = h->sensitivity;
+    hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES, st_walk, w);
+    AISX_HIPCHK(hipGetLastError());
+    AISX_HIPCHK(hipEventRecord(h->ev_walk, st_walk));
+    h->walk_pending = true;
+    return AISX_OK;
+}
+
+// Prepares, on `stream`, the frequency estimates and NCO phases of the NEXT
+// aisx_freqsync_agc_process call, which must come with the same d_in / in_stride / n (otherwise
+// the preparation is dropped and that call estimates for itself).  The serial phase walk of call
+// k + 1 can so run beside the sample passes of call k.  At most one call ahead.
+extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
+                                            void* walk_stream)
+{
+    if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n) {
+        set_err("aisx_freqsync_estimate_ahead: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    if (h->ahead) {
+        set_err("aisx_freqsync_estimate_ahead: an estimate is already waiting for its aisx_freqsync_agc_process call");
+        return AISX_ERR_INVALID;
+    }
+    int rc;
+    hipStream_t sw = walk_stream ? (hipStream_t)walk_stream : (hipStream_t)stream;
+    if ((rc = fs_fused_prepare(h)) != AISX_OK || (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw)) != AISX_OK)
+        return rc;
+    AISX_HIPCHK(hipEventRecord(h->ev_ahead, sw));
+    h->ahead = true;
+    h->ahead_in = d_in;
+    h->ahead_stride = in_stride;
+    h->ahead_n = n;
+    return AISX_OK;
+}
+
 // The first two blocks of python/ais_demod.py:56 in one pass over the samples: the frequency
 // estimates (fs_est_body) and the NCO phase walk (fs_walk_body) as in aisx_freqsync_process, the
 // mixing done where feedforward_agc_cc reads its input (agc8_body): square_and_fft_sync_cc's
@@ -438,38 +591,23 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
         return AISX_ERR_INVALID;
     }
     int rc;
-    if (!h->d_phases) {
-        h->phases_stride = ((long)h->max_vec * h->fftlen + 3) & ~3L;
-        if ((rc = dev_alloc(&h->d_phases, (size_t)h->nchan * (size_t)h->phases_stride, false)) != AISX_OK)
-            return rc;
+    if ((rc = fs_fused_prepare(h)) != AISX_OK)
+        return rc;
+    if (h->ahead && (h->ahead_in != (const void*)d_in || h->ahead_stride != in_stride || h->ahead_n != n))
+        h->ahead = false; // prepared for other arguments: nothing of it was committed, estimate afresh
+    if (h->ahead) {
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_ahead, 0));
+        h->ahead = false;
+    } else if ((rc = fs_estimate_into_slot(h, d_in, in_stride, n, st, st)) != AISX_OK) {
+        return rc;
     }
+    aisx_freqsync::Slot& s = h->slot[h->slot_cur];
     if (nvec > 0) {
-        FsEstParams e;
-        e.in = (const cf*)d_in;
-        e.in_stride = in_stride;
-        e.pend = h->d_pend[h->cur];
-        e.npend = h->npend;
-        e.wtab = h->d_wtab;
-        e.maxpos = h->d_maxpos;
-        e.maxpos_stride = h->max_vec;
-        e.nvec = nvec;
-        e.offset = h->offset;
-        hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
-        AISX_HIPCHK(hipGetLastError());
-        FsWalkParams w;
-        w.nchan = h->nchan;
-        w.maxpos = h->d_maxpos;
-        w.maxpos_stride = h->max_vec;
-        w.fhat = d_fhat;
-        w.fhat_stride = fhat_stride;
-        w.phase = h->d_phase;
-        w.phases = h->d_phases;
-        w.phases_stride = h->phases_stride;
-        w.nvec = nvec;
-        w.binsize = h->binsize;
-        w.sensitivity = h->sensitivity;
-        hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES, st, w);
-        AISX_HIPCHK(hipGetLastError());
+        h->phase_cur ^= 1; // the walk's end phase becomes the block's d_phase
+        h->d_phase = h->d_phase2[h->phase_cur];
+        if (d_fhat)
+            AISX_HIPCHK(hipMemcpy2DAsync(d_fhat, sizeof(float) * fhat_stride, s.d_fhat, sizeof(float) * h->max_vec, sizeof(float) * nvec,
+                                         h->nchan, hipMemcpyDeviceToDevice, st));
     }
     AgcParams p;
     p.in = (const cf*)d_in;
@@ -483,7 +621,7 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.reference = a->reference;
     p.floor_env = a->floor_env;
     p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1; // (a call without a whole vector still moves the pending items)
-    p.phases = h->d_phases;
+    p.phases = s.d_phases;
     p.phases_stride = h->phases_stride;
     p.pend_in = h->d_pend[h->cur];
     p.pend_out = h->d_pend[h->cur ^ 1];
@@ -491,6 +629,11 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.n_raw = n;
     hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, st, p);
     AISX_HIPCHK(hipGetLastError());
+    AISX_HIPCHK(hipEventRecord(s.ev_read, st));
+    s.read_pending = true;
+    AISX_HIPCHK(hipEventRecord(h->ev_proc, st));
+    h->proc_pending = true;
+    h->slot_cur ^= 1;
     h->npend = h->npend + n - total;
     h->cur ^= 1;
     a->cur ^= 1;

@@ -225,16 +225,20 @@ AISX_HD float nco_wrap_small(float ph)
 // frequency_modulator_fc's d_phase += k f; fmod wrap).  A wave keeps 64 steps of its 64 channels
 // in LDS and flushes them row by row: 256 contiguous bytes per channel and flush.
 constexpr int FSW_T = 64;
-constexpr int FSW_BLK = 64;      // steps per flush
-constexpr int FSW_PITCH = 68;    // floats per LDS row (rows 16-byte aligned)
+// steps per flush.  Small on purpose: 3 KB of LDS per wave -- the walk is meant to run beside the
+// timing recovery (84 KB per workgroup) AND the correlator (72 KB) on the same CU, which leaves 4
+#ifndef FSW_BLK
+#define FSW_BLK 8
+#endif
+constexpr int FSW_PITCH = FSW_BLK + 4; // floats per LDS row (rows 16-byte aligned)
 constexpr int FSW_LDS_BYTES = FSW_T * FSW_PITCH * 4;
-static_assert(FS_F % FSW_BLK == 0, "whole blocks per vector");
+static_assert(FS_F % FSW_BLK == 0 && FSW_BLK % 4 == 0 && FSW_BLK <= 64, "whole 16-byte quads, whole blocks per vector");
 
 struct FsWalkParams {
     int nchan;
     const int* maxpos; long maxpos_stride; // [nchan][nvec] from fs_est_body
     float* fhat; long fhat_stride;         // optional [nchan][nvec]
-    float* phase;                          // [nchan] NCO phase (d_phase), in and out
+    const float* phase_in; float* phase_out; // [nchan] NCO phase (d_phase) before / after (may be the same array)
     float* phases; long phases_stride;     // [nchan][nvec * fftlen] out; stride a multiple of 4
     int nvec;
     float binsize, sensitivity;
@@ -250,7 +254,7 @@ AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
     const bool live = c < p.nchan;
     float* R = (float*)cx.lds(); // [64][FSW_PITCH]: row = channel of the wave, column = step of the block
     float* mine = R + l * FSW_PITCH;
-    float ph = live ? p.phase[c] : 0.f;
+    float ph = live ? p.phase_in[c] : 0.f;
     unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
     for (int v = 0; v < p.nvec; v++) {
         float d = 0.f;
@@ -288,12 +292,13 @@ AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
                 }
             }
             cx.wave_sync();
-            // flush: 16 lanes x 16 bytes cover one channel's 64 phases, four channels per pass
-            const long col = (long)v * FS_F + b * FSW_BLK + 4 * (l & 15);
+            // flush: QPR lanes x 16 bytes cover one channel's FSW_BLK phases, 64 / QPR channels per pass
+            constexpr int QPR = FSW_BLK / 4;
+            const long col = (long)v * FS_F + b * FSW_BLK + 4 * (l % QPR);
 #pragma unroll 4
-            for (int pass = 0; pass < FSW_T / 4; pass++) {
-                const int r = pass * 4 + (l >> 4);
-                const ph4 q = *(const ph4*)(R + r * FSW_PITCH + 4 * (l & 15));
+            for (int pass = 0; pass < QPR; pass++) {
+                const int r = pass * (FSW_T / QPR) + l / QPR;
+                const ph4 q = *(const ph4*)(R + r * FSW_PITCH + 4 * (l % QPR));
                 if (cbase + r < p.nchan)
                     *(ph4*)(p.phases + (long)(cbase + r) * p.phases_stride + col) = q;
             }
@@ -301,7 +306,7 @@ AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
         }
     }
     if (live)
-        p.phase[c] = ph;
+        p.phase_out[c] = ph;
 }
 
 // ---------------------------------------------------------------------------

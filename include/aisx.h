@@ -248,6 +248,15 @@ int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf
  * those had been called.  AGC windows that are a multiple of 8 (the stock 512). */
 int aisx_freqsync_agc_process(aisx_freqsync* fs, aisx_agc* agc, const aisx_cf32* d_in, long in_stride, int n,
                               aisx_cf32* d_out, long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream);
+/* Prepares the frequency estimates (on `stream`) and the NCO phase walk (on `walk_stream`, NULL =
+ * the same stream, behind the estimates) of the NEXT aisx_freqsync_agc_process call, which must
+ * come with the same d_in / in_stride / n (it then waits for this preparation instead of
+ * estimating itself; with other arguments the preparation is dropped).  The walk is a strict
+ * recurrence per channel (one lane each, ~2 ms for 65536 samples whatever the channel count):
+ * prepared one call ahead and on a stream of its own it runs beside the sample passes of the call
+ * before.  At most one call ahead; d_in must stay valid and unchanged until then. */
+int aisx_freqsync_estimate_ahead(aisx_freqsync* fs, const aisx_cf32* d_in, long in_stride, int n, void* stream,
+                                 void* walk_stream);
 /* GNU Radio path (nchan == 1, HOST pointers): in = input_items[0] as the scheduler passes it to
  * a sync_block with set_history(nsamples): nsamples - 1 old items, then noutput_items new ones.
  * Returns noutput_items or a negative status. */

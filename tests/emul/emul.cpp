@@ -610,7 +610,7 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
         run_grid((nvec + 3) / 4, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
         FsWalkParams w;
         w.nchan = h->nchan; w.maxpos = h->maxpos.data(); w.maxpos_stride = h->max_vec; w.fhat = fhat; w.fhat_stride = fhat_stride;
-        w.phase = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.nvec = nvec; w.binsize = h->binsize;
+        w.phase_in = h->phase.data(); w.phase_out = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.nvec = nvec; w.binsize = h->binsize;
         w.sensitivity = h->sens;
         run_grid((h->nchan + FSW_T - 1) / FSW_T, 1, FSW_T, FSW_LDS_BYTES, [&](EmuCtx& cx) { fs_walk_body(cx, w); });
     }

@@ -282,3 +282,40 @@ def test_fused_front_end_equals_the_two_blocks(ais):
     assert nout == (total // 1024) * 1024
     with pytest.raises(ValueError):
         ais.freq_sync_agc(fs1, ais.feedforward_agc_cc(37, 2.0, nchan=nchan, max_items=max(lens) + 1024), _dev(xs[:, :100]))
+
+
+def test_estimate_ahead_gives_the_same_results(ais):
+    # aisx_freqsync_estimate_ahead: estimates + NCO phase walk of call k + 1 prepared on a second
+    # stream while call k's sample pass runs; ragged calls (pending items written by the pass the
+    # next estimate has to wait for), a prepared estimate that is dropped (other arguments)
+    import torch
+    from ais_amd import synth
+
+    nchan = 70
+    lens = [4096, 1000, 24, 5000, 9 * 1024 + 7, 10, 2048]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(1500 + c, total, "P", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
+    mk = lambda: (ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens)),
+                  ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024))
+    (fs1, ag1), (fs2, ag2) = mk(), mk()
+    side = torch.cuda.Stream()
+    chunks, k = [], 0
+    for L in lens:
+        chunks.append(_dev(xs[:, k:k + L]))
+        k += L
+    torch.cuda.synchronize()
+    fs2.estimate_ahead(chunks[0], stream=side)
+    for i, x in enumerate(chunks):
+        a, fa = ais.freq_sync_agc(fs1, ag1, x, want_fhat=True)
+        b, fb = ais.freq_sync_agc(fs2, ag2, x, want_fhat=True)
+        if i + 1 < len(chunks):
+            if i == 2:  # prepared for other arguments: must be dropped, not used
+                fs2.estimate_ahead(chunks[0], stream=side)
+            else:
+                fs2.estimate_ahead(chunks[i + 1], stream=side)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+        assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy())
+    with pytest.raises(ValueError):
+        fs2.estimate_ahead(chunks[0], stream=side)
+        fs2.estimate_ahead(chunks[0], stream=side)  # one call ahead at most
