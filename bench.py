@@ -318,6 +318,13 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def corr_kernel_name(n):
+    """the correlator kernel aisx_corr_process launches for an n-item template (aisx_lib.hip)"""
+    if n <= 512:
+        return "k_corr_main"
+    return "k_corr4_main" if os.environ.get("AISX_CORR_DMA", "1") == "0" else "k_corr4d_main"
+
+
 def main():
     args = parse_args()
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
@@ -509,7 +516,7 @@ def main():
         wall = (time.perf_counter() - t0) / nrun
         kms = float(np.mean(blk.kernel_ms_history()[-nrun:]))
         nbytes = CORR_BYTES_PER_SAMPLE * float(nch) * T
-        r = dict(channels=nch, template_len=int(tm.size), kernel="k_corr4_main" if tm.size > 512 else "k_corr_main",
+        r = dict(channels=nch, template_len=int(tm.size), kernel=corr_kernel_name(tm.size),
                  kernel_ms=kms, call_ms=wall * 1e3, achieved_GBs=nbytes / (kms * 1e-3) / 1e9,
                  frac=nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, complex_MSs=float(nch) * T / wall / 1e6)
         del blk, x, out
@@ -554,7 +561,7 @@ def main():
                 "parallelism": "channel-sharded x%d, no collective" % world,
             },
             "roofline": {
-                "kernel": "k_corr4_main" if tmpl.size > 512 else "k_corr_main",
+                "kernel": corr_kernel_name(tmpl.size),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

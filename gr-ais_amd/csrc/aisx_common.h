@@ -137,41 +137,41 @@ AISX_HD float fast_atan2f_tab(float y, float x, const float* tab)
     return ((y_abs > 0.0f) || (x_abs > 0.0f)) ? angle : 0.0f;
 }
 
-// Deterministic sin/cos for the NCO: plain IEEE double + and * only, so the
-// device result is bit-identical to the CPU checker's restatement of it.
-AISX_HD void det_sincos(float phase, float* s, float* c)
+// [GR] gr::fxpt (gnuradio-runtime fxpt.h, 3.7 / 3.8): the fixed-point sin / cos behind
+// frequency_modulator_fc (angle = float_to_fixed(d_phase); sincos(angle, &oq, &oi)).  A 32-bit
+// angle (2^31 = pi); its top 10 bits pick a {slope, offset} pair of s_sine_table (`tab`, 1024 x 2
+// floats: aisx_tables.h, staged in LDS by the kernels), the line is evaluated at ux >> 1 in float,
+// multiply and add rounded separately.  Integer and fp32 work only: both sides agree bit for bit.
+AISX_HD int fxpt_float_to_fixed(float x)
 {
-    const double TWO_OVER_PI = 0.63661977236758134308;
-    const double PIO2_HI = 1.57079632673412561417e+00;
-    const double PIO2_LO = 6.07710050650619224932e-11;
-    double x = (double)phase;
-    double kd = rint(x * TWO_OVER_PI);
-    int k = (int)kd;
-    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
-    double r2 = r * r;
-    double ps = -2.5052108385441718775e-08;
-    ps = ps * r2 + 2.7557319223985890653e-06;
-    ps = ps * r2 + -1.9841269841269841270e-04;
-    ps = ps * r2 + 8.3333333333333332177e-03;
-    ps = ps * r2 + -1.6666666666666665741e-01;
-    double sn = r + r * (r2 * ps);
-    double pc = 2.0876756987868098979e-09;
-    pc = pc * r2 + -2.7557319223985888276e-07;
-    pc = pc * r2 + 2.4801587301587301566e-05;
-    pc = pc * r2 + -1.3888888888888889419e-03;
-    pc = pc * r2 + 4.1666666666666664354e-02;
-    pc = pc * r2 + -0.5;
-    double cs = 1.0 + r2 * pc;
-    double so, co;
-    switch (k & 3) {
-    case 0: so = sn; co = cs; break;
-    case 1: so = cs; co = -sn; break;
-    case 2: so = -sn; co = -cs; break;
-    default: so = -cs; co = sn; break;
+    const float PI = 3.14159265358979323846f, TAU = 2.0f * 3.14159265358979323846f, TWO_TO_THE_31 = 2147483648.0f;
+    // Fold x into -PI .. PI: d = (int)floor(x / TAU + 0.5); x -= d * TAU.  For -PI <= x < PI the
+    // quotient lies in [-0.5, 0.5), the sum (formed in double, nothing is rounded) in [0, 1), d is 0
+    // and the fold changes nothing -- which is every phase frequency_modulator_fc's own wrap
+    // produces: one compare instead of a division and three double-precision operations.
+    if (!(x >= -PI && x < PI)) {
+        const int d = (int)floor((double)fdiv_rn(x, TAU) + 0.5);
+        x -= (float)d * TAU;
     }
-    *s = (float)so;
-    *c = (float)co;
+    // (int)(x * 2^31 / PI).  The float division by the constant PI is formed as Markstein's
+    // q = y * R; r = fma(-q, PI, y); q + r * R with R = fl(1 / PI): three instructions instead of
+    // the eleven of an IEEE division, and the same float for EVERY y in 1e-30 .. 1e30 (checked
+    // exhaustively, tests/test_oracle_kat.py::test_division_by_pi_is_exact holds the sampled form).
+    const float RCP_PI = 0.318309886183790671538f;
+    const float y = x * TWO_TO_THE_31;
+    const float q = y * RCP_PI;
+    return (int)fmaf(fmaf(-q, PI, y), RCP_PI, q);
 }
+AISX_HD void nco_sincos(float phase, const float* tab, float* s, float* c)
+{
+    const cf* T = reinterpret_cast<const cf*>(tab); // {slope, offset} pairs, 8-byte aligned (LDS or aisx_tables.h)
+    const unsigned x = (unsigned)fxpt_float_to_fixed(phase);
+    const unsigned xc = x + 0x40000000u;
+    const cf es = ld8(T + (x >> 22)), ec = ld8(T + (xc >> 22));
+    *s = es.re * (float)(x >> 1) + es.im;
+    *c = ec.re * (float)(xc >> 1) + ec.im;
+}
+constexpr int NCO_TAB_FLOATS = 2048; // s_sine_table: 1024 x {slope, offset}
 
 // std::abs(std::complex<float>) as glibc's hypotf evaluates it
 AISX_HD float cabs_f(cf a) { return (float)sqrt((double)a.re * (double)a.re + (double)a.im * (double)a.im); }

@@ -8,6 +8,7 @@
 
 #include "aisx_devctx.h"
 #include "aisx_host.h"
+#include "aisx_tables.h"
 #include "k_agc.h"
 #include "k_freqsync.h"
 
@@ -87,6 +88,7 @@ struct aisx_freqsync {
     const void* ahead_in = nullptr;
     long ahead_stride = 0;
     int ahead_n = 0;
+    float* d_sintab = nullptr; // gr::fxpt's sine table
     // GNU Radio path staging (aisx_freqest_work_host)
     cf* d_st_vec = nullptr;
     float* d_st_out = nullptr;
@@ -145,7 +147,12 @@ extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, doub
     CK(dev_alloc(&h->d_phase2[1], nchan));
     h->d_phase = h->d_phase2[0];
 #undef CK
-    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * FS_F, hipMemcpyHostToDevice) != hipSuccess) {
+    if ((rc = dev_alloc(&h->d_sintab, NCO_TAB_FLOATS)) != AISX_OK) {
+        aisx_freqsync_destroy(h);
+        return rc;
+    }
+    if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * FS_F, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_sintab, aisx_sine_table, sizeof(float) * NCO_TAB_FLOATS, hipMemcpyHostToDevice) != hipSuccess) {
         set_err("aisx_freqsync_create: table upload failed");
         aisx_freqsync_destroy(h);
         return AISX_ERR_HIP;
@@ -174,6 +181,7 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
             (void)hipEventDestroy(e);
     dev_free(h->d_st_vec);
     dev_free(h->d_st_out);
+    dev_free(h->d_sintab);
     delete h;
     return AISX_OK;
 }
@@ -243,6 +251,7 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
     m.nvec = nvec;
     m.binsize = h->binsize;
     m.sensitivity = h->sensitivity;
+    m.sintab = h->d_sintab;
     hipLaunchKernelGGL(k_fs_mix, dim3((h->nchan + FSM_CPW - 1) / FSM_CPW), dim3(FSM_T), FSM_LDS_BYTES, st, m);
     AISX_HIPCHK(hipGetLastError());
     h->npend = h->npend + n - nvec * h->fftlen;
@@ -444,6 +453,7 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.ntiles = (n + AGC_TL - 1) / AGC_TL;
     p.phases = nullptr;
     p.phases_stride = 0;
+    p.sintab = nullptr;
     p.pend_in = nullptr;
     p.pend_out = nullptr;
     p.npend = 0;
@@ -623,11 +633,12 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1; // (a call without a whole vector still moves the pending items)
     p.phases = s.d_phases;
     p.phases_stride = h->phases_stride;
+    p.sintab = h->d_sintab;
     p.pend_in = h->d_pend[h->cur];
     p.pend_out = h->d_pend[h->cur ^ 1];
     p.npend = h->npend;
     p.n_raw = n;
-    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES_MIXED, st, p);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipEventRecord(s.ev_read, st));
     s.read_pending = true;

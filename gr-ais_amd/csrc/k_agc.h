@@ -36,6 +36,7 @@ struct AgcParams {
     // raw[m] * e^{j phases[m]} (python/gmsk_sync.py:26-28,33; the phases come from fs_walk_body,
     // k_freqsync.h), raw = the pending partial vector followed by the new samples `in`.
     const float* phases; long phases_stride; // [nchan][n]
+    const float* sintab;                     // gr::fxpt's sine table (NCO_TAB_FLOATS floats, aisx_tables.h)
     const cf* pend_in; cf* pend_out;         // [nchan][1024] pending partial vector in / out
     int npend, n_raw;                        // valid pending items; new raw samples per channel
 };
@@ -140,6 +141,7 @@ constexpr int AGC8_NG = AGC_TL / AGC8_G;               // groups with outputs pe
 constexpr int AGC8_MAXQ = AGC_MAXW / AGC8_G;           // halo groups at most
 constexpr int AGC8_GROUPS = AGC8_NG + AGC8_MAXQ;       // group maxima per buffer
 constexpr int AGC8_LDS_BYTES = (2 * AGC8_GROUPS + AGC8_NG * AGC8_G) * 4; // group maxima x 2, prefix maxima of the NG groups windows end in
+constexpr int AGC8_LDS_BYTES_MIXED = AGC8_LDS_BYTES + NCO_TAB_FLOATS * 4;  // + the NCO's sine table (fused front end)
 static_assert(AGC8_NG == AGC_T, "one output group per thread");
 static_assert(AGC8_MAXQ <= AGC_T, "at most one halo group per thread");
 
@@ -170,49 +172,80 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     const bool mixed = p.phases != nullptr;
     const float* phi = mixed ? p.phases + (long)c * p.phases_stride : nullptr;
     const cf* pend = mixed ? p.pend_in + (long)c * 1024 : nullptr;
+    float* ST = PF + AGC8_NG * AGC8_G; // the NCO's sine table (fused front end only)
     auto mix = [&](cf raw, float ph) -> cf {
         float sn, cs;
-        det_sincos(ph, &sn, &cs);
+        nco_sincos(ph, ST, &sn, &cs);       // [GR] frequency_modulator_fc: gr::fxpt::sincos of d_phase
         return cmul_exact(raw, mk(cs, sn)); // multiply_cc(stream, frequency_modulator_fc output)
     };
-    auto item = [&](int m) -> cf { // item m >= 0 of the block's input
-        if (!mixed)
-            return xin[m];
-        return mix((m < p.npend) ? pend[m] : xin[m - p.npend], phi[m]);
+    auto raw_item = [&](int m) -> cf { // raw sample m >= 0 behind the pending partial vector
+        return (m < p.npend) ? pend[m] : xin[m - p.npend];
+    };
+    auto item = [&](int m) -> cf { // item m >= 0 of the block's input (needs the table in LDS)
+        return mixed ? mix(raw_item(m), phi[m]) : xin[m];
     };
 
-    // one group: load (zero past the end), envelopes, prefix maxima to LDS, group maximum
-    cf own[AGC8_G];
-    float sfx[AGC8_G]; // suffix maxima of the thread's output group: max(e[k .. 7])
-    auto do_group = [&](int g, bool keep) {
+    // One group in two steps, so that in the fused build every global load of the tile is in
+    // flight before the barrier that publishes the sine table: (1) load -- raw samples and, where
+    // they are still to be mixed, their NCO phases (mask `mx`); (2) mix, envelopes, prefix maxima
+    // to LDS, group maximum.
+    struct Grp {
         cf v[AGC8_G];
+        float f[AGC8_G];
+        unsigned mx;
+    };
+    auto load_group = [&](int g, Grp& G) {
         const int s0 = base + g * AGC8_G;
         const int m0 = s0 - H; // first item of the group in the block's input
+        G.mx = 0;
         if (s0 >= H && g * AGC8_G + AGC8_G <= E && (!mixed || m0 >= p.npend)) { // wholly inside the new samples: 16-byte loads
             const cf_pair_agc* src = (const cf_pair_agc*)(xin + (m0 - (mixed ? p.npend : 0)));
 #pragma unroll
             for (int k = 0; k < AGC8_G / 2; k++) {
                 const cf_pair_agc q = src[k];
-                v[2 * k] = q.a;
-                v[2 * k + 1] = q.b;
+                G.v[2 * k] = q.a;
+                G.v[2 * k + 1] = q.b;
             }
             if (mixed) {
-                float f[AGC8_G];
-#pragma unroll
-                for (int k = 0; k < AGC8_G; k++)
-                    f[k] = phi[m0 + k];
-#pragma unroll
-                for (int k = 0; k < AGC8_G; k++)
-                    v[k] = mix(v[k], f[k]);
+                // (the window is a multiple of 8, so m0 = 1 mod 8: phases m0 - 1 .. m0 + 6 are two
+                // aligned 16-byte quads, phase m0 + 7 opens the next one)
+                typedef float f4 __attribute__((vector_size(16)));
+                const f4* q4 = (const f4*)(phi + (m0 - 1));
+                const f4 a = q4[0], b = q4[1];
+                G.f[0] = a[1]; G.f[1] = a[2]; G.f[2] = a[3];
+                G.f[3] = b[0]; G.f[4] = b[1]; G.f[5] = b[2]; G.f[6] = b[3];
+                G.f[7] = phi[m0 + 7];
+                G.mx = 0xffu;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < AGC8_G; k++) {
                 const int j = g * AGC8_G + k, s = base + j;
-                v[k] = mk(0.f, 0.f);
-                if (j < E)
-                    v[k] = (s < H) ? hist[s] : item(s - H);
+                G.v[k] = mk(0.f, 0.f);
+                G.f[k] = 0.f;
+                if (j < E) {
+                    if (s < H)
+                        G.v[k] = hist[s];
+                    else if (!mixed)
+                        G.v[k] = xin[s - H];
+                    else {
+                        G.v[k] = raw_item(s - H);
+                        G.f[k] = phi[s - H];
+                        G.mx |= 1u << k;
+                    }
+                }
             }
+        }
+    };
+    cf own[AGC8_G];
+    float sfx[AGC8_G]; // suffix maxima of the thread's output group: max(e[k .. 7])
+    auto finish_group = [&](int g, bool keep, Grp& G) {
+        cf (&v)[AGC8_G] = G.v;
+        if (mixed) {
+#pragma unroll
+            for (int k = 0; k < AGC8_G; k++)
+                if ((G.mx >> k) & 1u)
+                    v[k] = mix(v[k], G.f[k]);
         }
         float e[AGC8_G];
 #pragma unroll
@@ -246,10 +279,24 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 own[k] = v[k];
         }
     };
-    if (t < ngroups)
-        do_group(t, true);
-    if (AGC8_NG + t < ngroups)
-        do_group(AGC8_NG + t, false);
+    {
+        Grp G1, G2;
+        const bool have1 = t < ngroups, have2 = AGC8_NG + t < ngroups;
+        if (have1)
+            load_group(t, G1);
+        if (have2)
+            load_group(AGC8_NG + t, G2);
+        if (mixed) {
+            typedef float f4 __attribute__((vector_size(16)));
+            for (int i = t; i < NCO_TAB_FLOATS / 4; i += AGC_T) // (8 KB, L2-resident: two 16-byte loads per thread)
+                ((f4*)ST)[i] = ((const f4*)p.sintab)[i];
+            cx.sync();
+        }
+        if (have1)
+            finish_group(t, true, G1);
+        if (have2)
+            finish_group(AGC8_NG + t, false, G2);
+    }
     for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC_T)
         GA[g] = 0.f; // groups past the data: neutral
     cx.sync();

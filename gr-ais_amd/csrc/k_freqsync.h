@@ -15,7 +15,8 @@
 //                 (gmsk_sync.py:26-28,33).  The NCO phase is GNU Radio's float
 //                 accumulator with its fmod wrap, a strict recurrence, so one
 //                 lane per channel walks it and the other waves do the
-//                 sin/cos + complex multiply with coalesced traffic.
+//                 sin/cos (gr::fxpt's table, as frequency_modulator_fc) + complex
+//                 multiply with coalesced traffic.
 // Only fftlen = 1024 (the value the reference uses, python/radio.py:60) is
 // implemented by fs_est_body.
 #pragma once
@@ -317,7 +318,7 @@ constexpr int FSM_CH = 128;            // samples per chunk
 constexpr int FSM_PITCH = FSM_CH + 4;  // floats per channel row in LDS (rows 16-byte aligned: the walk stores four phases at a time)
 constexpr int FSM_UNITS = FSM_CPW * (FSM_CH / 64);            // (channel, 64-sample half) units per chunk
 constexpr int FSM_UPW = (FSM_UNITS + FSM_MIXW - 1) / FSM_MIXW; // units per mixing wave
-constexpr int FSM_LDS_BYTES = 2 * FSM_CPW * FSM_PITCH * 4;    // two phase buffers
+constexpr int FSM_LDS_BYTES = 2 * FSM_CPW * FSM_PITCH * 4 + NCO_TAB_FLOATS * 4; // two phase buffers + the NCO's sine table
 
 struct FsMixParams {
     int nchan;
@@ -330,6 +331,7 @@ struct FsMixParams {
     float* phase;                                // [nchan] NCO phase (d_phase)
     int nvec;
     float binsize, sensitivity;
+    const float* sintab;                         // gr::fxpt's sine table (NCO_TAB_FLOATS floats)
 };
 
 template <class Ctx>
@@ -339,6 +341,12 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
     const int wave = t >> 6, l = t & 63;
     const int cbase = cx.bx() * FSM_CPW;
     float* PH = (float*)cx.lds(); // [2][FSM_CPW][FSM_PITCH]
+    float* ST = PH + 2 * FSM_CPW * FSM_PITCH; // the NCO's sine table (first used behind the first barrier)
+    {
+        typedef float f4 __attribute__((vector_size(16)));
+        for (int i = t; i < NCO_TAB_FLOATS / 4; i += FSM_T)
+            ((f4*)ST)[i] = ((const f4*)p.sintab)[i];
+    }
     // wave 0: lane l < FSM_CPW walks channel cbase + l
     const int myc = cbase + l;
     const bool mylive = (wave == 0) && (l < FSM_CPW) && (myc < p.nchan);
@@ -425,7 +433,7 @@ AISX_DI void fs_mix_body(Ctx& cx, const FsMixParams& p)
                     const int h = u / FSM_CPW;
                     if (u < FSM_UNITS && c < p.nchan) {
                         float sn, cs;
-                        det_sincos(src[r * FSM_PITCH + h * 64 + l], &sn, &cs);
+                        nco_sincos(src[r * FSM_PITCH + h * 64 + l], ST, &sn, &cs); // [GR] gr::fxpt::sincos
                         p.out[(long)c * p.out_stride + k0 + h * 64 + l] = cmul_exact(cur[q], mk(cs, sn));
                     }
                 }

@@ -149,44 +149,44 @@ float orc_branchless_clip(float x, float clip)
 }
 
 /* ------------------------------------------------------------------ */
-/* Deterministic sin/cos used for the NCO (stands in for GNU Radio     */
-/* 3.8's fixed-point gr::fxpt::sincos, which is a table look-up that   */
-/* cannot be reproduced here).  Plain IEEE double +,*: the HIP kernel  */
-/* runs the identical sequence, so both sides are bit-identical.       */
+/* [GR] gr::fxpt (gnuradio-runtime include/gnuradio/fxpt.h, 3.7 / 3.8): */
+/* the fixed-point sin/cos GNU Radio's NCOs and frequency_modulator_fc   */
+/* use.  32-bit angle (2^31 = pi), the top 10 bits pick a {slope, offset}*/
+/* pair of s_sine_table, the line is evaluated at ux >> 1 in float.      */
+/* The table is regenerated by tools/gen_tables.py from the recipe of    */
+/* upstream's gen_sine_table.py (orc_tables.h); its first entry equals   */
+/* upstream's first line digit for digit.                                */
 /* ------------------------------------------------------------------ */
-void orc_det_sincos(float phase, float *s, float *c)
+int32_t orc_fxpt_float_to_fixed(float x)
 {
-    const double TWO_OVER_PI = 0.63661977236758134308;
-    const double PIO2_HI = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
-    const double PIO2_LO = 6.07710050650619224932e-11; /* pi/2 - PIO2_HI */
-    double x = (double)phase;
-    double kd = rint(x * TWO_OVER_PI);
-    int k = (int)kd;
-    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
-    double r2 = r * r;
-    /* Taylor/minimax-ish polynomials, |r| <= pi/4: error < 1e-13 */
-    double ps = -2.5052108385441718775e-08; /* -1/11! */
-    ps = ps * r2 + 2.7557319223985890653e-06;  /* 1/9! */
-    ps = ps * r2 + -1.9841269841269841270e-04; /* -1/7! */
-    ps = ps * r2 + 8.3333333333333332177e-03;  /* 1/5! */
-    ps = ps * r2 + -1.6666666666666665741e-01; /* -1/3! */
-    double sn = r + r * (r2 * ps);
-    double pc = 2.0876756987868098979e-09; /* 1/12! */
-    pc = pc * r2 + -2.7557319223985888276e-07; /* -1/10! */
-    pc = pc * r2 + 2.4801587301587301566e-05;  /* 1/8! */
-    pc = pc * r2 + -1.3888888888888889419e-03; /* -1/6! */
-    pc = pc * r2 + 4.1666666666666664354e-02;  /* 1/4! */
-    pc = pc * r2 + -0.5;
-    double cs = 1.0 + r2 * pc;
-    double so, co;
-    switch (k & 3) {
-    case 0: so = sn; co = cs; break;
-    case 1: so = cs; co = -sn; break;
-    case 2: so = -sn; co = -cs; break;
-    default: so = -cs; co = sn; break;
-    }
-    *s = (float)so;
-    *c = (float)co;
+    const float PI = 3.14159265358979323846f, TAU = 2.0f * 3.14159265358979323846f, TWO_TO_THE_31 = 2147483648.0f;
+    /* Fold x into -PI to PI. */
+    int d = (int)floor(x / TAU + 0.5);
+    x -= d * TAU;
+    /* And convert to an integer. */
+    return (int32_t)((float)x * TWO_TO_THE_31 / PI);
+}
+
+void orc_fxpt_float_to_fixed_n(const float *x, int32_t *out, long n)
+{
+    for (long i = 0; i < n; i++) out[i] = orc_fxpt_float_to_fixed(x[i]);
+}
+
+void orc_fxpt_sincos(int32_t x, float *s, float *c)
+{
+    uint32_t ux = (uint32_t)x;
+    int sin_index = ux >> (32 - 10);
+    *s = orc_sine_table[sin_index][0] * (ux >> 1) + orc_sine_table[sin_index][1];
+    ux = (uint32_t)x + 0x40000000u;
+    int cos_index = ux >> (32 - 10);
+    *c = orc_sine_table[cos_index][0] * (ux >> 1) + orc_sine_table[cos_index][1];
+}
+
+/* frequency_modulator_fc's sin/cos of d_phase ([GR] frequency_modulator_fc_impl.cc:
+ * angle = gr::fxpt::float_to_fixed(d_phase); gr::fxpt::sincos(angle, &oq, &oi)) */
+void orc_nco_sincos(float phase, float *s, float *c)
+{
+    orc_fxpt_sincos(orc_fxpt_float_to_fixed(phase), s, c);
 }
 
 /* ------------------------------------------------------------------ */
@@ -599,7 +599,7 @@ int orc_freqsync_process(orc_freqsync *h, const orc_cf *in, int n, orc_cf *out, 
             const float F_PI = (float)M_PI;
             h->phase = fmodf(h->phase + F_PI, 2.0f * F_PI) - F_PI;
             float s, c;
-            orc_det_sincos(h->phase, &s, &c);
+            orc_nco_sincos(h->phase, &s, &c);
             orc_cf nco = { c, s };
             out[v * F + k] = cmul(x[v * F + k], nco);
         }
@@ -890,7 +890,7 @@ int orc_gmsk_modulate_vector(int sps, double bt, const unsigned char *data, int 
             const float F_PI = (float)M_PI;
             phase = fmodf(phase + F_PI, 2.0f * F_PI) - F_PI;
             float sn, cs;
-            orc_det_sincos(phase, &sn, &cs);
+            orc_nco_sincos(phase, &sn, &cs);
             out[o].re = cs;
             out[o].im = sn;
             o++;

@@ -39,7 +39,11 @@ typedef struct {
 float orc_fast_atan2f(float y, float x);
 orc_cf orc_mmse_interpolate(const orc_cf *in, float mu, int *err);
 float orc_branchless_clip(float x, float clip);
-void orc_det_sincos(float phase, float *s, float *c);
+/* [GR] gr::fxpt (fxpt.h): float_to_fixed, sincos; and the two as frequency_modulator_fc uses them */
+int32_t orc_fxpt_float_to_fixed(float x);
+void orc_fxpt_float_to_fixed_n(const float *x, int32_t *out, long n);
+void orc_fxpt_sincos(int32_t x, float *s, float *c);
+void orc_nco_sincos(float phase, float *s, float *c);
 void orc_fft(orc_cf *buf, int n, int inverse); /* in place, unnormalised */
 
 /* ---- corr_est_cc (lib/corr_est_cc_impl.cc) ---- */

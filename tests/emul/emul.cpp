@@ -509,6 +509,10 @@ int emu_pfb_process(void* hv, const cf* in, long in_stride, int n, cf* out, long
     return p.nframes;
 }
 float emu_fast_atan2f(float y, float x) { return fast_atan2f_tab(y, x, aisx_atan_table); }
+void emu_fxpt_float_to_fixed_n(const float* x, int* out, long n)
+{
+    for (long i = 0; i < n; i++) out[i] = fxpt_float_to_fixed(x[i]);
+}
 const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
 const float* emu_atan_table() { return aisx_atan_table; }
 
@@ -535,7 +539,7 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
-    p.phases = nullptr; p.phases_stride = 0; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
+    p.phases = nullptr; p.phases_stride = 0; p.sintab = nullptr; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
     if (agc8_applies(p.W))
         run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else
@@ -589,7 +593,7 @@ int emu_fs_process(void* hv, const cf* in, long in_stride, int n, cf* out, long 
     FsMixParams m;
     m.nchan = h->nchan; m.in = in; m.in_stride = in_stride; m.pend_in = h->pend[h->cur].data(); m.pend_out = h->pend[h->cur ^ 1].data();
     m.npend = h->npend; m.n = n; m.out = out; m.out_stride = out_stride; m.maxpos = h->maxpos.data(); m.maxpos_stride = h->max_vec;
-    m.fhat = fhat; m.fhat_stride = fhat_stride; m.phase = h->phase.data(); m.nvec = nvec; m.binsize = h->binsize; m.sensitivity = h->sens;
+    m.fhat = fhat; m.fhat_stride = fhat_stride; m.phase = h->phase.data(); m.nvec = nvec; m.binsize = h->binsize; m.sensitivity = h->sens; m.sintab = &aisx_sine_table[0][0];
     run_grid((h->nchan + FSM_CPW - 1) / FSM_CPW, 1, FSM_T, FSM_LDS_BYTES, [&](EmuCtx& cx) { fs_mix_body(cx, m); });
     h->npend = h->npend + n - nvec * FS_F;
     h->cur ^= 1;
@@ -619,9 +623,9 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
     p.hist_in = a->hist[a->cur].data(); p.hist_out = a->hist[a->cur ^ 1].data();
     p.n = total; p.W = a->W; p.reference = a->ref; p.floor_env = AGC_FLOOR_DEFAULT;
     p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1;
-    p.phases = phases.data(); p.phases_stride = pstride; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
+    p.phases = phases.data(); p.phases_stride = pstride; p.sintab = &aisx_sine_table[0][0]; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
     p.npend = h->npend; p.n_raw = n;
-    run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
+    run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
     h->npend = h->npend + n - total;
     h->cur ^= 1;
     a->cur ^= 1;

@@ -37,7 +37,9 @@ def lib():
         L.orc_fast_atan2f.argtypes = [f32, f32]
         L.orc_branchless_clip.restype = f32
         L.orc_branchless_clip.argtypes = [f32, f32]
-        L.orc_det_sincos.argtypes = [f32, vp, vp]
+        L.orc_nco_sincos.argtypes = [f32, vp, vp]
+        L.orc_fxpt_float_to_fixed.restype = C.c_int32
+        L.orc_fxpt_float_to_fixed.argtypes = [f32]
         L.orc_fft.argtypes = [vp, i32, i32]
         L.orc_corr_create.restype = vp
         L.orc_corr_create.argtypes = [vp, i32, f32, u32, f32]
@@ -116,10 +118,11 @@ def fast_atan2f(y, x):
     return float(lib().orc_fast_atan2f(y, x))
 
 
-def det_sincos(phase):
+def nco_sincos(phase):
+    """[GR] frequency_modulator_fc's sin / cos of d_phase (gr::fxpt)"""
     s = C.c_float()
     c = C.c_float()
-    lib().orc_det_sincos(phase, C.byref(s), C.byref(c))
+    lib().orc_nco_sincos(phase, C.byref(s), C.byref(c))
     return s.value, c.value
 
 

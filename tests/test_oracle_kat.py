@@ -5,6 +5,8 @@ answers are the control-flow observations the survey recorded from the
 reference's own block sources.  Everything here runs on
 the CPU (-m "not gpu").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -148,11 +150,47 @@ def test_fast_atan2f_accuracy():
     assert abs(orc.fast_atan2f(1.0, 0.0) - np.pi / 2) < 1e-6
 
 
-def test_det_sincos_accuracy():
-    for ph in np.linspace(-9.5, 3.2, 4001):
-        s, c = orc.det_sincos(float(np.float32(ph)))
-        assert abs(s - np.sin(np.float64(np.float32(ph)))) < 1.2e-7
-        assert abs(c - np.cos(np.float64(np.float32(ph)))) < 1.2e-7
+def test_fxpt_nco_sincos():
+    # [GR] gr::fxpt: a 1024-segment piecewise-linear sine on a 32-bit angle; the table's recipe
+    # (tools/gen_tables.py) reproduces the line upstream's sine_table.h opens with
+    txt = open(os.path.join(os.path.dirname(__file__), "..", "oracle", "orc_tables.h")).read()
+    assert "{  2.925817799165007e-09f,  7.219194364267018e-09f }," in txt
+    worst = 0.0
+    for ph in np.linspace(-3.1415925, 3.1415925, 20001):
+        p = np.float32(ph)
+        s, c = orc.nco_sincos(float(p))
+        worst = max(worst, abs(s - np.sin(np.float64(p))), abs(c - np.cos(np.float64(p))))
+    assert worst < 3.0e-6  # (chord error of a 2 pi / 1024 segment, halved by the offset: 2.4e-6)
+    assert orc.lib().orc_fxpt_float_to_fixed(0.0) == 0
+    assert orc.lib().orc_fxpt_float_to_fixed(float(np.float32(-np.pi))) == -2 ** 31
+    assert orc.lib().orc_fxpt_float_to_fixed(float(np.float32(np.pi / 2))) == 2 ** 30
+    assert orc.nco_sincos(0.0) == (float(np.float32(7.219194364267018e-09)), orc.nco_sincos(0.0)[1])
+    assert abs(orc.nco_sincos(0.0)[1] - 1.0) < 3e-6
+
+
+def test_division_by_pi_is_exact():
+    # the kernels form float_to_fixed's x * 2^31 / PI without an IEEE division (aisx_common.h:
+    # q = y * R, r = fma(-q, PI, y), q + r * R).  Every float in 1e-30 .. 1e30 was checked once
+    # against the division; this keeps a dense sample: 2^21 consecutive floats up to PI, the
+    # neighbourhoods of the fold, and phases far outside -PI .. PI
+    import ctypes as C
+
+    import emul_py as emu
+
+    top = np.float32(np.pi).view(np.uint32)
+    x = (top - np.arange(1 << 21, dtype=np.uint32)).view(np.float32)
+    rng = np.random.default_rng(77)
+    x = np.concatenate([x, -x, rng.uniform(-np.pi, np.pi, 1 << 20).astype(np.float32),
+                        rng.normal(scale=40.0, size=1 << 16).astype(np.float32),
+                        (rng.uniform(-1, 1, 1 << 16) * 10.0 ** rng.uniform(-30, 0, 1 << 16)).astype(np.float32),
+                        np.array([0.0, -0.0, np.pi, -np.pi, 2 * np.pi, 1e-38, -1e-38], np.float32)])
+    x = np.ascontiguousarray(x)
+    a = np.zeros(x.size, np.int32)
+    b = np.zeros(x.size, np.int32)
+    vp = C.c_void_p
+    emu.lib().emu_fxpt_float_to_fixed_n(vp(x.ctypes.data), vp(a.ctypes.data), C.c_long(x.size))
+    orc.lib().orc_fxpt_float_to_fixed_n(vp(x.ctypes.data), vp(b.ctypes.data), C.c_long(x.size))
+    assert np.array_equal(a, b)
 
 
 def test_gmsk_template_shape():
