@@ -486,10 +486,11 @@ def main():
         barrier()
         # the same kernel with the chip to itself (no timing-recovery kernel alongside)
         iso = []
-        for _ in range(3):
+        for _ in range(7):
             with torch.cuda.stream(s_main):
                 corr.work(x if not stock else y_corr[0], out=y_corr[1])
             iso.append(corr.last_kernel_ms())
+        iso = sorted(iso)[1:-1]  # (drop the fastest and the slowest of seven)
         torch.cuda.synchronize()
         res["el"] = max_over_ranks(el, device=device)
         res["iso"] = iso

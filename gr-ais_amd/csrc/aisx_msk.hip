@@ -398,6 +398,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.lds_wave_stride = msk_lds_wave(h->lpw);
     p.tq_stride = h->lpw;
     p.tq_private = 0;
+    p.lds_ring_off = msk_lds_ringoff(h->lpw);
     p.inline_tags = h->inline_tags;
 }
 
@@ -510,6 +511,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     p.err = d_err;
     p.mu_out = d_mu;
     p.out_stride = out_stride;
+    p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
     p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
     p.produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
     if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), (hipStream_t)stream)) != AISX_OK)
@@ -645,6 +647,7 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     p.err = h->d_st_err;
     p.mu_out = h->d_st_mu;
     p.out_stride = noutput_items;
+    p.sym_al16 = ((uintptr_t)h->d_st_sym % 16 == 0) && (noutput_items % 2 == 0);
     p.out_cap = noutput_items;
     p.produced = h->d_produced;
     if ((rc = msk_launch(p, 1, 0)) != AISX_OK)

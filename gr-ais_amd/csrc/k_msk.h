@@ -72,9 +72,24 @@ constexpr int MSK_TAGQ = 36;       // time_est tags queued per lane
 #endif
 constexpr int msk_waves(int lpw) { return lpw >= 16 ? 64 / lpw : (lpw == 4 ? MSK_WAVES_LPW4 : 4); }
 constexpr int msk_wg_channels(int lpw) { return msk_waves(lpw) * lpw; }
-constexpr int msk_lds_wave(int lpw) { return msk_lds_ring(lpw) + MSK_TAGQ * lpw * 8; }
-constexpr int msk_lds_taboff(int lpw) { return msk_waves(lpw) * msk_lds_wave(lpw); }
+// Symbols are staged in LDS and leave in 16-byte stores, 2 * (64 / lpw) symbols of a channel at a
+// time: MSK_STAGE slots per channel, [slot][lpw] like the rings, all waves' stages at the very
+// start of the workgroup's LDS (each aligned to its size: a slot address is one v_and_or).  A
+// run of the loop adds at most MSK_PAIRS_MAX + 1 symbols to fewer than 16 left by the flush.
+constexpr int MSK_STAGE = 32;
+static_assert(MSK_STAGE >= 15 + MSK_PAIRS_MAX + 1, "a lock-step run and a general step between two flushes");
+// (builds with 16 or more channels per wave fill the LDS with rings: they store symbol by symbol)
+constexpr bool msk_staged(int lpw) { return lpw <= 8; }
+constexpr int msk_lds_stage(int lpw) { return msk_staged(lpw) ? MSK_STAGE * lpw * 8 : 0; }
+constexpr int msk_lds_ringoff(int lpw) { return msk_waves(lpw) * msk_lds_stage(lpw); } // first wave's rings
+// a wave's region: rings, tag queue, one spare slot row (where the lanes that run odd iterations "stage")
+constexpr int msk_lds_wave(int lpw) { return msk_lds_ring(lpw) + MSK_TAGQ * lpw * 8 + lpw * 8; }
+constexpr int msk_lds_taboff(int lpw) { return msk_lds_ringoff(lpw) + msk_waves(lpw) * msk_lds_wave(lpw); }
 constexpr int msk_lds_bytes(int lpw) { return msk_lds_taboff(lpw) + MSK_LDS_MMSE; }
+static_assert(msk_lds_bytes(4) <= 160 * 1024 && msk_lds_bytes(8) <= 160 * 1024 && msk_lds_bytes(16) <= 160 * 1024 &&
+              msk_lds_bytes(32) <= 160 * 1024 && msk_lds_bytes(64) <= 160 * 1024, "a workgroup's LDS");
+// (8 channels per wave: 92160 bytes, which leaves room for one 71680-byte workgroup of the correlator on the same CU)
+static_assert(msk_lds_bytes(8) + 71680 <= 160 * 1024, "timing recovery + one correlator workgroup per CU");
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
@@ -114,6 +129,8 @@ struct MskParams {
     // stride msk_lds_wave(lpw), lpw, 0); the CPU lane model, whose lanes are free-running
     // threads, gives each lane its own (stride msk_lds_ring(lpw) + MSK_TAGQ * 64 * 8, 64, 1).
     int lds_wave_stride, tq_stride, tq_private;
+    int lds_ring_off;  // = msk_lds_ringoff(lpw): the waves' regions start behind the symbol stages
+    int sym_al16;      // every output row starts 16-byte aligned (syms pointer and out_stride both even in items)
     int lpw;           // channels per wave, = the build's LPW: 4, 8, 16, 32 or 64
     int inline_tags;   // tag resets inside the lock-step runs (0: every tag through the general steps)
 };
@@ -168,7 +185,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     const int cc = live ? c : (p.nchan - 1); // dead lanes mirror the last channel read-only
 
     char* const lds0 = cx.lds();
-    char* const lds = lds0 + wv * p.lds_wave_stride; // this wave's rings [MSK_SLOTS][LPW] and tag queue
+    char* const lds = lds0 + p.lds_ring_off + wv * p.lds_wave_stride; // this wave's rings [MSK_SLOTS][LPW] and tag queue
     cf* ring = (cf*)lds;
     // [130][MSK_TAPS_PITCH], one per workgroup, behind the waves' regions; the offset comes in
     // as a kernel argument so that it sits in a scalar register and a row address is one
@@ -280,6 +297,57 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     char* const oerr0 = AUX && p.err ? (char*)(p.err + (long)cbase * p.out_stride) : nullptr;
     char* const omu0 = AUX && p.mu_out ? (char*)(p.mu_out + (long)cbase * p.out_stride) : nullptr;
     unsigned ob = (unsigned)((long)(cc - cbase) * p.out_stride) * 8u; // byte offset of the next symbol
+    // ---- symbol stage (osps == 1, err / mu ports open, at most 8 channels per wave).  A global store per symbol costs the
+    // recurrence more than its issue slots: the chunk fetch is awaited with s_waitcnt vmcnt(0),
+    // which also waits for the store issued a moment ago.  Symbols go to LDS instead (slot =
+    // symbol number mod MSK_STAGE) and leave FL at a time, each of the channel's lanes (up to eight)
+    // storing two: whole 128-byte lines per channel, issued right after a chunk landed and
+    // complete long before the next wait.
+    constexpr bool STG = !AUX && !OSPS2 && msk_staged(LPW);
+    constexpr unsigned FLQ = NQ < 8 ? NQ : 8;                     // lanes of a channel that store (two symbols each)
+    constexpr unsigned FL = 2 * FLQ;                              // symbols per flush of a channel
+    constexpr unsigned STG_MASK = (unsigned)((MSK_STAGE - 1) * SLOT_B);
+    const unsigned obrow = ob;                                    // byte offset of the channel's output row
+    const unsigned stg_real = (unsigned)(wv * msk_lds_stage(LPW) + l * 8);   // LDS byte offset of slot 0
+    const unsigned stg_spare = (unsigned)(p.lds_ring_off + wv * p.lds_wave_stride + p.lds_wave_stride - SLOT_B + l * 8);
+    unsigned so = 0;  // SLOT_B * (symbols of this call so far)
+    unsigned nf = 0;  // symbols of this call already in the output row
+    struct alignas(8) cf8s { float re, im; };
+    auto stage_put = [&](unsigned mask, unsigned base, cf v) {
+        cf8s t;
+        t.re = v.re;
+        t.im = v.im;
+        *(cf8s*)(lds0 + ((so & mask) | base)) = t;
+        so += (unsigned)SLOT_B;
+    };
+    auto stage_get = [&](unsigned k) -> cf {
+        const cf8s t = *(const cf8s*)(lds0 + ((((k & (unsigned)(MSK_STAGE - 1)) << SLOT_SH)) | stg_real));
+        return mk(t.re, t.im);
+    };
+    auto flush_syms = [&]() {
+        if constexpr (STG) {
+            if (cx.ballot((so >> SLOT_SH) - nf >= FL) == 0ull)
+                return;
+            cx.wave_sync(); // (lane model: the symbols the channel's other lanes staged are in place)
+            while (cx.ballot((so >> SLOT_SH) - nf >= FL) != 0ull) {
+                if ((so >> SLOT_SH) - nf >= FL) {
+                    const unsigned k0 = nf + 2u * (unsigned)q;
+                    if (NQ <= 8 || (unsigned)q < FLQ) {
+                        const cf a = stage_get(k0), b = stage_get(k0 + 1u);
+                        cf* dst = (cf*)(osym0 + obrow) + k0;
+                        if (p.sym_al16) {
+                            st16(dst, a, b);
+                        } else {
+                            st8(dst, a);
+                            st8(dst + 1, b);
+                        }
+                    }
+                    nf += FL;
+                }
+            }
+            cx.wave_sync(); // (lane model: read before the slots are staged again)
+        }
+    };
 
     // ---- "scheduler": one general_work() call after another (stream mode) ----
     int base = 0, ototal = 0;     // items consumed / produced by finished calls
@@ -505,7 +573,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             d_mu += p.gain * err_out;
         }
         if (!PAR || OSPS2) { // :186-191
-            *(cf*)(osym0 + ob) = in_interp;
+            if constexpr (STG)
+                stage_put(STG_MASK, stg_real, in_interp);
+            else
+                *(cf*)(osym0 + ob) = in_interp;
             if (AUX) {
                 if (oerr0)
                     *(float*)(oerr0 + (ob >> 1)) = err_out;
@@ -597,6 +668,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     rearm();
     // ------------- the recurrence: every lane goes as far as its data allows -------------
     for (;;) {
+        flush_syms(); // (right behind a landed chunk: the stores are done when the next one is awaited)
         // lock step: nobody parked, every lane about to run an even iteration, none at its
         // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
         // their own (so that the values the loop carries stay in place)
@@ -659,6 +731,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 }
                 if (ntrips > 0) {
                     const bool roleO = (cx.tid() & ROW) != 0;
+                    const unsigned pmask = roleO ? 0u : STG_MASK, pbase = roleO ? stg_spare : stg_real;
                     cf sqO = prev_sq, sqE = mk(0.f, 0.f), acc = last_interp;
                     float nl_prev = d_dly_diff_1.re;
                     bool last_skip = false;
@@ -717,9 +790,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                         float om2 = d_omega + p.gain_omega * err;
                         om2 = d_sps + branchless_clip(om2 - d_sps, p.limit);
                         const float mu2 = muO + p.gain * err;
-                        if (!roleO)
-                            *(cf*)(osym0 + ob) = acc;                                  // :186-191 (even iterations only)
-                        ob += 8u;
+                        if constexpr (STG) {                                           // :186-191 (even iterations only)
+                            stage_put(pmask, pbase, acc);
+                        } else {
+                            if (!roleO)
+                                *(cf*)(osym0 + ob) = acc;
+                            ob += 8u;
+                        }
                         const float m2 = mu2 + om2;                                    // > 0 (lock_ok)
                         const int adv2 = (int)m2;
                         d_mu = skipO ? muO : cx.fract(m2);
@@ -763,6 +840,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 // computed by both lanes alike.  (With LPW <= 16 the other copies of a channel do the same once more.)
                 constexpr int ROW = LPW <= 16 ? 16 : 32; // lane i and lane i ^ ROW carry the same channel
                 const bool roleO = (cx.tid() & ROW) != 0;
+                // (the lanes running odd iterations stage theirs in the spare row: no exec masking)
+                const unsigned pmask = roleO ? 0u : STG_MASK, pbase = roleO ? stg_spare : stg_real;
                 cf sqO = prev_sq, sqE = mk(0.f, 0.f), acc = last_interp;
                 float nl_prev = d_dly_diff_1.re;
                 const int sb_entry = sb;
@@ -796,6 +875,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                                 *(float*)(omu0 + (o >> 1)) = roleO ? mu2 : d_mu;
                         }
                         ob += 16u;
+                    } else if constexpr (STG) {
+                        stage_put(pmask, pbase, acc);
                     } else {
                         if (!roleO) {
                             *(cf*)(osym0 + ob) = acc;
@@ -849,7 +930,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                     const cf accE = fir_sum(svE, tvE);
                     const cf sE = cmul_exact(accE, accE);                          // :171
                     const float nlE = sE.re * sqO.re + sE.im * sqO.im;             // :173-174, real part
-                    *(cf*)(osym0 + ob) = accE;                                     // :186-191
+                    if constexpr (STG)                                             // :186-191
+                        stage_put(STG_MASK, stg_real, accE);
+                    else
+                        *(cf*)(osym0 + ob) = accE;
                     if (AUX) {
                         if (oerr0)
                             *(float*)(oerr0 + (ob >> 1)) = nlE - nl_prev;
@@ -949,6 +1033,16 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         printf("msk prof: total %lld lock %lld (failed entries %lld: %lld) land %lld gen %lld | pairs %lld runs %lld genpasses %lld events %lld\n", pf_t1 - pf_t0, pf_lock, pf_nfail, pf_fail, pf_land, pf_gen, pf_n[0], pf_n[1], pf_n[2], pf_n[3]);
     }
 #endif
+    if constexpr (STG) { // what is left in the stage: fewer than FL symbols per channel, 8-byte stores
+        flush_syms();
+        const unsigned left = (so >> SLOT_SH) - nf;
+#pragma unroll
+        for (unsigned j = 0; j < 2; j++) {
+            const unsigned k = (unsigned)q + j * FLQ;
+            if ((unsigned)q < FLQ && k < left)
+                st8((cf*)(osym0 + obrow) + nf + k, stage_get(nf + k));
+        }
+    }
     if (!live || !owner)
         return;
     if (worst_imu >= (unsigned)MSK_ZERO_ROW)

@@ -389,11 +389,12 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.mmse = &aisx_mmse_taps[0][0];
     // free-running lanes: every lane gets a tag-queue column of its own (see MskParams)
     p.lpw = h->lpw;
-    p.lds_wave_stride = msk_lds_ring(h->lpw) + MSK_TAGQ * 64 * 8;
+    p.lds_wave_stride = msk_lds_ring(h->lpw) + MSK_TAGQ * 64 * 8 + h->lpw * 8;
+    p.lds_ring_off = msk_lds_ringoff(h->lpw);
     p.tq_stride = 64;
     p.tq_private = 1;
     p.inline_tags = getenv("AISX_MSK_INLINE_TAGS") ? atoi(getenv("AISX_MSK_INLINE_TAGS")) : 1;
-    p.lds_tab_off = msk_waves(h->lpw) * p.lds_wave_stride;
+    p.lds_tab_off = p.lds_ring_off + msk_waves(h->lpw) * p.lds_wave_stride;
 }
 
 static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap)
@@ -437,6 +438,7 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
         syms = h->symscratch.data();
     }
     p.syms = syms; p.err = err; p.mu_out = mu; p.out_stride = out_stride; p.out_cap = (int)out_stride;
+    p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
     p.produced = produced;
     emu_msk(&p);
     h->cur ^= 1;
@@ -464,6 +466,7 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
     emu_msk_fill(h, p);
     p.in = in; p.in_stride = ninput + 1; p.n = ninput; p.stream_mode = 0; p.gr_ninput = ninput; p.gr_noutput = noutput;
     p.syms = out; p.err = err; p.mu_out = mu; p.out_stride = noutput; p.out_cap = noutput;
+    p.sym_al16 = ((uintptr_t)out % 16 == 0) && (noutput % 2 == 0);
     p.produced = h->produced.data();
     emu_msk(&p);
     h->cur ^= 1;

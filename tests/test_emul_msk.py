@@ -202,7 +202,8 @@ def test_emul_msk_tag_resets_inside_the_lock_step(sps, lpw):
             tg[c, : len(sel)] = sel
             cnt[c] = len(sel)
             new.append(sel)
-        r = e.step(chunk, tg, cnt, want_aux=False)
+        # (sps 5.0: output rows of odd length -- the symbol stage then leaves in 8-byte stores)
+        r = e.step(chunk, tg, cnt, want_aux=False, out_cap=((L // 2 + 301) | 1) if sps == 5.0 else None)
         assert r["status"] == 0
         for c in range(nchan):
             ot = np.zeros(len(new[c]), dtype=orc.TAG_DTYPE)
