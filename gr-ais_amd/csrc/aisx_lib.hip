@@ -380,6 +380,15 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     const bool dma = h->dma && h->F == CF4_F;
     int nseg, tps;
     corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, dma ? 2 : 0);
+    static const int force_nseg = [] { // (experiments: segments per channel, AISX_CORR_NSEG)
+        const char* e = getenv("AISX_CORR_NSEG");
+        return e ? atoi(e) : 0;
+    }();
+    if (force_nseg > 0) {
+        const int ntiles = (n + h->L - 1) / h->L;
+        tps = (ntiles + force_nseg - 1) / force_nseg;
+        nseg = (ntiles + tps - 1) / tps;
+    }
 
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;

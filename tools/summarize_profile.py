@@ -24,7 +24,7 @@ def short(name):
 
 
 def timed_stats(trace_csv, steps, warmup):
-    """The default bench run = (warmup + steps) steps of the stock chain, 3 isolated correlator
+    """The default bench run = (warmup + steps) steps of the stock chain, 7 isolated correlator
     launches, then the same for the corr_est -> msk chain.  Stock-chain kernels are identified by
     position: launches warmup .. warmup+steps of each stock-only kernel; the correlator's timed
     launches are those that run while a k_fs_est of a timed step precedes them."""
@@ -76,14 +76,15 @@ if __name__ == "__main__":
           "`roofline.kernel_ms` %.3f (hipEvents over the timed region), `kernel_ms_alone` %.3f."
           % (tag, line["value"], line["ms_per_step"], line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms_alone"]), "",
           "Per kernel, the %d TIMED launches of the whole-flowgraph chain only (the run also holds %d warm-up steps, "
-          "3 isolated correlator launches and the corr_est -> msk-only chain; rocprofv3's own `--stats` table over "
+          "7 isolated correlator launches and the corr_est -> msk-only chain; rocprofv3's own `--stats` table over "
           "ALL launches is in `%s_default_bench_kernel_stats.csv`):" % (line["steps"], line["warmup"], tag), "",
           "| kernel | timed launches | avg ms | min ms | max ms | launches in the whole run |", "|---|---|---|---|---|---|"]
     for k, v in sorted(st.items(), key=lambda kv: -kv[1]["avg"]):
         md.append("| %s | %d | %.3f | %.3f | %.3f | %d |" % (k[:48], v["n"], v["avg"], v["mn"], v["mx"], v["calls"]))
     kname = line["roofline"]["kernel"]
-    if kname in st:
-        md += ["", "`%s`: %.3f ms here against `roofline.kernel_ms` = %.3f ms in the bench line." % (
-            kname, st[kname]["avg"], line["roofline"]["kernel_ms"])]
+    for k in st:
+        if k == kname or k.startswith(kname + "<"):
+            md += ["", "`%s`: %.3f ms here against `roofline.kernel_ms` = %.3f ms in the bench line." % (
+                k, st[k]["avg"], line["roofline"]["kernel_ms"])]
     open("profiles/%s_default_bench_kernel_stats.md" % tag, "w").write("\n".join(md) + "\n")
     print("\n".join(md))
