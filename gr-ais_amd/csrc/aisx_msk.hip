@@ -131,12 +131,17 @@ static int msk_check_geometry(float d_sps, float gain, float limit)
     }
     return AISX_OK;
 }
-// items per channel one call can produce at most: every output consumes at least
-// 2 (d_sps - |limit|) input items (osps = 1; half of that for osps = 2)
+// items per channel one call can produce: without tags every output consumes at least
+// 2 (d_sps - |limit|) input items (osps = 1; half of that for osps = 2).  A time_est tag sets
+// d_div = 0 (:159): the iteration it resets emits a symbol whatever came before, and it may step
+// iidx back by one (:151-154) -- up to two more outputs per tag.  Room for max_items / 64 tags
+// per call is added (the stock chain produces one per ~600 samples; a burst gives 3-4 on
+// consecutive pairs); a call that needs more ends with AISX_MSK_ST_OUT_FULL.
 static int msk_out_cap(const aisx_msk* h)
 {
     const double wmin = (double)h->d_sps - fabs((double)h->limit);
-    return (int)ceil((h->max_items + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16;
+    const int tag_room = 2 * std::max(16, h->max_items / 64);
+    return ((int)ceil((h->max_items + aisx_msk::carry_cap) / (2.0 * wmin)) + tag_room) * h->osps + 16;
 }
 
 static int msk_init_state(aisx_msk* h)
@@ -196,7 +201,7 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     h->gain_omega = msk_setup(sps, gain).gain_omega; // :83
     h->out_cap = msk_out_cap(h);
     {
-        // 8 channels per wave, four waves (one per SIMD), 32 channels and ~84 KB of LDS per
+        // 8 channels per wave, four waves (one per SIMD), 32 channels and 90 KB of LDS per
         // workgroup: fewer lanes per wave = fewer events of other lanes to wait for (a tag costs
         // the whole wave a general pass), and half of each CU's LDS stays free for the stages
         // that run beside this kernel on the other stream.  Measured on the whole flowgraph:

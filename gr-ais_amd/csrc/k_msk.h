@@ -469,7 +469,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         if (!(oidx < noutput && iidx < ninp)) { // this general_work() call is over (:138)
             base += iidx;                       // consume_each(iidx)
             ototal += oidx;
-            const bool progress = (iidx > 0) || (oidx > 0);
+            // (a call that consumed nothing ends the step whatever it produced: with sps < 4 a tag
+            // with a negative centre right at nitems_read can emit a symbol and leave iidx at 0
+            // when one output fits -- called again with the same items it would do so for ever)
+            const bool progress = iidx > 0;
             if (!p.stream_mode || !progress)
                 done = true;
             else

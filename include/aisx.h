@@ -145,7 +145,11 @@ int aisx_msk_set_sps(aisx_msk* h, float sps);     /* :69-74 (d_sps = sps/2, omeg
  * after set_sps / set_limit ask aisx_msk_out_capacity() again. */
 float aisx_msk_get_sps(const aisx_msk* h);        /* :76-78 returns d_sps */
 int aisx_msk_forecast(const aisx_msk* h, int noutput_items); /* :98-105 */
-int aisx_msk_out_capacity(const aisx_msk* h);     /* items per channel the output arrays must hold */
+/* items per channel the output arrays must hold: ceil((max_items + 128) / (2 (sps/2 - |limit|)))
+ * outputs a call can produce without tags, plus room for the extra outputs of max_items / 64
+ * time_est tags (each reset restarts the even/odd cadence, :159), times osps.  A call that would
+ * need more stops there and reports AISX_MSK_ST_OUT_FULL. */
+int aisx_msk_out_capacity(const aisx_msk* h);
 int aisx_msk_reset(aisx_msk* h);
 
 /* One general_work() call per channel under the stream contract:

@@ -1082,7 +1082,11 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
             memcpy(syms_out + nbits, syms, sizeof(orc_cf) * prod);
         nbits += prod;
         free(syms);
-        if (consumed <= 0 && prod == 0)
+        /* a call that consumed nothing ends the step, whatever it produced: at sps < 4 a tag
+         * with a negative centre right at nitems_read (iidx - 1, :151-154) can emit a symbol and
+         * leave iidx at 0 when only one output fits; called again with the same items it would
+         * do so for ever.  (A live scheduler comes back with more input instead.) */
+        if (consumed <= 0)
             break;
     }
     free(newtags);

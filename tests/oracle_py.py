@@ -325,7 +325,7 @@ class MskStream:
             o2s.append(o2)
             o3s.append(o3)
             total += cons
-            if cons <= 0 and len(out) == 0:
+            if cons <= 0:  # (nothing consumed: the step ends, see orc_demod_step)
                 break
         if not outs:
             return np.zeros(0, np.complex64), np.zeros(0, np.float32), np.zeros(0, np.float32), 0

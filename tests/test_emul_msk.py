@@ -177,7 +177,7 @@ def _burst_like_tags(rng, total, chan, nclusters=12):
     return tags
 
 
-@pytest.mark.parametrize("sps,lpw", [(4.0, 8), (4.0, 4), (4.0, 16), (5.2083, 32), (5.0, 8), (4.0, 64), (4.4, 8)])
+@pytest.mark.parametrize("sps,lpw", [(4.0, 8), (4.0, 4), (4.0, 16), (5.2083, 32), (5.0, 8), (4.0, 64), (4.4, 8), (3.0, 8)])
 def test_emul_msk_tag_resets_inside_the_lock_step(sps, lpw):
     # osps = 1, err / mu ports not connected: the build whose lock-step runs handle time_est tags in
     # line (tag before the even iteration, tag before the odd one, clusters on consecutive pairs,
@@ -202,8 +202,9 @@ def test_emul_msk_tag_resets_inside_the_lock_step(sps, lpw):
             tg[c, : len(sel)] = sel
             cnt[c] = len(sel)
             new.append(sel)
-        # (sps 5.0: output rows of odd length -- the symbol stage then leaves in 8-byte stores)
-        r = e.step(chunk, tg, cnt, want_aux=False, out_cap=((L // 2 + 301) | 1) if sps == 5.0 else None)
+        # (sps 5.0: output rows of odd length -- the symbol stage then leaves in 8-byte stores;
+        # sps 3.0: a tag on every other sample makes every iteration an even one, :159 -- room for that)
+        r = e.step(chunk, tg, cnt, want_aux=False, out_cap={5.0: (L // 2 + 301) | 1, 3.0: L + 300}.get(sps))
         assert r["status"] == 0
         for c in range(nchan):
             ot = np.zeros(len(new[c]), dtype=orc.TAG_DTYPE)

@@ -337,6 +337,47 @@ def test_msk_channels_per_wave_builds(ais, lpw, monkeypatch):
         k += L
 
 
+@pytest.mark.parametrize("sps", [4.0, 3.0])
+def test_msk_bursts_of_tags_symbol_stage(ais, sps):
+    # osps = 1 without err / mu: the build with tag resets inside the lock-step runs and symbols
+    # staged in LDS.  Clusters of time_est tags on consecutive pairs (what a burst gives), NaN and
+    # +-1 values, ragged call lengths; at sps 3 a cluster makes every iteration an even one (:159),
+    # more outputs than samples / sps -- within aisx_msk_out_capacity's room for tags
+    import torch
+    from test_emul_msk import _burst_like_tags, _signal
+
+    rng = np.random.default_rng(int(sps * 10))
+    nchan, lens = 37, [2600, 37, 1800, 1, 900]
+    total = sum(lens)
+    xs = np.stack([_signal(150 + c, total, 4)[0] for c in range(nchan)])
+    blk = ais.msk_timing_recovery_cc(sps, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    o = [orc.MskStream(sps, 0.04, 0.01, 1) for _ in range(nchan)]
+    all_tags = [_burst_like_tags(rng, total, c, nclusters=14 if c % 3 else 40) for c in range(nchan)]
+    k, cap = 0, 256
+    for L in lens:
+        tg = np.zeros((nchan, cap), dtype=ais.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        sels = []
+        for c in range(nchan):
+            sel = all_tags[c][(all_tags[c]["offset"] >= k) & (all_tags[c]["offset"] < k + L)]
+            tg[c, : len(sel)] = sel
+            cnt[c] = len(sel)
+            sels.append(sel)
+        d_tags = torch.as_tensor(tg.view(np.uint8).reshape(nchan, -1).copy()).cuda()
+        d_cnt = torch.as_tensor(cnt).cuda()
+        r = blk.work(_dev(xs[:, k:k + L]), tags_ptrs=(d_tags.data_ptr(), d_cnt.data_ptr(), cap))
+        assert blk.last_status() == 0
+        prod = r["produced"].cpu().numpy()
+        syms = r["syms"].cpu().numpy()
+        for c in range(nchan):
+            ot = np.zeros(len(sels[c]), dtype=orc.TAG_DTYPE)
+            ot["offset"], ot["value"], ot["key"] = sels[c]["offset"], sels[c]["value"], sels[c]["key"]
+            out, _, _, _ = o[c].step(xs[c, k:k + L], ot)
+            assert prod[c] == len(out), (L, c)
+            assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32)), (L, c)
+        k += L
+
+
 def test_msk_bit_tail_on_its_own_stream(ais):
     # aisx_msk_set_tail_stream: same bits, computed on a second stream while the next call runs
     import torch
