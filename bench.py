@@ -405,11 +405,16 @@ def main():
                      produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(NBUF)]
         # (the stream stages' workgroups go first when LDS / wave slots free up: the estimates of the
         # next step, on s_pre, take what is left)
-        hi = -1 if os.environ.get("AISX_BENCH_PRIO", "0") == "1" else 0  # (measured: no gain)
-        s_main, s_msk = torch.cuda.Stream(device=device, priority=hi), torch.cuda.Stream(device=device)
+        prio = os.environ.get("AISX_BENCH_PRIO", "0")  # (experiments: 1 = stream stages first, 2 = timing recovery first)
+        s_main = torch.cuda.Stream(device=device, priority=-1 if prio == "1" else 0)
+        s_msk = torch.cuda.Stream(device=device, priority=-1 if prio == "2" else 0)
         s_tail = torch.cuda.Stream(device=device)  # the bit tail of step k runs beside the recovery of step k+1
-        s_pre = torch.cuda.Stream(device=device)   # frequency estimates + NCO phase walk, one step ahead
+        s_pre = torch.cuda.Stream(device=device)   # NCO phase walk, one step ahead
+        s_est = torch.cuda.Stream(device=device)   # frequency estimates, one step ahead
         fused = stock and not os.environ.get("AISX_BENCH_UNFUSED")
+        wait_prepass = chain != "corr" and os.environ.get("AISX_BENCH_NO_PREPASS_WAIT") is None
+        if wait_prepass:
+            dem.clockrec.wait_prepass(s_main)  # (arms the event)
         dem.clockrec.set_tail_stream(s_tail)
         msk_done = [None] * NBUF
         state = dict(k=0)
@@ -435,11 +440,17 @@ def main():
                     # between the two sample passes (full-grid kernels of different streams take turns
                     # anyway, and side by side they cost the correlator its second workgroup per CU),
                     # the phase walk on s_pre beside the correlator
-                    if os.environ.get("AISX_BENCH_EST_ON_PRE"):
+                    # (measured: kernels with large grids are dispatched one after the other whatever
+                    # their streams, so the estimates gain nothing from a stream of their own)
+                    mode = os.environ.get("AISX_BENCH_EST", "main")
+                    if mode == "pre":      # estimates and walk on s_pre
                         with torch.cuda.stream(s_pre):
                             dem.freq_sync.estimate_ahead(x)
-                    else:
+                    elif mode == "main":   # estimates behind this step's front-end pass, walk on s_pre
                         dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
+                    else:                  # estimates on a stream of their own, walk on s_pre
+                        with torch.cuda.stream(s_est):
+                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
                 o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
                 tags_ptrs = corr.tags_device()
                 ready = torch.cuda.Event()
@@ -451,6 +462,10 @@ def main():
                     ev = torch.cuda.Event()
                     ev.record(s_msk)
                     msk_done[par] = ev
+                if wait_prepass:
+                    # the next step's sample passes start behind this step's tag prepass: the recovery's
+                    # 128 large workgroups are dispatched before thousands of small ones take the LDS
+                    dem.clockrec.wait_prepass(s_main)
             state["k"] = k + 1
 
         for _ in range(args.warmup):

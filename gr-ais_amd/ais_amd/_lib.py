@@ -86,6 +86,7 @@ def lib():
     sig("aisx_msk_last_status", i32, [vp, pi32, vp])
     sig("aisx_msk_set_tail_stream", i32, [vp, vp, i32])
     sig("aisx_msk_wait_tail", i32, [vp, vp])
+    sig("aisx_msk_wait_prepass", i32, [vp, vp])
     sig("aisx_msk_general_work_host", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, i32, pi32, pi32])
     sig("aisx_freqsync_create", i32, [pvp, f64, f64, i32, i32, i32])
     sig("aisx_freqsync_destroy", i32, [vp])

@@ -254,6 +254,12 @@ class msk_timing_recovery_cc:
     def wait_tail(self, stream=None):
         check(_lib.lib().aisx_msk_wait_tail(self._h, _stream_ptr(stream)), "wait_tail")
 
+    def wait_prepass(self, stream=None):
+        """`stream` waits until the last work() call's recovery kernel stands at the head of its queue
+        (aisx_msk_wait_prepass): call it on the stream whose next kernels would otherwise take the
+        LDS the recovery's workgroups need.  The first call only arms the event."""
+        check(_lib.lib().aisx_msk_wait_prepass(self._h, _stream_ptr(stream)), "wait_prepass")
+
     def last_status(self, stream=None):
         st = C.c_int(0)
         check(_lib.lib().aisx_msk_last_status(self._h, C.byref(st), _stream_ptr(stream)), "last_status")

@@ -94,6 +94,8 @@ struct aisx_msk {
     bool tail_on = false;
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_msk = nullptr, ev_tail[2] = { nullptr, nullptr };
+    hipEvent_t ev_prep = nullptr; // behind the tag prepass of the last aisx_msk_process_stream (aisx_msk_wait_prepass)
+    bool ev_prep_set = false;
     bool ev_tail_set[2] = { false, false };
     int* d_produced2 = nullptr; // second internal `produced` array (alternates with d_produced)
     unsigned long long* d_nread = nullptr;
@@ -289,6 +291,8 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     for (int k = 0; k < 2; k++)
         if (h->ev_tail[k])
             (void)hipEventDestroy(h->ev_tail[k]);
+    if (h->ev_prep)
+        (void)hipEventDestroy(h->ev_prep);
     dev_free(h->d_ct);
     dev_free(h->d_ct_n);
     dev_free(h->d_nread);
@@ -481,6 +485,10 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     int rc;
     if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, (hipStream_t)stream)) != AISX_OK)
         return rc;
+    if (h->ev_prep) {
+        AISX_HIPCHK(hipEventRecord(h->ev_prep, (hipStream_t)stream));
+        h->ev_prep_set = true;
+    }
     MskParams p;
     msk_fill_common(h, p);
     p.in = (const cf*)d_in;
@@ -568,6 +576,19 @@ extern "C" int aisx_msk_wait_tail(aisx_msk* h, void* stream)
         for (int k = 0; k < 2; k++)
             if (h->ev_tail_set[k])
                 AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[k], 0));
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_wait_prepass(aisx_msk* h, void* stream)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (!h->ev_prep) { // first use: from now on every aisx_msk_process_stream records the event
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
+        return AISX_OK;
+    }
+    if (h->ev_prep_set)
+        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_prep, 0));
     return AISX_OK;
 }
 

@@ -186,6 +186,15 @@ int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
  * d_produced buffers from call to call.  Default: off, everything on the call's stream. */
 int aisx_msk_set_tail_stream(aisx_msk* h, void* tail_stream, int enable);
 int aisx_msk_wait_tail(aisx_msk* h, void* stream);
+/* Makes `stream` wait until the tag prepass of the last aisx_msk_process_stream call has run, i.e.
+ * until that call's recovery kernel stands at the head of its queue.  The recovery kernel is 128
+ * workgroups of 90 KB of LDS each: when it becomes ready at the same moment as a kernel with
+ * thousands of small workgroups on another stream (both waiting for the same predecessor), those
+ * fill every CU first and the recovery waits for a contiguous 90 KB until they drain (measured:
+ * 1.6 ms of a 6 ms step, every other step).  A caller that pipelines the next step's sample passes
+ * beside the recovery calls this on their stream right after aisx_msk_process_stream.  The first
+ * call only arms the event (returns at once). */
+int aisx_msk_wait_prepass(aisx_msk* h, void* stream);
 /* GNU Radio path (nchan == 1), host pointers as general_work() receives them
  * (impl :107-206): tags = the time_est tags get_tags_in_range would return or
  * any superset, nitems_read = nitems_read(0).  *consumed is what to pass to
