@@ -230,7 +230,7 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
         e.maxpos_stride = h->max_vec;
         e.nvec = nvec;
         e.offset = h->offset;
-        hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+        hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
         AISX_HIPCHK(hipGetLastError());
     }
     FsMixParams m;
@@ -520,7 +520,7 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.maxpos_stride = h->max_vec;
     e.nvec = nvec;
     e.offset = h->offset;
-    hipLaunchKernelGGL(k_fs_est, dim3((nvec + 3) / 4, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
     AISX_HIPCHK(hipGetLastError());
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
         AISX_HIPCHK(hipEventRecord(h->ev_est, st));

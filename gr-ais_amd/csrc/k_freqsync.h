@@ -26,10 +26,17 @@
 namespace aisx {
 
 constexpr int FS_F = 1024;
-constexpr int FS_T = 256;             // 4 waves = 4 vectors per workgroup
+// (measured, round 2: two waves per workgroup -- 18 KB of LDS, and 64 VGPRs with a cap -- so that
+// the estimates of the next step might slip in beside the AGC pass from a stream of their own:
+// they still start only when that pass has been dispatched; -DFS_WAVES_PER_WG=2 rebuilds it)
+#ifndef FS_WAVES_PER_WG
+#define FS_WAVES_PER_WG 4
+#endif
+constexpr int FS_WAVES = FS_WAVES_PER_WG; // one 1024-vector per wave
+constexpr int FS_T = 64 * FS_WAVES;
 constexpr int FS_ROW = 68;            // LDS row pitch (complex) per k1 row
 constexpr int FS_WAVE_ELEMS = 16 * FS_ROW; // complex slots per wave
-constexpr int FS_LDS_BYTES = (4 * FS_WAVE_ELEMS + 64) * 8; // data per wave + tw2 table
+constexpr int FS_LDS_BYTES = (FS_WAVES * FS_WAVE_ELEMS + 64) * 8; // data per wave + tw2 table
 
 struct FsEstParams {
     const cf* in; long in_stride;   // [nchan][n] new items
@@ -45,10 +52,10 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
     const int t = cx.tid();
     const int wave = t >> 6, l = t & 63;
     const int c = cx.by();
-    const int v = cx.bx() * 4 + wave;
+    const int v = cx.bx() * FS_WAVES + wave;
     cf* lds = (cf*)cx.lds();
     cf* X = lds + wave * FS_WAVE_ELEMS;
-    cf* T2 = lds + 4 * FS_WAVE_ELEMS; // W_64^{k2*n3}, index k2*4+n3
+    cf* T2 = lds + FS_WAVES * FS_WAVE_ELEMS; // W_64^{k2*n3}, index k2*4+n3
     if (t < 64)
         T2[t] = p.wtab[(16 * (t >> 2) * (t & 3)) & (FS_F - 1)];
     const bool live = v < p.nvec;
