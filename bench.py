@@ -428,29 +428,33 @@ def main():
                 y = x
                 if stock:
                     if fused:
-                        # freq_sync -> agc in one pass over the samples (same results, bit for bit); the
-                        # frequency estimates and the NCO phase walk of THIS step were prepared on
-                        # s_pre while the previous step's passes ran
+                        # The frequency estimates and the NCO phase walk of step k + 1 (this benchmark
+                        # feeds the same samples again) are issued BEFORE the front-end pass of step k:
+                        # the estimates on this stream (kernels with large grids are dispatched one
+                        # after the other whatever their streams), the walk -- 2.4 ms of latency on 64
+                        # waves -- on s_pre, beside this step's passes.  Issued behind the pass
+                        # (AISX_BENCH_EST=late) the chain pass(k) -> estimates(k+1) -> walk(k+1) ->
+                        # pass(k+1) is as long as the step and this stream idles 0.5 ms waiting for it.
+                        mode = os.environ.get("AISX_BENCH_EST", "early")
+                        if mode == "early" and T % 1024:
+                            mode = "late"  # (two estimates may wait only behind calls of whole vectors)
+                        if mode == "early":
+                            if k == 0:
+                                dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)  # (for step 0 itself)
+                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
+                        # freq_sync -> agc in one pass over the samples (same results, bit for bit)
                         y, _ = ais_amd.freq_sync_agc(dem.freq_sync, dem.agc, y)
+                        if mode == "late":
+                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
+                        elif mode == "pre":    # estimates and walk on s_pre
+                            with torch.cuda.stream(s_pre):
+                                dem.freq_sync.estimate_ahead(x)
+                        elif mode == "own":    # estimates on a stream of their own, walk on s_pre
+                            with torch.cuda.stream(s_est):
+                                dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
                     else:
                         y, _ = dem.freq_sync.work(y)
                         y = dem.agc.work(y)
-                if stock and fused:
-                    # for step k + 1 (this benchmark feeds the same samples again): the estimates here,
-                    # between the two sample passes (full-grid kernels of different streams take turns
-                    # anyway, and side by side they cost the correlator its second workgroup per CU),
-                    # the phase walk on s_pre beside the correlator
-                    # (measured: kernels with large grids are dispatched one after the other whatever
-                    # their streams, so the estimates gain nothing from a stream of their own)
-                    mode = os.environ.get("AISX_BENCH_EST", "main")
-                    if mode == "pre":      # estimates and walk on s_pre
-                        with torch.cuda.stream(s_pre):
-                            dem.freq_sync.estimate_ahead(x)
-                    elif mode == "main":   # estimates behind this step's front-end pass, walk on s_pre
-                        dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
-                    else:                  # estimates on a stream of their own, walk on s_pre
-                        with torch.cuda.stream(s_est):
-                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
                 o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
                 tags_ptrs = corr.tags_device()
                 ready = torch.cuda.Event()

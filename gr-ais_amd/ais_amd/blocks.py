@@ -307,7 +307,8 @@ class square_and_fft_sync_cc:
         """Prepare the frequency estimates (on `stream`) and the NCO phase walk (on `walk_stream`,
         default: the same) of the next freq_sync_agc() call on exactly this tensor
         (aisx_freqsync_estimate_ahead): the serial walk of step k + 1 then runs beside the sample
-        passes of step k."""
+        passes of step k.  Up to two preparations may wait (the second only behind a call whose
+        length is a multiple of fftlen with nothing pending); they are consumed in order."""
         x = _dev_c64(x, self.nchan)
         check(_lib.lib().aisx_freqsync_estimate_ahead(self._h, x.data_ptr(), x.stride(0), x.shape[1], _stream_ptr(stream),
                                                       _stream_ptr(walk_stream) if walk_stream is not None else None),

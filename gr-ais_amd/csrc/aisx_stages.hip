@@ -65,8 +65,9 @@ struct aisx_freqsync {
     int cur = 0, npend = 0;
     cf* d_wtab = nullptr;
     int* d_maxpos = nullptr;   // = slot[0].d_maxpos (the two-pass path)
-    float* d_phase = nullptr;  // the committed NCO phase, = d_phase2[phase_cur]
-    float* d_phase2[2] = { nullptr, nullptr };
+    float* d_phase = nullptr;  // the committed NCO phase, = d_phase3[phase_cur]
+    // (three copies in rotation: the committed one and the end phases of up to two walks prepared ahead)
+    float* d_phase3[3] = { nullptr, nullptr, nullptr };
     int phase_cur = 0;
     // Fused front end (aisx_freqsync_agc_process).  What a call's sample pass needs from the
     // frequency estimator -- maxpos per vector, the walked NCO phases phi[c][i] (4 bytes per sample,
@@ -79,15 +80,20 @@ struct aisx_freqsync {
         float* d_fhat = nullptr;
         hipEvent_t ev_read = nullptr; // the last sample pass that read this slot
         bool read_pending = false;
+        hipEvent_t ev_ready = nullptr; // behind the walk that filled this slot (estimates prepared ahead)
     } slot[2];
     long phases_stride = 0;
     int slot_cur = 0; // the slot the next process call uses
-    hipEvent_t ev_walk = nullptr, ev_proc = nullptr, ev_ahead = nullptr, ev_est = nullptr;
+    hipEvent_t ev_walk = nullptr, ev_proc = nullptr, ev_est = nullptr;
     bool walk_pending = false, proc_pending = false;
-    bool ahead = false; // an estimate prepared ahead, for a call with exactly these arguments
-    const void* ahead_in = nullptr;
-    long ahead_stride = 0;
-    int ahead_n = 0;
+    // estimates prepared ahead, in call order: [0] for the next aisx_freqsync_agc_process call (in
+    // slot[slot_cur]), [1] for the one after (slot[slot_cur ^ 1]), each for exactly these arguments
+    struct Ahead {
+        const void* in = nullptr;
+        long stride = 0;
+        int n = 0;
+    } ahead_q[2];
+    int ahead_cnt = 0;
     float* d_sintab = nullptr; // gr::fxpt's sine table
     // GNU Radio path staging (aisx_freqest_work_host)
     cf* d_st_vec = nullptr;
@@ -143,9 +149,9 @@ extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, doub
     CK(dev_alloc(&h->d_wtab, FS_F));
     CK(dev_alloc(&h->slot[0].d_maxpos, (size_t)nchan * h->max_vec));
     h->d_maxpos = h->slot[0].d_maxpos;
-    CK(dev_alloc(&h->d_phase2[0], nchan));
-    CK(dev_alloc(&h->d_phase2[1], nchan));
-    h->d_phase = h->d_phase2[0];
+    for (int k = 0; k < 3; k++)
+        CK(dev_alloc(&h->d_phase3[k], nchan));
+    h->d_phase = h->d_phase3[0];
 #undef CK
     if ((rc = dev_alloc(&h->d_sintab, NCO_TAB_FLOATS)) != AISX_OK) {
         aisx_freqsync_destroy(h);
@@ -174,9 +180,12 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
         dev_free(h->slot[k].d_fhat);
         if (h->slot[k].ev_read)
             (void)hipEventDestroy(h->slot[k].ev_read);
-        dev_free(h->d_phase2[k]);
+        if (h->slot[k].ev_ready)
+            (void)hipEventDestroy(h->slot[k].ev_ready);
     }
-    for (hipEvent_t e : { h->ev_walk, h->ev_proc, h->ev_ahead, h->ev_est })
+    for (int k = 0; k < 3; k++)
+        dev_free(h->d_phase3[k]);
+    for (hipEvent_t e : { h->ev_walk, h->ev_proc, h->ev_est })
         if (e)
             (void)hipEventDestroy(e);
     dev_free(h->d_st_vec);
@@ -195,7 +204,7 @@ extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
     AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fill vs. the caller's non-blocking streams)
     h->npend = 0;
     h->cur = 0;
-    h->ahead = false;
+    h->ahead_cnt = 0;
     h->walk_pending = h->proc_pending = false;
     h->slot[0].read_pending = h->slot[1].read_pending = false;
     return AISX_OK;
@@ -214,7 +223,7 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
         set_err("aisx_freqsync_process: output stride too small for %d vectors", nvec);
         return AISX_ERR_INVALID;
     }
-    h->ahead = false; // (an estimate prepared for the fused call is dropped: nothing of it was committed)
+    h->ahead_cnt = 0; // (estimates prepared for the fused call are dropped: nothing of them was committed)
     if (h->walk_pending)
         AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_walk, 0));
     if (h->proc_pending)
@@ -474,13 +483,14 @@ static int fs_fused_prepare(aisx_freqsync* h)
     if (!h->ev_walk) {
         AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming));
         AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_proc, hipEventDisableTiming));
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_ahead, hipEventDisableTiming));
         AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_est, hipEventDisableTiming));
     }
     for (int k = 0; k < 2; k++) {
         aisx_freqsync::Slot& s = h->slot[k];
         if (!s.ev_read)
             AISX_HIPCHK(hipEventCreateWithFlags(&s.ev_read, hipEventDisableTiming));
+        if (!s.ev_ready)
+            AISX_HIPCHK(hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming));
         if (!s.d_maxpos && (rc = dev_alloc(&s.d_maxpos, (size_t)h->nchan * h->max_vec)) != AISX_OK)
             return rc;
         if (!s.d_fhat && (rc = dev_alloc(&s.d_fhat, (size_t)h->nchan * h->max_vec)) != AISX_OK)
@@ -495,18 +505,20 @@ static int fs_fused_prepare(aisx_freqsync* h)
 }
 
 // frequency estimates (fs_est_body) and NCO phase walk (fs_walk_body) of the call that comes
-// next, into the slot it will use; the walk leaves the phase it ends on in the uncommitted copy
+// next (depth 0) or of the one after it (depth 1: only behind a call that leaves no pending items),
+// into the slot it will use; the walk leaves the phase it ends on in an uncommitted copy
 static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, hipStream_t st,
-                                 hipStream_t st_walk)
+                                 hipStream_t st_walk, int depth = 0)
 {
-    const int nvec = (h->npend + n) / h->fftlen;
+    const int npend = depth ? 0 : h->npend;
+    const int nvec = (npend + n) / h->fftlen;
     if (nvec == 0)
         return AISX_OK;
-    aisx_freqsync::Slot& s = h->slot[h->slot_cur];
+    aisx_freqsync::Slot& s = h->slot[h->slot_cur ^ depth];
     // what this estimate reads or overwrites may still be in use on another stream
     if (s.read_pending)
         AISX_HIPCHK(hipStreamWaitEvent(st, s.ev_read, 0)); // the pass of two calls ago read this slot
-    if (h->proc_pending && h->npend > 0)
+    if (h->proc_pending && npend > 0)
         AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_proc, 0)); // the last pass wrote the pending items
     if (h->walk_pending)
         AISX_HIPCHK(hipStreamWaitEvent(st_walk, h->ev_walk, 0)); // the last walk wrote the phase this one starts from
@@ -514,7 +526,7 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.in = (const cf*)d_in;
     e.in_stride = in_stride;
     e.pend = h->d_pend[h->cur];
-    e.npend = h->npend;
+    e.npend = npend;
     e.wtab = h->d_wtab;
     e.maxpos = s.d_maxpos;
     e.maxpos_stride = h->max_vec;
@@ -534,8 +546,8 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     w.maxpos_stride = h->max_vec;
     w.fhat = s.d_fhat;
     w.fhat_stride = h->max_vec;
-    w.phase_in = h->d_phase2[h->phase_cur];
-    w.phase_out = h->d_phase2[h->phase_cur ^ 1];
+    w.phase_in = h->d_phase3[(h->phase_cur + depth) % 3];
+    w.phase_out = h->d_phase3[(h->phase_cur + depth + 1) % 3];
     w.phases = s.d_phases;
     w.phases_stride = h->phases_stride;
     w.nvec = nvec;
@@ -544,6 +556,7 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES, st_walk, w);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipEventRecord(h->ev_walk, st_walk));
+    AISX_HIPCHK(hipEventRecord(s.ev_ready, st_walk));
     h->walk_pending = true;
     return AISX_OK;
 }
@@ -551,7 +564,10 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
 // Prepares, on `stream`, the frequency estimates and NCO phases of the NEXT
 // aisx_freqsync_agc_process call, which must come with the same d_in / in_stride / n (otherwise
 // the preparation is dropped and that call estimates for itself).  The serial phase walk of call
-// k + 1 can so run beside the sample passes of call k.  At most one call ahead.
+// k + 1 can so run beside the sample passes of call k.  A second estimate (for call k + 2) may be
+// prepared while the first is still waiting, provided call k + 1 leaves no pending items (nothing
+// pending now, its n a multiple of fftlen): a caller that issues estimate_ahead(k + 1) BEFORE
+// process(k) gives the walk the whole of step k to hide in.
 extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
                                             void* walk_stream)
 {
@@ -559,19 +575,25 @@ extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d
         set_err("aisx_freqsync_estimate_ahead: bad argument");
         return AISX_ERR_INVALID;
     }
-    if (h->ahead) {
-        set_err("aisx_freqsync_estimate_ahead: an estimate is already waiting for its aisx_freqsync_agc_process call");
+    if (h->ahead_cnt == 2) {
+        set_err("aisx_freqsync_estimate_ahead: two estimates are already waiting for their aisx_freqsync_agc_process calls");
+        return AISX_ERR_INVALID;
+    }
+    if (h->ahead_cnt == 1 && (h->npend != 0 || h->ahead_q[0].n % h->fftlen != 0)) {
+        set_err("aisx_freqsync_estimate_ahead: a second estimate can be prepared only behind a call that leaves no pending "
+                "items (%d pending now, n = %d of the call waiting, fftlen %d)", h->npend, h->ahead_q[0].n, h->fftlen);
         return AISX_ERR_INVALID;
     }
     int rc;
     hipStream_t sw = walk_stream ? (hipStream_t)walk_stream : (hipStream_t)stream;
-    if ((rc = fs_fused_prepare(h)) != AISX_OK || (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw)) != AISX_OK)
+    const int depth = h->ahead_cnt;
+    if ((rc = fs_fused_prepare(h)) != AISX_OK ||
+        (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw, depth)) != AISX_OK)
         return rc;
-    AISX_HIPCHK(hipEventRecord(h->ev_ahead, sw));
-    h->ahead = true;
-    h->ahead_in = d_in;
-    h->ahead_stride = in_stride;
-    h->ahead_n = n;
+    h->ahead_q[depth].in = d_in;
+    h->ahead_q[depth].stride = in_stride;
+    h->ahead_q[depth].n = n;
+    h->ahead_cnt = depth + 1;
     return AISX_OK;
 }
 
@@ -603,18 +625,25 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     int rc;
     if ((rc = fs_fused_prepare(h)) != AISX_OK)
         return rc;
-    if (h->ahead && (h->ahead_in != (const void*)d_in || h->ahead_stride != in_stride || h->ahead_n != n))
-        h->ahead = false; // prepared for other arguments: nothing of it was committed, estimate afresh
-    if (h->ahead) {
-        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_ahead, 0));
-        h->ahead = false;
+    if (h->ahead_cnt > 0 && (h->ahead_q[0].in != (const void*)d_in || h->ahead_q[0].stride != in_stride || h->ahead_q[0].n != n)) {
+        // prepared for other arguments: nothing of it was committed, estimate afresh -- behind whatever
+        // the dropped preparations still have running (they write the slots and phase copies used next)
+        h->ahead_cnt = 0;
+        if (h->walk_pending)
+            AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_walk, 0));
+    }
+    aisx_freqsync::Slot& s = h->slot[h->slot_cur];
+    if (h->ahead_cnt > 0) {
+        if (nvec > 0)
+            AISX_HIPCHK(hipStreamWaitEvent(st, s.ev_ready, 0));
+        h->ahead_q[0] = h->ahead_q[1];
+        h->ahead_cnt--;
     } else if ((rc = fs_estimate_into_slot(h, d_in, in_stride, n, st, st)) != AISX_OK) {
         return rc;
     }
-    aisx_freqsync::Slot& s = h->slot[h->slot_cur];
     if (nvec > 0) {
-        h->phase_cur ^= 1; // the walk's end phase becomes the block's d_phase
-        h->d_phase = h->d_phase2[h->phase_cur];
+        h->phase_cur = (h->phase_cur + 1) % 3; // the walk's end phase becomes the block's d_phase
+        h->d_phase = h->d_phase3[h->phase_cur];
         if (d_fhat)
             AISX_HIPCHK(hipMemcpy2DAsync(d_fhat, sizeof(float) * fhat_stride, s.d_fhat, sizeof(float) * h->max_vec, sizeof(float) * nvec,
                                          h->nchan, hipMemcpyDeviceToDevice, st));

@@ -267,7 +267,11 @@ int aisx_freqsync_agc_process(aisx_freqsync* fs, aisx_agc* agc, const aisx_cf32*
  * estimating itself; with other arguments the preparation is dropped).  The walk is a strict
  * recurrence per channel (one lane each, ~2 ms for 65536 samples whatever the channel count):
  * prepared one call ahead and on a stream of its own it runs beside the sample passes of the call
- * before.  At most one call ahead; d_in must stay valid and unchanged until then. */
+ * before.  A second estimate may be prepared while the first still waits for its call, provided
+ * that call leaves no pending items (nothing pending now, its n a multiple of fftlen): issuing
+ * estimate_ahead(call k + 1) BEFORE agc_process(call k) gives the walk all of step k to hide in
+ * (what bench.py does).  Preparations are consumed in order; a call with other arguments drops all
+ * of them.  d_in must stay valid and unchanged until its call. */
 int aisx_freqsync_estimate_ahead(aisx_freqsync* fs, const aisx_cf32* d_in, long in_stride, int n, void* stream,
                                  void* walk_stream);
 /* GNU Radio path (nchan == 1, HOST pointers): in = input_items[0] as the scheduler passes it to

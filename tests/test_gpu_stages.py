@@ -318,4 +318,49 @@ def test_estimate_ahead_gives_the_same_results(ais):
         assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy())
     with pytest.raises(ValueError):
         fs2.estimate_ahead(chunks[0], stream=side)
-        fs2.estimate_ahead(chunks[0], stream=side)  # one call ahead at most
+        fs2.estimate_ahead(chunks[0], stream=side)  # a second one only when nothing is or will be pending
+
+
+def test_estimate_two_calls_ahead(ais):
+    # estimate_ahead(call k + 1) issued BEFORE freq_sync_agc(call k), as bench.py does: two
+    # preparations wait at a time (two slots, three copies of the NCO phase); allowed behind calls
+    # that leave no pending items; a call with other arguments drops both
+    import torch
+    from ais_amd import synth
+
+    nchan = 70
+    lens = [4096, 2048, 1024, 8192, 3072, 1000, 24, 2048]
+    total = sum(lens)
+    xs = np.stack([synth.make_channel(1700 + c, total, "P", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
+    mk = lambda: (ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens)),
+                  ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024))
+    (fs1, ag1), (fs2, ag2) = mk(), mk()
+    side, walk = torch.cuda.Stream(), torch.cuda.Stream()
+    chunks, k = [], 0
+    for L in lens:
+        chunks.append(_dev(xs[:, k:k + L]))
+        k += L
+    torch.cuda.synchronize()
+    fs2.estimate_ahead(chunks[0], stream=side, walk_stream=walk)
+    for i, x in enumerate(chunks):
+        if i + 1 < len(chunks) and lens[i] % 1024 == 0 and sum(lens[:i]) % 1024 == 0:
+            if i == 3:  # prepared for other arguments while another one waits: both are dropped
+                fs2.estimate_ahead(chunks[1], stream=side, walk_stream=walk)
+                b, fb = ais.freq_sync_agc(fs2, ag2, chunks[3][:, :4096].contiguous(), want_fhat=True)
+                a, fa = ais.freq_sync_agc(fs1, ag1, chunks[3][:, :4096].contiguous(), want_fhat=True)
+                assert np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
+                x = chunks[3][:, 4096:].contiguous()
+            else:
+                fs2.estimate_ahead(chunks[i + 1], stream=side, walk_stream=walk)  # two waiting now
+                with pytest.raises(ValueError):
+                    fs2.estimate_ahead(chunks[i + 1], stream=side, walk_stream=walk)  # a third
+        a, fa = ais.freq_sync_agc(fs1, ag1, x, want_fhat=True)
+        b, fb = ais.freq_sync_agc(fs2, ag2, x, want_fhat=True)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+        assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy())
+    # behind a call that leaves items pending no second estimate can be prepared
+    fs3, ag3 = mk()
+    fs3.estimate_ahead(chunks[5], stream=side)  # 1000 items
+    with pytest.raises(ValueError):
+        fs3.estimate_ahead(chunks[6], stream=side)
