@@ -37,6 +37,8 @@ def timed_stats(trace_csv, steps, warmup):
     for k, v in per.items():
         if not k.startswith("k_"):
             continue
+        if len(v) < nstock:
+            continue  # (a kernel of the side measurements only, e.g. the other correlator build)
         first = v[:nstock]  # the stock chain comes first in the run
         timed = first[warmup:nstock]
         if timed:
