@@ -11,7 +11,7 @@ from ais_amd import synth
 def test_emul_agc_bit_exact():
     rng = np.random.default_rng(2)
     nchan = 3
-    lens = [5000, 1, 300, 2048, 4097]
+    lens = [5000, 1, 300, 2048, 4097, 9000]  # (9000: a second workgroup of four tiles per channel)
     total = sum(lens)
     x = (rng.normal(size=(nchan, total)) + 1j * rng.normal(size=(nchan, total))).astype(np.complex64)
     x[0, 1000:3000] = 0          # floor 1e-12 path
@@ -83,7 +83,7 @@ def test_emul_fused_front_end_is_freq_sync_then_agc():
     # freq_sync followed by its AGC, ragged calls (pending partial vectors, carried AGC history,
     # a call without a whole vector), an all-zero stretch (stale maxpos)
     nchan = 3
-    lens = [4096, 1000, 24, 5000, 3 * 1024 + 7, 10]
+    lens = [4096, 1000, 24, 5000, 3 * 1024 + 7, 10, 9 * 1024]
     total = sum(lens)
     xs = np.stack([synth.make_channel(900 + c, total, "P", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
     xs[1, 2048:5120] = 0
