@@ -21,7 +21,10 @@ __global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk(MskParams p)
     DevCtx cx{ smem };
     // the recurrence is latency-bound and issues little: its waves go first on their SIMDs, ahead
     // of the throughput kernels of the other stream that share them
-    __builtin_amdgcn_s_setprio(3);
+#ifndef MSK_PRIO
+#define MSK_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(MSK_PRIO);
     msk_body<DevCtx, AUX, OSPS2, LPW>(cx, p);
 }
 
