@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
     DevCtx cx{ nullptr };
     fs_freqest_body(cx, p);
 }
-__global__ __launch_bounds__(AGC_T) void k_agc8(AgcParams p)
+__global__ __launch_bounds__(AGC8_T) void k_agc8(AgcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
@@ -459,7 +459,8 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.W = h->W;
     p.reference = h->reference;
     p.floor_env = h->floor_env;
-    p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    const int TL = agc8_applies(h->W) ? AGC8_TL : AGC_TL;
+    p.ntiles = (n + TL - 1) / TL;
     p.phases = nullptr;
     p.phases_stride = 0;
     p.sintab = nullptr;
@@ -468,7 +469,7 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.npend = 0;
     p.n_raw = 0;
     if (agc8_applies(p.W))
-        hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
     AISX_HIPCHK(hipGetLastError());
@@ -659,7 +660,7 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.W = a->W;
     p.reference = a->reference;
     p.floor_env = a->floor_env;
-    p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1; // (a call without a whole vector still moves the pending items)
+    p.ntiles = total > 0 ? (total + AGC8_TL - 1) / AGC8_TL : 1; // (a call without a whole vector still moves the pending items)
     p.phases = s.d_phases;
     p.phases_stride = h->phases_stride;
     p.sintab = h->d_sintab;
@@ -667,7 +668,7 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.pend_out = h->d_pend[h->cur ^ 1];
     p.npend = h->npend;
     p.n_raw = n;
-    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC8_LDS_BYTES_MIXED, st, p);
+    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES_MIXED, st, p);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipEventRecord(s.ev_read, st));
     s.read_pending = true;

@@ -13,7 +13,7 @@
 
 namespace aisx {
 
-constexpr int AGC_T = 256;       // threads per workgroup
+constexpr int AGC_T = 256;       // threads per workgroup (k_agc)
 constexpr int AGC_TL = 2048;     // outputs per tile
 constexpr int AGC_PER = AGC_TL / AGC_T;
 constexpr int AGC_MAXW = 2048;   // largest supported window
@@ -136,14 +136,22 @@ AISX_DI void agc_body(Ctx& cx, const AgcParams& p)
 // sliding maximum over GROUP maxima: 1/8 of the elements, log2(Q) doubling passes) and the
 // first k items of group a + Q (that group's prefix maxima, exchanged through LDS).  About
 // three LDS operations per item instead of three per item and doubling pass.
+// Workgroups of 1024 threads, 8192 outputs per tile: the 511-item halo a tile reads (and, in the
+// fused front end, mixes) a second time is 6 % of it (25 % with 256 threads: 2.26 -> 2.04 ms per
+// launch in the chain at 512 threads, the step 1.7 % shorter at 1024; -DAGC8_THREADS rebuilds)
+#ifndef AGC8_THREADS
+#define AGC8_THREADS 1024
+#endif
+constexpr int AGC8_T = AGC8_THREADS;
 constexpr int AGC8_G = 8;
-constexpr int AGC8_NG = AGC_TL / AGC8_G;               // groups with outputs per tile (= AGC_T)
+constexpr int AGC8_TL = AGC8_G * AGC8_T;               // outputs per tile: one group per thread
+constexpr int AGC8_NG = AGC8_TL / AGC8_G;               // groups with outputs per tile (= AGC8_T)
 constexpr int AGC8_MAXQ = AGC_MAXW / AGC8_G;           // halo groups at most
 constexpr int AGC8_GROUPS = AGC8_NG + AGC8_MAXQ;       // group maxima per buffer
 constexpr int AGC8_LDS_BYTES = (2 * AGC8_GROUPS + AGC8_NG * AGC8_G) * 4; // group maxima x 2, prefix maxima of the NG groups windows end in
 constexpr int AGC8_LDS_BYTES_MIXED = AGC8_LDS_BYTES + NCO_TAB_FLOATS * 4;  // + the NCO's sine table (fused front end)
-static_assert(AGC8_NG == AGC_T, "one output group per thread");
-static_assert(AGC8_MAXQ <= AGC_T, "at most one halo group per thread");
+static_assert(AGC8_NG == AGC8_T, "one output group per thread");
+static_assert(AGC8_MAXQ <= AGC8_T, "at most one halo group per thread");
 
 AISX_HD bool agc8_applies(int W) { return W % AGC8_G == 0 && W >= 2 * AGC8_G && W <= AGC_MAXW; }
 
@@ -164,8 +172,8 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     const cf* hist = p.hist_in + (long)c * H;
     cf* xout = p.out + (long)c * p.out_stride;
 
-    const int base = tile * AGC_TL;
-    const int nout = (n - base) < AGC_TL ? (n - base) : AGC_TL;
+    const int base = tile * AGC8_TL;
+    const int nout = (n - base) < AGC8_TL ? (n - base) : AGC8_TL;
     const int E = (nout > 0 ? nout : 0) + H;        // items of the combined stream this tile looks at
     const int ngroups = (E + AGC8_G - 1) / AGC8_G;  // <= AGC8_NG + Q
     // fused front end: new item m is raw[m] mixed with the walked NCO phase (AgcParams)
@@ -288,7 +296,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
             load_group(AGC8_NG + t, G2);
         if (mixed) {
             typedef float f4 __attribute__((vector_size(16)));
-            for (int i = t; i < NCO_TAB_FLOATS / 4; i += AGC_T) // (8 KB, L2-resident: two 16-byte loads per thread)
+            for (int i = t; i < NCO_TAB_FLOATS / 4; i += AGC8_T) // (8 KB, L2-resident: two 16-byte loads per thread)
                 ((f4*)ST)[i] = ((const f4*)p.sintab)[i];
             cx.sync();
         }
@@ -297,7 +305,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         if (have2)
             finish_group(AGC8_NG + t, false, G2);
     }
-    for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC_T)
+    for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC8_T)
         GA[g] = 0.f; // groups past the data: neutral
     cx.sync();
     // sliding maximum over Q - 1 group maxima by doubling: 2^K <= Q - 1
@@ -308,7 +316,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     float* dst = GB;
     for (int k = 0; k < K; k++) {
         const int step = 1 << k;
-        for (int g = t; g < AGC8_GROUPS; g += AGC_T) {
+        for (int g = t; g < AGC8_GROUPS; g += AGC8_T) {
             const float a = src[g];
             const float b = (g + step < AGC8_GROUPS) ? src[g + step] : a;
             dst[g] = a < b ? b : a;
@@ -355,14 +363,14 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     // set_history(nsamples): keep the last W-1 items of the combined stream
     if (tile == p.ntiles - 1) {
         cf* ho = p.hist_out + (long)c * H;
-        for (int j = t; j < H; j += AGC_T) {
+        for (int j = t; j < H; j += AGC8_T) {
             const int s = n + j;
             ho[j] = (s < H) ? hist[s] : item(s - H);
         }
         if (mixed) { // stream_to_vector's pending items: the raw samples behind the last whole vector
             cf* po = p.pend_out + (long)c * 1024;
             const int rem = p.npend + p.n_raw - n;
-            for (int i = t; i < rem; i += AGC_T) {
+            for (int i = t; i < rem; i += AGC8_T) {
                 const int m = n + i;
                 po[i] = (m < p.npend) ? pend[m] : xin[m - p.npend];
             }

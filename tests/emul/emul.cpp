@@ -541,10 +541,10 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     AgcParams p;
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
-    p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = (n + AGC_TL - 1) / AGC_TL;
+    p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = agc8_applies(h->W) ? (n + AGC8_TL - 1) / AGC8_TL : (n + AGC_TL - 1) / AGC_TL;
     p.phases = nullptr; p.phases_stride = 0; p.sintab = nullptr; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
     if (agc8_applies(p.W))
-        run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
+        run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else
         run_grid(p.ntiles, h->nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, p); });
     h->cur ^= 1;
@@ -625,10 +625,10 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = a->hist[a->cur].data(); p.hist_out = a->hist[a->cur ^ 1].data();
     p.n = total; p.W = a->W; p.reference = a->ref; p.floor_env = AGC_FLOOR_DEFAULT;
-    p.ntiles = total > 0 ? (total + AGC_TL - 1) / AGC_TL : 1;
+    p.ntiles = total > 0 ? (total + AGC8_TL - 1) / AGC8_TL : 1;
     p.phases = phases.data(); p.phases_stride = pstride; p.sintab = &aisx_sine_table[0][0]; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
     p.npend = h->npend; p.n_raw = n;
-    run_grid(p.ntiles, h->nchan, AGC_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
+    run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
     h->npend = h->npend + n - total;
     h->cur ^= 1;
     a->cur ^= 1;
