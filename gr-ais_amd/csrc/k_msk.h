@@ -1203,9 +1203,20 @@ AISX_DI void bittail_body(Ctx& cx, const BitTailParams& p)
     unsigned char* ob = p.bits + (long)ch * p.bit_stride;
     const cf sym_m1 = p.prev_sym_in[ch];
     const unsigned char bit_m1 = p.prev_bit_in[ch];
+    // binary_slicer(quadrature_demod) only wants the SIGN of pi/2 * fast_atan2f(y, x).  For finite
+    // operands every arm of fast_atan2f gives an angle >= 0 when y >= 0 (-0 included: base_angle,
+    // pi - base_angle, pi/2 -+ base_angle with base_angle <= pi/4; 0 for x = y = 0) and an angle < 0
+    // when y < 0 -- except -base_angle = -0 (which the slicer takes for 1) when the quotient
+    // |y| / |x| underflows to zero.  So: the sign of y decides, unless an operand is not finite or
+    // a negative y is tiny against x; those (never, on symbols) go through the table.
     auto slice = [&](const cf& cur, const cf& prev) -> unsigned char {
         const cf prod = cmul_exact(cur, cconj(prev));
-        const float fm = 1.57079632679489661923f * fast_atan2f_tab(prod.im, prod.re, at);
+        const float y = prod.im, x = prod.re;
+        const float ya = fabsf(y), xa = fabsf(x);
+        const bool plain = (ya < 1.0e30f) && (xa < 1.0e18f) && (y >= 0.0f || ya > 1.0e-18f); // (false for NaN / inf)
+        if (plain)
+            return y >= 0.0f ? 1 : 0;
+        const float fm = 1.57079632679489661923f * fast_atan2f_tab(y, x, at);
         return fm >= 0 ? 1 : 0;
     };
     if (cx.bx() == 0 && t == 0 && P == 0) { // nothing produced: the state carries over

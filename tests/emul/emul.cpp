@@ -246,6 +246,24 @@ void emu_bittail(const BitTailParams* p, int max_out)
     run_grid(nseg, p->nchan, BT_T, 260 * 4, [&](EmuCtx& cx) { bittail_body(cx, *p); });
 }
 
+// the bit tail on its own: one channel, `n` symbols, state (prev symbol, prev sliced bit) in / out
+void emu_bittail_run(const cf* syms, int n, cf* prev_sym, unsigned char* prev_bit, unsigned char* bits)
+{
+    BitTailParams b;
+    cf so = *prev_sym;
+    unsigned char bo = *prev_bit;
+    b.nchan = 1;
+    b.syms = syms; b.sym_stride = n;
+    b.produced = &n;
+    b.bits = bits; b.bit_stride = n;
+    b.prev_sym_in = prev_sym; b.prev_bit_in = prev_bit;
+    b.prev_sym_out = &so; b.prev_bit_out = &bo;
+    b.atan_tab = aisx_atan_table;
+    emu_bittail(&b, n);
+    *prev_sym = so;
+    *prev_bit = bo;
+}
+
 void emu_msk(const MskParams* p)
 {
     const bool aux = p->err || p->mu_out;

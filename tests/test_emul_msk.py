@@ -217,3 +217,34 @@ def test_emul_msk_tag_resets_inside_the_lock_step(sps, lpw):
             nsym += p
         k += L
     assert nsym > nchan * total / sps * 0.9
+
+
+def test_emul_bittail_sign_shortcut_on_awkward_symbols():
+    # the bit tail decides by the sign of Im(sym[o] * conj(sym[o-1])) and goes through
+    # fast_atan2f's table only for non-finite or underflowing operands: zeros of both signs,
+    # denormals, tiny negative quadrature against a large in-phase part (-base_angle = -0 slices to
+    # 1), huge values, inf and NaN -- against the oracle's full quadrature_demod -> slicer -> decoder
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1e-30, -1e-30, 1e-19, -1e-19, 1e-10, -1e-10, 1.0, -1.0,
+                         3.0, -3.0, 1e10, -1e10, 1e19, -1e19, 1e30, -1e30, 3e38, -3e38, np.inf, -np.inf, np.nan],
+                        dtype=np.float32)
+    re = rng.choice(specials, size=6000)
+    im = rng.choice(specials, size=6000)
+    syms = (re + 1j * im).astype(np.complex64)
+    syms = np.concatenate([syms, (rng.normal(size=3000) + 1j * rng.normal(size=3000)).astype(np.complex64)])
+    rng.shuffle(syms)
+    L = emu.lib()
+    L.emu_bittail_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    prev_sym = np.zeros(1, np.complex64)
+    prev_bit = np.zeros(1, np.uint8)
+    bt = orc.BitTail()
+    k = 0
+    with np.errstate(all="ignore"):
+        for n in (1, 2, 5000, 1, 3996):
+            bits = np.zeros(n, np.uint8)
+            chunk = np.ascontiguousarray(syms[k:k + n])
+            L.emu_bittail_run(chunk.ctypes.data, n, prev_sym.ctypes.data, prev_bit.ctypes.data, bits.ctypes.data)
+            assert np.array_equal(bits, bt.process(chunk)), n
+            k += n
