@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AISX_VERSION 200
+#define AISX_VERSION 210
 
 /* gr_complex = std::complex<float>: interleaved re, im */
 typedef struct aisx_cf32 { float re, im; } aisx_cf32;
