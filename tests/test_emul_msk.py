@@ -232,7 +232,8 @@ def test_emul_bittail_sign_shortcut_on_awkward_symbols():
                         dtype=np.float32)
     re = rng.choice(specials, size=6000)
     im = rng.choice(specials, size=6000)
-    syms = (re + 1j * im).astype(np.complex64)
+    syms = np.empty(re.size, np.complex64)
+    syms.real, syms.imag = re, im  # (not re + 1j * im: 0 * inf would turn the real part into NaN)
     syms = np.concatenate([syms, (rng.normal(size=3000) + 1j * rng.normal(size=3000)).astype(np.complex64)])
     rng.shuffle(syms)
     L = emu.lib()
