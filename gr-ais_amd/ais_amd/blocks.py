@@ -54,7 +54,7 @@ class corr_est_cc:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (None while the interpreter shuts down: the process is going anyway)
             _lib.lib().aisx_corr_destroy(h)
             self._h = None
 
@@ -163,7 +163,7 @@ class msk_timing_recovery_cc:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (None while the interpreter shuts down: the process is going anyway)
             _lib.lib().aisx_msk_destroy(h)
             self._h = None
 
@@ -296,7 +296,7 @@ class square_and_fft_sync_cc:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (None while the interpreter shuts down: the process is going anyway)
             _lib.lib().aisx_freqsync_destroy(h)
             self._h = None
 
@@ -393,7 +393,7 @@ class feedforward_agc_cc:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (None while the interpreter shuts down: the process is going anyway)
             _lib.lib().aisx_agc_destroy(h)
             self._h = None
 
@@ -506,7 +506,7 @@ class pfb_channelizer_ccf:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (None while the interpreter shuts down: the process is going anyway)
             _lib.lib().aisx_pfb_destroy(h)
             self._h = None
 
