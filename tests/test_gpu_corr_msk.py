@@ -414,6 +414,37 @@ def test_msk_bit_tail_on_its_own_stream(ais):
     assert rb["produced"].shape[0] == nchan
 
 
+def test_msk_wait_prepass_orders_another_stream(ais):
+    # aisx_msk_wait_prepass: a second stream waits for the tag prepass of the last call (so that the
+    # recovery's large workgroups are placed before that stream's small ones); the first call only
+    # arms the event, results are untouched
+    import torch
+    from ais_amd import synth
+
+    nchan, lens = 12, [3000, 2500, 4000]
+    xs = np.stack([synth.make_channel(760 + c, sum(lens), "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
+    a = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    b = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
+    other = torch.cuda.Stream()
+    b.wait_prepass(other)  # arms
+    k = 0
+    for L in lens:
+        x = _dev(xs[:, k:k + L])
+        ra = a.work(x)
+        rb = b.work(x)
+        b.wait_prepass(other)
+        with torch.cuda.stream(other):
+            y = x * 2  # (anything on the ordered stream)
+        torch.cuda.synchronize()
+        pa, pb = ra["produced"].cpu().numpy(), rb["produced"].cpu().numpy()
+        assert np.array_equal(pa, pb) and pa.min() > 0
+        ba, bb = ra["bits"].cpu().numpy(), rb["bits"].cpu().numpy()
+        for c in range(nchan):
+            assert np.array_equal(ba[c, :pa[c]], bb[c, :pb[c]])
+        assert torch.equal(y, x * 2)
+        k += L
+
+
 @pytest.mark.parametrize("family", ["P", "S"])
 def test_core_chain_corr_to_msk_bits_identical(ais, family):
     # corr_est -> msk -> NRZI bits with the tags handed over on the device, vs
