@@ -406,6 +406,13 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
     cx.sync();
     int ntag = 0;
     int i = 0;
+    // the window in hand: items wq0 .. wq0 + 63 (lane j: value, mag^2), the lanes whose value is in
+    // hand, the lanes from which the climb steps on
+    bool win = false;
+    int wq0 = 0;
+    cf wcv = mk(0.f, 0.f);
+    float wmg = 0.f;
+    unsigned long long wHV = 0ull, wC = 0ull;
     for (int base = 0; base < nwords; base += 64) {
         if ((long)(base + 64) * 64 <= (long)i)
             continue;
@@ -424,64 +431,72 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
             const int src = cx.ctz64(nz);
             const unsigned long long word = cx.shfl_u64(we, src);
             int pk = (base + src) * 64 + cx.ctz64(word);
-            // One window per detection: lane j looks at item q0 + j, q0 = pk - 1 -- its
-            // above-threshold bit and its correlation value, fetched in one go -- so that the
-            // climb (:202-204) and the centre of mass (:219-227) cost one memory round trip
-            // instead of one per step.
+            // One window per burst: lane j looks at item q0 + j -- its above-threshold bit and its
+            // correlation value, fetched in one go -- so that the climb (:202-204) and the centre of
+            // mass (:219-227) cost one memory round trip instead of one per step; and the next
+            // detections of the same burst (isps items on, :270: usually still inside the window)
+            // none at all.  A fresh window starts at q0 = pk - 1.
             cf cp = mk(0.f, 0.f);
             float mp = 0.f, m0 = 0.f, m2 = 0.f;
             bool have0 = false, have2 = false;
             for (;;) {
-                const int q0 = pk - 1;
-                const int wa = (q0 < 0 ? 0 : q0) >> 6;
-                // (words base .. base + 63 of the bitmask are in the wave's registers)
-                const int ra = wa - base, rb = wa + 1 - base;
-                unsigned long long WA = cx.shfl_u64(w, ra & 63), WB = cx.shfl_u64(w, rb & 63);
-                if (ra < 0 || ra > 63)
-                    WA = A[wa];
-                if (rb < 0 || rb > 63)
-                    WB = (wa + 1 < nwords) ? A[wa + 1] : 0ull;
-                const int pos = q0 + lane;
-                const bool inside = pos >= 0 && pos < n;
-                const unsigned long long wsel = ((pos >> 6) == wa) ? WA : WB;
-                const bool above = inside && ((pos >> 6) <= wa + 1) && ((wsel >> (pos & 63)) & 1ull);
-                const unsigned long long AB = cx.ballot(above);
-                // below-threshold items the main kernel left in the scratch next to a hit
-                // (corr_emit_hits): element m of its tile, same tile and same wave as the hit
-                bool nbr = false;
-                if (!p.dense_corr) {
-                    const int F = p.L + p.N;
-                    const int t0 = ((q0 < 0 ? 0 : q0) / p.L) * p.L; // first output of the tile the window starts in
-                    int m = pos - t0 + p.N;
-                    if (m >= F)
-                        m -= p.L;
-                    const bool left_hit = lane > 0 && ((AB >> (lane - 1)) & 1ull);   // item pos - 1 is a hit
-                    const bool right_hit = lane < 63 && ((AB >> (lane + 1)) & 1ull); // item pos + 1 is a hit
-                    nbr = inside && !above &&
-                          ((left_hit && m - 1 >= p.N && ((m - 1) & 63) != 63) || (right_hit && m + 1 < F && ((m + 1) & 63) != 0));
+                int j = pk - wq0; // lane of item pk in the window in hand
+                if (!(win && j >= 1 && j <= 61)) {
+                    const int q0 = pk - 1;
+                    const int wa = (q0 < 0 ? 0 : q0) >> 6;
+                    // (words base .. base + 63 of the bitmask are in the wave's registers)
+                    const int ra = wa - base, rb = wa + 1 - base;
+                    unsigned long long WA = cx.shfl_u64(w, ra & 63), WB = cx.shfl_u64(w, rb & 63);
+                    if (ra < 0 || ra > 63)
+                        WA = A[wa];
+                    if (rb < 0 || rb > 63)
+                        WB = (wa + 1 < nwords) ? A[wa + 1] : 0ull;
+                    const int pos = q0 + lane;
+                    const bool inside = pos >= 0 && pos < n;
+                    const unsigned long long wsel = ((pos >> 6) == wa) ? WA : WB;
+                    const bool above = inside && ((pos >> 6) <= wa + 1) && ((wsel >> (pos & 63)) & 1ull);
+                    const unsigned long long AB = cx.ballot(above);
+                    // below-threshold items the main kernel left in the scratch next to a hit
+                    // (corr_emit_hits): element m of its tile, same tile and same wave as the hit
+                    bool nbr = false;
+                    if (!p.dense_corr) {
+                        const int F = p.L + p.N;
+                        const int t0 = ((q0 < 0 ? 0 : q0) / p.L) * p.L; // first output of the tile the window starts in
+                        int m = pos - t0 + p.N;
+                        if (m >= F)
+                            m -= p.L;
+                        const bool left_hit = lane > 0 && ((AB >> (lane - 1)) & 1ull);   // item pos - 1 is a hit
+                        const bool right_hit = lane < 63 && ((AB >> (lane + 1)) & 1ull); // item pos + 1 is a hit
+                        nbr = inside && !above &&
+                              ((left_hit && m - 1 >= p.N && ((m - 1) & 63) != 63) || (right_hit && m + 1 < F && ((m + 1) & 63) != 0));
+                    }
+                    wcv = mk(0.f, 0.f);
+                    if (inside && (above || nbr || p.dense_corr))
+                        wcv = corr[pos];
+                    wmg = mag2(wcv);
+                    // climb: from item q to q + 1 while q + 1 is above threshold and larger
+                    const float mg_next = cx.shfl_down_f32(wmg, 1);
+                    wHV = AB | cx.ballot(nbr); // lanes whose value is in hand
+                    const bool step_ok = (lane < 63) && ((AB >> (lane + 1)) & 1ull) && (wmg < mg_next);
+                    wC = cx.ballot(step_ok);
+                    wq0 = q0;
+                    win = true;
+                    j = 1;
                 }
-                cf cv = mk(0.f, 0.f);
-                if (inside && (above || nbr || p.dense_corr))
-                    cv = corr[pos];
-                const float mg = mag2(cv);
-                // climb: from item q to q + 1 while q + 1 is above threshold and larger
-                const float mg_next = cx.shfl_down_f32(mg, 1);
-                const unsigned long long HV = AB | cx.ballot(nbr); // lanes whose value is in hand
-                const bool step_ok = (lane < 63) && ((AB >> (lane + 1)) & 1ull) && (mg < mg_next);
-                const unsigned long long C = cx.ballot(step_ok);
-                const int run = cx.ctz64(~(C >> 1)); // consecutive climbs from lane 1 (= pk)
-                const int jp = 1 + run;              // lane of the local maximum, if it is inside the window
+                const int run = cx.ctz64(~(wC >> j)); // consecutive climbs from lane j (= pk)
+                const int jp = j + run;               // lane of the local maximum, if it is inside the window
                 if (jp >= 63) { // the climb runs off the window: move the window there and go on
-                    pk = q0 + 62;
+                    pk = wq0 + 62;
+                    win = false;
                     continue;
                 }
-                pk = q0 + jp;
-                cp = mk(cx.shfl_f32(cv.re, jp), cx.shfl_f32(cv.im, jp));
+                pk = wq0 + jp;
+                cp = mk(cx.shfl_f32(wcv.re, jp), cx.shfl_f32(wcv.im, jp));
                 mp = mag2(cp);
-                have0 = p.dense_corr || ((HV >> (jp - 1)) & 1ull);
-                have2 = p.dense_corr || ((HV >> (jp + 1)) & 1ull);
-                m0 = cx.shfl_f32(mg, jp - 1);
-                m2 = cx.shfl_f32(mg, jp + 1);
+                have0 = p.dense_corr || ((wHV >> (jp - 1)) & 1ull);
+                have2 = p.dense_corr || ((wHV >> (jp + 1)) & 1ull);
+                m0 = cx.shfl_f32(wmg, jp - 1);
+                m2 = cx.shfl_f32(wmg, jp + 1);
                 break;
             }
             // centre of mass (:219-227)
