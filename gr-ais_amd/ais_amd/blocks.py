@@ -423,7 +423,7 @@ class ais_demod:
     reference's connect order) or 'core' (corr_est -> msk only, the chain
     BASELINE.json's metric names)."""
 
-    def __init__(self, options, nchan=1, max_items=65536, stages="stock", preamble_symbols=None):
+    def __init__(self, options, nchan=1, max_items=65536, stages="stock", preamble_symbols=None, fused_front_end=False):
         from .modulate import gmsk_mod, modulate_vector_bc
 
         self._samples_per_symbol = options["samples_per_symbol"]
@@ -434,9 +434,10 @@ class ais_demod:
         self.fftlen = options["fftlen"]
         self.nchan = nchan
         self.stages = stages
-        # freq_sync -> agc in one pass (freq_sync_agc): same results; off by default, the separate
-        # NCO phase walk it needs is slower than fs_mix's in-kernel one when run in series
-        self.fused_front_end = False
+        # freq_sync -> agc in one pass (freq_sync_agc): same results, bit for bit; off by default: the
+        # separate NCO phase walk it needs is slower than fs_mix's in-kernel one when everything runs
+        # in series on one stream -- it pays when the caller prepares it ahead (estimate_ahead, bench.py)
+        self.fused_front_end = bool(fused_front_end)
         if stages == "stock":
             self.freq_sync = square_and_fft_sync_cc(self._samplerate, self._bits_per_sec, self.fftlen, nchan=nchan,
                                                     max_items=max_items)

@@ -364,3 +364,29 @@ def test_estimate_two_calls_ahead(ais):
     fs3.estimate_ahead(chunks[5], stream=side)  # 1000 items
     with pytest.raises(ValueError):
         fs3.estimate_ahead(chunks[6], stream=side)
+
+
+def test_ais_demod_fused_front_end_gives_the_same_bits(ais):
+    # ais_demod(..., fused_front_end=True): the whole python/ais_demod.py:56 chain with freq_sync and
+    # the AGC as one pass -- bits, symbol counts and tags equal to the chain with the two blocks
+    from ais_amd import synth
+
+    nchan, lens = 24, [8192, 5000, 12288]
+    opts = dict(samples_per_symbol=4, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
+    xs = np.stack([synth.make_channel(2100 + c, sum(lens), "S", 4, amp=0.3, cfo_max=500.0)[0] for c in range(nchan)])
+    a = ais.ais_demod(opts, nchan=nchan, max_items=max(lens))
+    b = ais.ais_demod(opts, nchan=nchan, max_items=max(lens), fused_front_end=True)
+    k = nbits = 0
+    for L in lens:
+        x = _dev(xs[:, k:k + L])
+        ra, rb = a.work(x), b.work(x)
+        pa, pb = ra["produced"].cpu().numpy(), rb["produced"].cpu().numpy()
+        assert np.array_equal(pa, pb)
+        ba, bb = ra["bits"].cpu().numpy(), rb["bits"].cpu().numpy()
+        for c in range(nchan):
+            assert np.array_equal(ba[c, :pa[c]], bb[c, :pb[c]])
+        ta, tb = a.preamble_detect.tags(), b.preamble_detect.tags()
+        assert ta.tobytes() == tb.tobytes()
+        nbits += int(pa.sum())
+        k += L
+    assert nbits > nchan * sum(lens) / 4 * 0.9
