@@ -130,14 +130,20 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(chain, family, sps, T, budget_s=7.0, max_ch=4096):
-    """The CPU oracle (a plain-C port of the reference's algorithm: the reference's VOLK path
-    needs GNU Radio, absent here) on a bounded sample of the same workload, on this host:
+def cpu_baseline(chain, family, sps, T, budget_s=6.0):
+    """The CPU path timed beside the GPU's, on this host, on a bounded sample of the same workload.
+    The reference's own VOLK / FFTW path needs GNU Radio (absent), so this is the oracle: a plain-C
+    port of the reference's algorithm (`kind: "port"`).  Timed build = oracle/ais_oracle.c compiled
+    HERE with -O3 -march=native, work buffers kept between channels (a
+    flowgraph allocates its buffers once), -ffp-contract=off kept so that its results are the
+    portable build's, which is checked first (orc_demod_hash).
       B1  one thread, whole channels of T samples one after the other (the like-for-like of one
-          GNU Radio block thread chain), ~budget_s seconds of CPU work;
-      B2  all cores: one worker thread per core (the oracle releases the GIL inside ctypes), each
-          running whole channels, ~budget_s seconds of wall time.
-    `value` is B2, `cores` the threads it used; B1 is reported next to it."""
+          GNU Radio flowgraph of one channel);
+      B2  one worker thread per hardware thread, each running whole channels.
+    `value` is B2, `cores` the threads it used; B1 and the portable -O2 build's figures (what
+    rounds 1-2 reported) stand next to it."""
+    import tempfile
+
     import oracle_py as orc
     from ais_amd import synth
 
@@ -145,32 +151,45 @@ def cpu_baseline(chain, family, sps, T, budget_s=7.0, max_ch=4096):
     stock = chain == "stock"
     ip = dict(amp=0.3 if stock else 1.0, cfo_max=500.0 if stock else 15.0)
     stages = 3 if stock else 0
-    orc.Demod(sps, tmpl, stages=stages).step(synth.make_channel(synth.SEED0, 4096, family, sps)[0])  # FFT plan cache
-    xs = [synth.make_channel(synth.SEED0 + c, T, family, sps, **ip)[0] for c in range(8)]
-
-    def one(c):
-        dem = orc.Demod(sps, tmpl, stages=stages)
-        t0 = time.perf_counter()
-        dem.step(xs[c % len(xs)])
-        return time.perf_counter() - t0
-
-    spent, nch = 0.0, 0
-    while spent < budget_s and nch < max_ch:
-        spent += one(nch)
-        nch += 1
-    b1 = nch * T / spent / 1e6
+    xs = np.stack([synth.make_channel(synth.SEED0 + c, T, family, sps, **ip)[0] for c in range(8)])
     ncores = os.cpu_count() or 1
     try:
         ncores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
-    # (the workers are C threads inside the oracle library: no interpreter in the timed loop)
-    done, wall = orc.demod_bench_mt(ncores, sps, tmpl, stages, np.stack(xs), budget_s)
-    b2 = done * T / wall / 1e6
+    tmpdir = tempfile.mkdtemp(prefix="aisx_orc_")
+    native = orc.build_native(os.path.join(tmpdir, "libais_oracle_native.so"))
+    same = None
+    if native is not None:
+        same = all(orc.demod_hash(sps, tmpl, stages, xs[c]) == orc.demod_hash(sps, tmpl, stages, xs[c], native) for c in (0, 1))
+        if not same:
+            native = None  # (a timing build whose results differ is not the same algorithm: do not time it)
+
+    def run(L, nthreads, budget):
+        done, wall = orc.demod_bench_mt(nthreads, sps, tmpl, stages, xs, budget, L)
+        return done * T / wall / 1e6, done, wall
+
+    b1, n1, w1 = run(native, 1, budget_s)
+    b2, n2, w2 = run(native, ncores, budget_s)
+    half = run(native, max(1, ncores // 2), budget_s / 2)[0]  # (one thread per core if SMT is on)
+    p1 = run(None, 1, budget_s / 2)[0]
+    p2 = run(None, ncores, budget_s / 2)[0]
+    flags = "gcc -O3 -march=native -ffp-contract=off, buffers kept between channels" if native is not None else \
+        "gcc -O2 (no native build on this host%s)" % ("" if same is None else ": its results differed")
+    note = None
+    if b2 / b1 < 30.0 and ncores >= 64:
+        note = ("B2 / B1 = %.1f on %d threads (%.1f on %d): every channel streams ~%.0f MB through buffers far larger than a "
+                "core's share of L2/L3 (input 0.5 MB + five work buffers of 0.5 MB + 6 MB of tag scratch per 65536 samples), "
+                "the per-sample work is short dependent float chains (NCO phase, timing loop) that SMT siblings share one "
+                "core's ports for, and the radix-2 FFT walks its 16 KB block twelve times" %
+                (b2 / b1, ncores, half / b1, max(1, ncores // 2), 8.0 * T * 7 / 1e6))
     return dict(value=b2, unit="complex MS/s", cores=ncores, kind="port",
                 sample="B2: %d channels x %d samples on %d threads in %.1f s wall; B1: %d channels on one thread (%.1f s); chain=%s; "
-                       "oracle/ais_oracle.c (gcc -O2, radix-2 FFT standing in for FFTW/VOLK)" % (done, T, ncores, wall, nch, spent, chain),
-                single_thread_value=b1, cpu_model=cpu_model(), nproc=os.cpu_count(),
+                       "oracle/ais_oracle.c (%s; radix-2 FFT standing in for FFTW/VOLK)" % (n2, T, ncores, w2, n1, w1, chain, flags),
+                single_thread_value=b1, scaling_B2_over_B1=b2 / b1, half_threads_value=half,
+                native_build=native is not None, native_results_equal_portable=same,
+                portable_O2_build={"single_thread_value": p1, "value": p2},
+                scaling_note=note, cpu_model=cpu_model(), nproc=os.cpu_count(),
                 reference_volk_path="unavailable (no GNU Radio / VOLK in the image)")
 
 
@@ -288,6 +307,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=4096,
                     help="channels each rank owns (weak scaling); BASELINE config 4 = --gpus 8 --channels-per-gpu 8192")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE config 4's per-GPU shape: 8192 channels per GPU (65536 channels on 8 GPUs); "
+                         "the same as --channels-per-gpu 8192, named in config.workload")
     ap.add_argument("--samples", type=int, default=65536)
     ap.add_argument("--template", choices=["S", "P"], default="S", help="S: stock 896-sample template; P: 112-sample preamble")
     ap.add_argument("--chain", choices=["core", "stock", "corr", "wideband"], default="stock",
@@ -340,6 +362,8 @@ def main():
     if launched and world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
               file=sys.stderr)
+    if args.config4:
+        args.channels_per_gpu = 8192
     sps, T, nchan = 4, args.samples, args.channels_per_gpu
     from ais_amd.shard import max_over_ranks, shard_channels
 
@@ -352,13 +376,16 @@ def main():
         if launched:
             dist.barrier()
         el = max_over_ranks(1e-3 * (1 + rank))
+        el_min = -max_over_ranks(-1e-3 * (1 + rank))
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "complex MS/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "none", "dry": True,
-                              "config": {"workload": "dry run: %d ranks x %d channels, nothing computed" % (world, nchan),
+                              "config": {"workload": "dry run: %d ranks x %d channels%s, nothing computed" % (
+                                  world, nchan, " (BASELINE config 4: %d channels in all)" % (world * nchan) if args.config4 else ""),
                                          "channels_per_gpu": nchan, "parallelism": "channel-sharded x%d, no collective" % world},
-                              "max_over_ranks_check": el}))
+                              "max_over_ranks_check": el,
+                              "rank_ms_per_step": {"min": 1e3 * el_min, "max": 1e3 * el}}))
         if launched:
             dist.barrier()
             dist.destroy_process_group()
@@ -387,90 +414,26 @@ def main():
     def measure(chain, want_parity):
         """K timed steps of `chain` on this rank's channel shard; returns the wall time (max over
         ranks), the correlator kernel's per-launch times inside the timed region and (rank 0) the
-        parity gates of the last step."""
+        parity gates of the last step.  The step is the product's pipelined chain
+        (ais_demod.work_pipelined = aisx_chain_step, include/aisx.h): the sample passes of step k + 1
+        on one stream beside the timing recovery of step k on another, its bit tail and the NCO
+        phase walk of step k + 2 on two more.  This benchmark feeds the same samples every step, so
+        the next step's input is always at hand (x_next = x); a live source runs one block ahead."""
         stock = chain == "stock"
         x = make_input(nchan, T, args.template, sps, device, rank, stock)
         dem = ais_amd.ais_demod(opts, nchan=nchan, max_items=T, stages="stock" if stock else "core",
-                                preamble_symbols=tmpl)
+                                preamble_symbols=tmpl, fused_front_end=True)
         corr = dem.preamble_detect
         corr.set_profiling(True)
-        # preallocated inter-stage buffers, three of each in rotation: the timing recovery of
-        # step k (latency-bound) runs on its own stream under the streaming stages of step k+1;
-        # with a third buffer the streaming stages of step k+2 need not wait for it either
-        # (the two sides take about the same time, and every wait of one for the other adds up)
-        NBUF = 3
-        y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(NBUF)]
-        cap = dem.clockrec.out_capacity
-        outs = [dict(syms=None, bits=torch.empty((nchan, cap), dtype=torch.uint8, device=device),
-                     produced=torch.empty(nchan, dtype=torch.int32, device=device)) for _ in range(NBUF)]
-        # (the stream stages' workgroups go first when LDS / wave slots free up: the estimates of the
-        # next step, on s_pre, take what is left)
-        prio = os.environ.get("AISX_BENCH_PRIO", "0")  # (experiments: 1 = stream stages first, 2 = timing recovery first)
-        s_main = torch.cuda.Stream(device=device, priority=-1 if prio == "1" else 0)
-        s_msk = torch.cuda.Stream(device=device, priority=-1 if prio == "2" else 0)
-        s_tail = torch.cuda.Stream(device=device)  # the bit tail of step k runs beside the recovery of step k+1
-        s_pre = torch.cuda.Stream(device=device)   # NCO phase walk, one step ahead
-        s_est = torch.cuda.Stream(device=device)   # frequency estimates, one step ahead
-        fused = stock and not os.environ.get("AISX_BENCH_UNFUSED")
-        wait_prepass = chain != "corr" and os.environ.get("AISX_BENCH_NO_PREPASS_WAIT") is None
-        if wait_prepass:
-            dem.clockrec.wait_prepass(s_main)  # (arms the event)
-        dem.clockrec.set_tail_stream(s_tail)
-        msk_done = [None] * NBUF
-        state = dict(k=0)
+        y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(2)] if chain == "corr" else None
+        state = dict(k=0, last=None)
 
         def step():
-            k = state["k"]
-            par = k % NBUF
-            with torch.cuda.stream(s_main):
-                if msk_done[par] is not None:
-                    s_main.wait_event(msk_done[par])  # step k-3 released y_corr[par] and its tags
-                y = x
-                if stock:
-                    if fused:
-                        # The frequency estimates and the NCO phase walk of step k + 1 (this benchmark
-                        # feeds the same samples again) are issued BEFORE the front-end pass of step k:
-                        # the estimates on this stream (kernels with large grids are dispatched one
-                        # after the other whatever their streams), the walk -- 2.4 ms of latency on 64
-                        # waves -- on s_pre, beside this step's passes.  Issued behind the pass
-                        # (AISX_BENCH_EST=late) the chain pass(k) -> estimates(k+1) -> walk(k+1) ->
-                        # pass(k+1) is as long as the step and this stream idles 0.5 ms waiting for it.
-                        mode = os.environ.get("AISX_BENCH_EST", "early")
-                        if mode == "early" and T % 1024:
-                            mode = "late"  # (two estimates may wait only behind calls of whole vectors)
-                        if mode == "early":
-                            if k == 0:
-                                dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)  # (for step 0 itself)
-                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
-                        # freq_sync -> agc in one pass over the samples (same results, bit for bit)
-                        y, _ = ais_amd.freq_sync_agc(dem.freq_sync, dem.agc, y)
-                        if mode == "late":
-                            dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
-                        elif mode == "pre":    # estimates and walk on s_pre
-                            with torch.cuda.stream(s_pre):
-                                dem.freq_sync.estimate_ahead(x)
-                        elif mode == "own":    # estimates on a stream of their own, walk on s_pre
-                            with torch.cuda.stream(s_est):
-                                dem.freq_sync.estimate_ahead(x, walk_stream=s_pre)
-                    else:
-                        y, _ = dem.freq_sync.work(y)
-                        y = dem.agc.work(y)
-                o, _ = corr.work(y, out=y_corr[par] if y.shape[1] == T else None)
-                tags_ptrs = corr.tags_device()
-                ready = torch.cuda.Event()
-                ready.record(s_main)
-            if chain != "corr":
-                with torch.cuda.stream(s_msk):
-                    s_msk.wait_event(ready)
-                    dem.clockrec.work(o, tags_ptrs=tags_ptrs, outs=outs[par])
-                    ev = torch.cuda.Event()
-                    ev.record(s_msk)
-                    msk_done[par] = ev
-                if wait_prepass:
-                    # the next step's sample passes start behind this step's tag prepass: the recovery's
-                    # 128 large workgroups are dispatched before thousands of small ones take the LDS
-                    dem.clockrec.wait_prepass(s_main)
-            state["k"] = k + 1
+            if chain == "corr":
+                corr.work(x, out=y_corr[state["k"] & 1])
+            else:
+                state["last"] = dem.work_pipelined(x, x_next=x if stock else None)
+            state["k"] += 1
 
         for _ in range(args.warmup):
             step()
@@ -497,23 +460,31 @@ def main():
             res["ndet"] = int((tags["key"] == 2).sum())
             K = min(args.parity_channels, nchan) if want_parity else 0
             if K > 0:
-                last = (state["k"] - 1) % NBUF
-                gbits = outs[last]["bits"][:K].cpu().numpy() if chain != "corr" else None
-                gprod = outs[last]["produced"][:K].cpu().numpy() if chain != "corr" else None
+                last = state["last"]
+                gbits = last["bits"][:K].cpu().numpy() if chain != "corr" else None
+                gprod = last["produced"][:K].cpu().numpy() if chain != "corr" else None
                 res["parity"] = parity_gates(chain, tmpl, sps, T, args.template, rank, x[:K].cpu().numpy(),
                                              args.warmup + args.steps, tags[tags["chan"] < K], gbits, gprod, corr.threshold())
         barrier()
-        # the same kernel with the chip to itself (no timing-recovery kernel alongside)
+        # the same kernel with the chip to itself (no timing-recovery kernel alongside), on the
+        # data it sees in the chain: behind the front end for the stock chain
+        yin = x
+        if stock:
+            fs2 = ais_amd.square_and_fft_sync_cc(sps * 9600.0, 9600.0, 1024, nchan=nchan, max_items=T)
+            agc2 = ais_amd.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=T + 1024)
+            yin = ais_amd.freq_sync_agc(fs2, agc2, x)[0]
+            del fs2, agc2
+        yout = torch.empty((nchan, T), dtype=torch.complex64, device=device)
         iso = []
         for _ in range(7):
-            with torch.cuda.stream(s_main):
-                corr.work(x if not stock else y_corr[0], out=y_corr[1])
+            corr.work(yin, out=yout)
             iso.append(corr.last_kernel_ms())
         iso = sorted(iso)[1:-1]  # (drop the fastest and the slowest of seven)
         torch.cuda.synchronize()
         res["el"] = max_over_ranks(el, device=device)
+        res["el_min"] = -max_over_ranks(-el, device=device)
         res["iso"] = iso
-        del dem, x, y_corr, outs
+        del dem, x, y_corr, yin, yout
         torch.cuda.empty_cache()
         return res
 
@@ -552,6 +523,15 @@ def main():
     if side and world == 1:
         corr_only = [measure_corr_only(c, f) for c in (256, 4096) for f in ("S", "P")]
 
+    copy_gbs = None
+    if rank == 0 and side:
+        # what a plain 16-byte-per-lane copy sustains on this chip, no profiler attached (2 GiB each way)
+        from ais_amd import _lib as _L
+        import ctypes as _C
+
+        g = _C.c_float(0)
+        if _L.lib().aisx_util_copy_GBs(2 << 30, 10, _C.byref(g)) == 0:
+            copy_gbs = float(g.value)
     if rank == 0:
         total_samples = float(nchan) * T * world * args.steps
         kms = float(np.mean(kern_ms))
@@ -565,14 +545,16 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
+            "rank_ms_per_step": {"min": r["el_min"] / args.steps * 1e3, "max": el / args.steps * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d batched channels/GPU x %d complex samples/step, sps=4, template N=%d (%s), chain=%s"
-                % (nchan, T, tmpl.size, "stock ais_demod.py" if args.template == "S" else "28-symbol preamble",
+                "workload": "%s%d batched channels/GPU x %d complex samples/step, sps=4, template N=%d (%s), chain=%s"
+                % ("BASELINE config 4 (%d channels on %d GPUs): " % (nchan * world, world) if args.config4 else "",
+                   nchan, T, tmpl.size, "stock ais_demod.py" if args.template == "S" else "28-symbol preamble",
                    CHAIN_TEXT[args.chain]),
                 "channels_per_gpu": nchan,
                 "samples_per_step": T,
@@ -585,6 +567,8 @@ def main():
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
+                "copy_ceiling_GBs": copy_gbs,
+                "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
@@ -593,7 +577,8 @@ def main():
                 "kernel_ms_alone": float(np.mean(iso)),
                 "frac_alone": CORR_BYTES_PER_SAMPLE * float(nchan) * T / (float(np.mean(iso)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "kernel_ms is measured over the timed region, where the timing-recovery kernel of the "
-                        "previous step shares the chip; *_alone = same launch with nothing else running",
+                        "previous step shares the chip; *_alone = same launch with nothing else running; copy_ceiling_GBs = "
+                        "read + write rate of a plain float4 copy of 2 GiB on this box (hipEvents, no profiler)",
                 "algorithmic_bytes_per_launch": CORR_BYTES_PER_SAMPLE * float(nchan) * T,
             },
             "parity": r["parity"],

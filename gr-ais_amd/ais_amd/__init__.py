@@ -7,6 +7,13 @@ Mirrors the reference's Python-visible interface for this path
 helper `modulate_vector_bc`.  All signal processing runs in libaisx.so (hand
 written HIP for gfx950, C ABI in include/aisx.h).
 """
+import os as _os
+
+# the pipelined chain (ais_demod.work_pipelined, aisx_chain_*) keeps four streams busy; with the HIP
+# runtime's default of four hardware queues two of them would share one and run in turn.  Read by
+# the runtime at its first call, i.e. after this import.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .framing import hdlc_deframer_bp, pdu_to_nmea  # noqa: F401
 from .modulate import gmsk_mod, modulate_vector_bc  # noqa: F401
 

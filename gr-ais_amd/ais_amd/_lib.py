@@ -53,6 +53,7 @@ def lib():
     sig("aisx_last_error", C.c_char_p, [])
     sig("aisx_device_count", i32, [pi32])
     sig("aisx_set_device", i32, [i32])
+    sig("aisx_util_copy_GBs", i32, [C.c_size_t, i32, C.POINTER(C.c_float)])
     sig("aisx_corr_create", i32, [pvp, vp, i32, f32, u32, f32, i32, i32, i32])
     sig("aisx_corr_destroy", i32, [vp])
     sig("aisx_corr_symbols", i32, [vp, vp, i32])
@@ -103,6 +104,14 @@ def lib():
     sig("aisx_agc_reset", i32, [vp])
     sig("aisx_agc_set_floor", i32, [vp, f32])
     sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
+    sig("aisx_chain_create", i32, [pvp, vp, vp, vp, vp, i32, i32, i32])
+    sig("aisx_chain_destroy", i32, [vp])
+    sig("aisx_chain_depth", i32, [])
+    sig("aisx_chain_step", i32, [vp, vp, lng, i32, vp, lng, i32, vp, vp, lng, vp, vp, C.POINTER(C.c_longlong)])
+    sig("aisx_chain_wait", i32, [vp, C.c_longlong, vp, i32])
+    sig("aisx_chain_wait_input", i32, [vp, C.c_longlong, vp, i32])
+    sig("aisx_chain_synchronize", i32, [vp])
+    sig("aisx_chain_stream", vp, [vp, i32])
     sig("aisx_pfb_create", i32, [pvp, i32, i32, vp, i32, i32, i32])
     sig("aisx_pfb_destroy", i32, [vp])
     sig("aisx_pfb_process", i32, [vp, vp, lng, i32, vp, lng, pi32, vp])

@@ -433,6 +433,8 @@ class ais_demod:
         self._omega_relative_limit = options["omega_relative_limit"]
         self.fftlen = options["fftlen"]
         self.nchan = nchan
+        self._max_items = int(max_items)
+        self._chain = None
         self.stages = stages
         # freq_sync -> agc in one pass (freq_sync_agc): same results, bit for bit; off by default: the
         # separate NCO phase walk it needs is slower than fs_mix's in-kernel one when everything runs
@@ -455,6 +457,72 @@ class ais_demod:
         self.clockrec = msk_timing_recovery_cc(self._samples_per_symbol, self._clockrec_gain,
                                                self._omega_relative_limit, 1, nchan=nchan,
                                                max_items=max_items + self.fftlen)
+
+    # -- pipelined step (aisx_chain_*): the path bench.py times ------------------------------
+    def _chain_handle(self):
+        if getattr(self, "_chain", None) is None:
+            h = C.c_void_p()
+            stock = self.stages == "stock"
+            check(_lib.lib().aisx_chain_create(C.byref(h), self.freq_sync._h if stock else None, self.agc._h if stock else None,
+                                               self.preamble_detect._h, self.clockrec._h, self.nchan, self._max_items,
+                                               self.fftlen if stock else 0), "ais_demod chain")
+            self._chain = h
+            self._chain_outs = []
+            self._chain_step = -1
+        return self._chain
+
+    def __del__(self):
+        h = getattr(self, "_chain", None)
+        if h and _lib is not None:
+            _lib.lib().aisx_chain_destroy(h)  # (before the stage handles it borrows go)
+            self._chain = None
+
+    def work_pipelined(self, x, x_next=None, want_syms=False, outs=None, stream=None):
+        """One step of the pipelined chain (aisx_chain_step) on x[nchan][n]: the same results as work(), bit
+        for bit, with the sample passes of this step running beside the timing recovery of the
+        previous one on the chain's own streams.  `x_next` = the NEXT step's input if it is
+        already on the device (its frequency estimates and NCO phase walk are then prepared
+        during this step; the next call must pass exactly that tensor, unchanged).
+        Returns dict(bits, produced[, syms], step): device tensors that are complete once
+        wait(step) has returned; AISX_CHAIN_DEPTH sets rotate, so a result must be consumed
+        before the call three steps later.  Do not mix with work() on one object."""
+        h = self._chain_handle()
+        x = _dev_c64(x, self.nchan)
+        nx = _dev_c64(x_next, self.nchan) if x_next is not None else None
+        self._chain_keep = (x, nx)  # (the chain reads them asynchronously)
+        cap = self.clockrec.out_capacity
+        if outs is None:
+            depth = _lib.lib().aisx_chain_depth()
+            while len(self._chain_outs) < depth:
+                self._chain_outs.append(dict(
+                    syms=torch.empty((self.nchan, cap), dtype=torch.complex64, device=x.device) if want_syms else None,
+                    bits=torch.empty((self.nchan, cap), dtype=torch.uint8, device=x.device),
+                    produced=torch.empty(self.nchan, dtype=torch.int32, device=x.device)))
+            outs = self._chain_outs[(self._chain_step + 1) % depth]
+            if want_syms and outs["syms"] is None:
+                outs["syms"] = torch.empty((self.nchan, cap), dtype=torch.complex64, device=x.device)
+        syms, bits, prod = outs.get("syms") if want_syms else None, outs["bits"], outs["produced"]
+        step = C.c_longlong(0)
+        check(_lib.lib().aisx_chain_step(
+            h, x.data_ptr(), x.stride(0), x.shape[1], nx.data_ptr() if nx is not None else None,
+            nx.stride(0) if nx is not None else 0, nx.shape[1] if nx is not None else 0,
+            syms.data_ptr() if syms is not None else None, bits.data_ptr(), bits.stride(0), prod.data_ptr(),
+            _stream_ptr(stream), C.byref(step)), "ais_demod.work_pipelined")
+        self._chain_step = step.value
+        return dict(bits=bits, produced=prod, syms=syms, step=step.value)
+
+    def wait(self, step=None, stream=None, host=False):
+        """`stream` (default: the current one) -- or the calling thread with host=True -- waits for the
+        outputs of `step` (default: the last one issued)."""
+        check(_lib.lib().aisx_chain_wait(self._chain_handle(), self._chain_step if step is None else step,
+                                         None if host else _stream_ptr(stream), 1 if host else 0), "ais_demod.wait")
+
+    def synchronize(self):
+        check(_lib.lib().aisx_chain_synchronize(self._chain_handle()), "ais_demod.synchronize")
+
+    def chain_stream(self, which):
+        """the chain's streams as raw hipStream_t values: 0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk"""
+        return _lib.lib().aisx_chain_stream(self._chain_handle(), which)
 
     def work(self, x, want_syms=False, stream=None):
         """One chain step on x[nchan][n].  Returns dict(bits, produced[, syms])."""

@@ -1,0 +1,266 @@
+// aisx_chain.hip -- C ABI (include/aisx.h) of the pipelined demod chain: the connect order of
+// python/ais_demod.py:56 (freq_sync -> agc -> corr_est -> msk timing recovery -> NRZI bit tail)
+// driven as one call per step over the stage handles, with the stream / event / buffer
+// choreography that makes the stages of neighbouring steps overlap.
+// Host code only: every kernel is launched through the stages' own entry points.
+#include <stdlib.h>
+
+#include "aisx_host.h"
+
+using namespace aisx;
+
+struct aisx_chain {
+    aisx_freqsync* fs = nullptr; // borrowed; null = core chain (corr_est -> msk only)
+    aisx_agc* agc = nullptr;     // borrowed
+    aisx_corr* corr = nullptr;   // borrowed
+    aisx_msk* msk = nullptr;     // borrowed
+    int nchan = 0, max_items = 0, fftlen = 0;
+    int serial = 0; // AISX_CHAIN_SERIAL: every stage on s_main (A/B runs)
+    // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead
+    hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr;
+    static constexpr int NBUF = AISX_CHAIN_DEPTH;
+    cf* d_y = nullptr; // front-end output (stock chain): one buffer, written and read on s_main
+    long y_stride = 0;
+    cf* d_yc[NBUF] = {}; // corr_est's delayed output, read by the recovery of the same step on s_msk
+    long yc_stride = 0;
+    hipEvent_t ev_in = nullptr;
+    hipEvent_t ev_ready[NBUF] = {};    // s_main: the step's sample passes and tags are done (its input is free)
+    hipEvent_t ev_msk_done[NBUF] = {}; // s_msk: the step's recovery has read d_yc[par] and its tags
+    hipEvent_t ev_done[NBUF] = {};     // the step's outputs are complete (bit tail included)
+    long long nsteps = 0;
+    int npend = 0; // items the front end holds back (n % fftlen arithmetic of stream_to_vector)
+    // what aisx_freqsync_estimate_ahead was last asked to prepare and has not been consumed yet
+    const void* ahead_in = nullptr;
+    long ahead_stride = 0;
+    int ahead_n = 0;
+};
+
+static void chain_free(aisx_chain* h)
+{
+    if (!h)
+        return;
+    if (h->msk)
+        (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
+        if (s)
+            (void)hipStreamSynchronize(s);
+    dev_free(h->d_y);
+    for (int k = 0; k < aisx_chain::NBUF; k++) {
+        dev_free(h->d_yc[k]);
+        for (hipEvent_t e : { h->ev_ready[k], h->ev_msk_done[k], h->ev_done[k] })
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+    if (h->ev_in)
+        (void)hipEventDestroy(h->ev_in);
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
+        if (s)
+            (void)hipStreamDestroy(s);
+    delete h;
+}
+
+extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* agc, aisx_corr* corr, aisx_msk* msk,
+                                 int nchan, int max_items, int fftlen)
+{
+    if (!out)
+        return AISX_ERR_INVALID;
+    *out = nullptr;
+    if (!corr || !msk || (fs == nullptr) != (agc == nullptr) || nchan < 1 || max_items < 1 || (fs && fftlen < 1)) {
+        set_err("aisx_chain_create: needs corr_est and msk handles, freq_sync and agc both or neither");
+        return AISX_ERR_INVALID;
+    }
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    aisx_chain* h = new aisx_chain();
+    h->fs = fs;
+    h->agc = agc;
+    h->corr = corr;
+    h->msk = msk;
+    h->nchan = nchan;
+    h->max_items = max_items;
+    h->fftlen = fs ? fftlen : 0;
+    if (const char* e = getenv("AISX_CHAIN_SERIAL"))
+        h->serial = atoi(e) != 0;
+#define CKH(e)                                                                                     \
+    do {                                                                                           \
+        hipError_t e__ = (e);                                                                      \
+        if (e__ != hipSuccess) {                                                                   \
+            set_err("aisx_chain_create: %s failed: %s", #e, hipGetErrorString(e__));               \
+            chain_free(h);                                                                         \
+            return AISX_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+    for (hipStream_t* s : { &h->s_main, &h->s_msk, &h->s_tail, &h->s_walk })
+        CKH(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    CKH(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    for (int k = 0; k < aisx_chain::NBUF; k++) {
+        CKH(hipEventCreateWithFlags(&h->ev_ready[k], hipEventDisableTiming));
+        CKH(hipEventCreateWithFlags(&h->ev_msk_done[k], hipEventDisableTiming));
+        CKH(hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming));
+    }
+#undef CKH
+    // a step's front end emits every complete fftlen-vector of (pending + new) items
+    const long cap = (long)max_items + h->fftlen;
+    h->y_stride = h->yc_stride = (cap + 1) & ~1L; // rows 16-byte aligned
+    if (fs && (rc = dev_alloc(&h->d_y, (size_t)nchan * h->y_stride, false)) != AISX_OK) {
+        chain_free(h);
+        return rc;
+    }
+    for (int k = 0; k < aisx_chain::NBUF; k++)
+        if ((rc = dev_alloc(&h->d_yc[k], (size_t)nchan * h->yc_stride, false)) != AISX_OK) {
+            chain_free(h);
+            return rc;
+        }
+    if (!h->serial) {
+        // the bit tail of step k beside the recovery of step k + 1; the next step's sample passes
+        // behind this step's tag prepass (aisx_msk_wait_prepass: the first call arms the event)
+        if ((rc = aisx_msk_set_tail_stream(msk, h->s_tail, 1)) != AISX_OK || (rc = aisx_msk_wait_prepass(msk, h->s_main)) != AISX_OK) {
+            chain_free(h);
+            return rc;
+        }
+    }
+    *out = h;
+    return AISX_OK;
+}
+
+extern "C" int aisx_chain_destroy(aisx_chain* h)
+{
+    chain_free(h);
+    return AISX_OK;
+}
+
+extern "C" int aisx_chain_depth(void) { return aisx_chain::NBUF; }
+
+extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next,
+                               long next_stride, int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride,
+                               int* d_produced, void* stream, long long* step)
+{
+    if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n || !d_produced ||
+        (d_in_next && (n_next < 1 || n_next > h->max_items || next_stride < n_next))) {
+        set_err("aisx_chain_step: bad argument (n = %d, max_items = %d)", n, h ? h->max_items : -1);
+        return AISX_ERR_INVALID;
+    }
+    int rc;
+    const int par = (int)(h->nsteps % aisx_chain::NBUF);
+    hipStream_t sm = h->s_main, sk = h->serial ? h->s_main : h->s_msk;
+    // the caller's stream has produced d_in (and d_in_next)
+    AISX_HIPCHK(hipEventRecord(h->ev_in, (hipStream_t)stream));
+    AISX_HIPCHK(hipStreamWaitEvent(sm, h->ev_in, 0));
+    if (h->nsteps >= aisx_chain::NBUF) // step k - NBUF has released d_yc[par] and its tags
+        AISX_HIPCHK(hipStreamWaitEvent(sm, h->ev_msk_done[par], 0));
+
+    const cf* y = (const cf*)d_in;
+    long ys = in_stride;
+    int m = n;
+    if (h->fs) {
+        // The frequency estimates and the NCO phase walk of step k + 1 are issued BEFORE the
+        // front-end pass of step k when two preparations may wait (whole vectors, nothing pending):
+        // the estimates on s_main (kernels with large grids are dispatched one after the other
+        // whatever their streams), the walk -- a strict recurrence, one lane per channel -- on
+        // s_walk, beside this step's sample passes.  Otherwise behind the pass.
+        const bool prepared = h->ahead_in == (const void*)d_in && h->ahead_stride == in_stride && h->ahead_n == n;
+        const bool early = !h->serial && h->npend == 0 && n % h->fftlen == 0;
+        hipStream_t sw = h->serial ? sm : h->s_walk;
+        if (early) {
+            if (!prepared && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in, in_stride, n, sm, sw)) != AISX_OK)
+                return rc;
+            if (d_in_next && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, sm, sw)) != AISX_OK)
+                return rc;
+        }
+        int nout = 0;
+        if ((rc = aisx_freqsync_agc_process(h->fs, h->agc, d_in, in_stride, n, (aisx_cf32*)h->d_y, h->y_stride, nullptr, 0, &nout,
+                                            sm)) != AISX_OK)
+            return rc;
+        h->npend = h->npend + n - nout;
+        h->ahead_in = nullptr;
+        if (!early && !h->serial && d_in_next &&
+            (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, sm, sw)) != AISX_OK)
+            return rc;
+        if (d_in_next && !h->serial) {
+            h->ahead_in = d_in_next;
+            h->ahead_stride = next_stride;
+            h->ahead_n = n_next;
+        }
+        y = h->d_y;
+        ys = h->y_stride;
+        m = nout;
+    }
+    if (m == 0) { // not one whole vector yet: nothing reaches the correlator (stream_to_vector holds the items)
+        AISX_HIPCHK(hipMemsetAsync(d_produced, 0, sizeof(int) * h->nchan, sm));
+        AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
+        AISX_HIPCHK(hipEventRecord(h->ev_msk_done[par], sm));
+        AISX_HIPCHK(hipEventRecord(h->ev_done[par], sm));
+    } else {
+        if ((rc = aisx_corr_process(h->corr, (const aisx_cf32*)y, ys, (aisx_cf32*)h->d_yc[par], h->yc_stride, nullptr, 0, m, sm)) != AISX_OK)
+            return rc;
+        const aisx_tag* tags = nullptr;
+        const int* counts = nullptr;
+        int tcap = 0;
+        if ((rc = aisx_corr_tags_device(h->corr, &tags, &counts, &tcap)) != AISX_OK)
+            return rc;
+        AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
+        if (sk != sm)
+            AISX_HIPCHK(hipStreamWaitEvent(sk, h->ev_ready[par], 0));
+        if ((rc = aisx_msk_process_stream(h->msk, (const aisx_cf32*)h->d_yc[par], h->yc_stride, m, tags, counts, tcap, d_syms, nullptr,
+                                          nullptr, d_bits, out_stride, d_produced, sk)) != AISX_OK)
+            return rc;
+        AISX_HIPCHK(hipEventRecord(h->ev_msk_done[par], sk));
+        // the bit tail (if any) was queued on s_tail behind the recovery
+        AISX_HIPCHK(hipEventRecord(h->ev_done[par], (d_bits && !h->serial) ? h->s_tail : sk));
+        if (!h->serial && (rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
+            return rc;
+    }
+    if (step)
+        *step = h->nsteps;
+    h->nsteps++;
+    return AISX_OK;
+}
+
+static int chain_wait_event(aisx_chain* h, long long step, void* stream, bool have_stream, hipEvent_t* evs, const char* what)
+{
+    if (!h || step < 0 || step >= h->nsteps) {
+        set_err("%s: step %lld has not been issued", what, step);
+        return AISX_ERR_INVALID;
+    }
+    // (an event already reused by a later step of the same parity completes behind the step asked
+    // for: waiting for it is still correct)
+    hipEvent_t e = evs[step % aisx_chain::NBUF];
+    if (have_stream)
+        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    else
+        AISX_HIPCHK(hipEventSynchronize(e));
+    return AISX_OK;
+}
+
+extern "C" int aisx_chain_wait(aisx_chain* h, long long step, void* stream, int host_blocks)
+{
+    return chain_wait_event(h, step, stream, !host_blocks, h ? h->ev_done : nullptr, "aisx_chain_wait");
+}
+
+extern "C" int aisx_chain_wait_input(aisx_chain* h, long long step, void* stream, int host_blocks)
+{
+    return chain_wait_event(h, step, stream, !host_blocks, h ? h->ev_ready : nullptr, "aisx_chain_wait_input");
+}
+
+extern "C" int aisx_chain_synchronize(aisx_chain* h)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail })
+        AISX_HIPCHK(hipStreamSynchronize(s));
+    return AISX_OK;
+}
+
+extern "C" void* aisx_chain_stream(aisx_chain* h, int which)
+{
+    if (!h)
+        return nullptr;
+    switch (which) {
+    case 0: return (void*)h->s_main;
+    case 1: return (void*)h->s_msk;
+    case 2: return (void*)h->s_tail;
+    case 3: return (void*)h->s_walk;
+    default: return nullptr;
+    }
+}

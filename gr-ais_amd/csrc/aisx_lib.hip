@@ -106,6 +106,56 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 }
 
 // ---------------------------------------------------------------------------
+// measurement hook: what a plain copy sustains on this chip (16 bytes per lane and access,
+// grid-stride, no profiler attached) -- the practical ceiling next to the 8 TB/s spec peak the
+// correlator's roofline fraction is quoted against
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        dst[i] = src[i];
+}
+
+extern "C" int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs)
+{
+    if (!GBs || bytes < (1u << 20) || iters < 1)
+        return AISX_ERR_INVALID;
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto done = [&](int r) {
+        dev_free(a);
+        dev_free(b);
+        if (e0)
+            (void)hipEventDestroy(e0);
+        if (e1)
+            (void)hipEventDestroy(e1);
+        return r;
+    };
+    if ((rc = dev_alloc(&a, n)) != AISX_OK || (rc = dev_alloc(&b, n, false)) != AISX_OK)
+        return done(rc);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return done(AISX_ERR_HIP);
+    const int grid = 256 * 16; // 16 workgroups of four waves per CU
+    for (int k = 0; k < 2; k++)
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, a, b, n);
+    if (hipEventRecord(e0, 0) != hipSuccess)
+        return done(AISX_ERR_HIP);
+    for (int k = 0; k < iters; k++)
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, a, b, n);
+    float ms = 0.f;
+    if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+        !(ms > 0.f))
+        return done(AISX_ERR_HIP);
+    *GBs = (float)(2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9); // bytes read + bytes written
+    return done(AISX_OK);
+}
+
+// ---------------------------------------------------------------------------
 // corr_est_cc
 // ---------------------------------------------------------------------------
 struct aisx_corr {

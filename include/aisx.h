@@ -21,13 +21,14 @@
 #ifndef AISX_H
 #define AISX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define AISX_VERSION 210
+#define AISX_VERSION 300
 
 /* gr_complex = std::complex<float>: interleaved re, im */
 typedef struct aisx_cf32 { float re, im; } aisx_cf32;
@@ -63,6 +64,11 @@ int aisx_version(void);
 const char* aisx_last_error(void);
 int aisx_device_count(int* count);
 int aisx_set_device(int device);
+/* measurement hook (bench.py's "copy_ceiling"): the rate, in GB/s of bytes read + bytes written,
+ * a plain 16-bytes-per-lane device copy of `bytes` bytes sustains over `iters` launches, timed
+ * with hipEvents and no profiler attached: what "HBM-bound" can mean on this chip next to the
+ * 8 TB/s spec peak */
+int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs);
 
 /* ------------------------------------------------------------------------ */
 /* corr_est_cc  (include/ais/corr_est_cc.h:85-106, lib/corr_est_cc_impl.cc)  */
@@ -278,6 +284,55 @@ int aisx_freqsync_estimate_ahead(aisx_freqsync* fs, const aisx_cf32* d_in, long 
  * a sync_block with set_history(nsamples): nsamples - 1 old items, then noutput_items new ones.
  * Returns noutput_items or a negative status. */
 int aisx_agc_work_host(aisx_agc* h, int noutput_items, const aisx_cf32* in, aisx_cf32* out);
+
+/* ------------------------------------------------------------------------ */
+/* ais_demod (python/ais_demod.py:21-56): the demod chain as ONE pipelined    */
+/* step per batch of new samples, over the stage handles above                */
+/* ------------------------------------------------------------------------ */
+typedef struct aisx_chain aisx_chain;
+#define AISX_CHAIN_DEPTH 3 /* steps in flight: buffers and events rotate through this many sets */
+/* The connect order of python/ais_demod.py:56 -- freq_sync -> agc -> (preamble_detect, 0) ->
+ * clockrec -> demod -> slicer -> diff -> invert -- over handles the caller has built with that
+ * file's constants (:28-47): fs = aisx_freqsync_create(sps * bits_per_sec, bits_per_sec, fftlen),
+ * agc = aisx_agc_create(512, 2), corr = aisx_corr_create(template, sps, 1, 0.9), msk =
+ * aisx_msk_create(sps, clockrec_gain, omega_relative_limit, 1), the last three sized for
+ * max_items + fftlen items per call.  fs = agc = NULL gives the chain BASELINE.json's metric
+ * names (corr_est -> msk timing recovery only).  The handles stay the caller's (tags, status,
+ * setters, profiling go through them) and must outlive the chain; while a chain drives them
+ * they must not be called directly.
+ * The chain owns four streams, AISX_CHAIN_DEPTH sets of inter-stage buffers and the events that
+ * order them: the sample passes of step k + 1 (one stream) run beside the timing recovery of step
+ * k (a strict recurrence per channel, on its own stream), its bit tail and the NCO phase walk of
+ * step k + 2 (two more).  Results are those of the stages called one after the other, bit for
+ * bit.  The HIP runtime shares hardware queues between streams unless GPU_MAX_HW_QUEUES >= 8 is
+ * in the environment before the first HIP call (the Python package sets it on import). */
+int aisx_chain_create(aisx_chain** h, aisx_freqsync* fs, aisx_agc* agc, aisx_corr* corr, aisx_msk* msk, int nchan,
+                      int max_items, int fftlen);
+int aisx_chain_destroy(aisx_chain* h); /* waits for the steps in flight; the stage handles are not destroyed */
+int aisx_chain_depth(void);            /* AISX_CHAIN_DEPTH */
+/* One step: d_in [nchan][in_stride] holds n new items per channel, ready on `stream` (the chain's
+ * streams wait for what `stream` has queued so far).  Outputs as in aisx_msk_process_stream:
+ * d_syms (optional), d_bits (optional) [nchan][out_stride], d_produced [nchan]; they are complete
+ * when aisx_chain_wait(step) says so, and every step in flight needs its own set (rotate through
+ * AISX_CHAIN_DEPTH of them).  *step (optional) receives the step's number, counted from 0.
+ * d_in_next / next_stride / n_next (optional): the input of the NEXT step, if it is already in
+ * device memory: its frequency estimates and NCO phase walk are then prepared during this step
+ * (aisx_freqsync_estimate_ahead).  The next call must come with exactly that pointer, stride and
+ * count, and the samples must not change in between -- a live source therefore runs one buffer
+ * ahead: step k is issued when block k + 1 has arrived.  Without it (NULL) every step estimates
+ * for itself: same results, the phase walk (~2 ms at 65536 items) no longer hidden.
+ * d_in may be reused once aisx_chain_wait_input(step) has passed (d_in_next: its own step's). */
+int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next,
+                    long next_stride, int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride, int* d_produced,
+                    void* stream, long long* step);
+/* `stream` (host_blocks == 0) or the calling thread (host_blocks != 0) waits until the outputs of
+ * `step` are complete / until its input buffer has been read for the last time */
+int aisx_chain_wait(aisx_chain* h, long long step, void* stream, int host_blocks);
+int aisx_chain_wait_input(aisx_chain* h, long long step, void* stream, int host_blocks);
+int aisx_chain_synchronize(aisx_chain* h); /* everything issued so far has run */
+/* the chain's streams (0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk), e.g. to
+ * read a stage handle's results in order with the step that produced them */
+void* aisx_chain_stream(aisx_chain* h, int which);
 
 /* ------------------------------------------------------------------------ */
 /* wideband front end (BASELINE config 5; reference analogue: one             */

@@ -141,6 +141,13 @@ int orc_firdes_low_pass(double gain, double fs, double cutoff, double transition
 long orc_demod_bench_mt(int nthreads, float sps, const orc_cf *symbols, int nsym, int stages, const orc_cf *x, int nx,
                         int nsets, double budget_s, double *wall_s);
 
+/* FNV-1a hash over the bits and tags one channel produces (one orc_demod_step of nx samples on a
+ * fresh chain): bench.py holds the timing build of this file (other compiler flags, see Makefile)
+ * to the results of the portable build with it. */
+uint64_t orc_demod_hash(float sps, const orc_cf *symbols, int nsym, int stages, const orc_cf *x, int nx);
+/* returns the calling thread's kept work buffers to the C library */
+void orc_pool_release(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,8 @@ def lib():
         L.orc_demod_step.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, pi32]
         L.orc_demod_bench_mt.restype = C.c_long
         L.orc_demod_bench_mt.argtypes = [i32, f32, vp, i32, i32, vp, i32, i32, f64, C.POINTER(C.c_double)]
+        L.orc_demod_hash.restype = u64
+        L.orc_demod_hash.argtypes = [f32, vp, i32, i32, vp, i32]
         L.orc_hdlc_init.argtypes = [vp, i32, i32]
         L.orc_hdlc_work.restype = i32
         L.orc_hdlc_work.argtypes = [vp, vp, i32, vp, i32, vp, i32]
@@ -372,14 +374,38 @@ class Demod:
         return bits[:nb].copy(), (syms[:nb].copy() if want_syms else None), tags[: min(nt.value, maxt)].copy()
 
 
-def demod_bench_mt(nthreads, sps, symbols, stages, xs, budget_s):
-    """CPU baseline B2: (channels completed, wall seconds) of `nthreads` C threads running whole
+def build_native(out_path):
+    """The CPU-baseline build of the same C file, compiled on THIS host with -O3 -march=native
+    (oracle/Makefile `native`); returns a ctypes handle with the timing entry points, or None if
+    the host has no working compiler."""
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "native", "OUT=%s" % out_path],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(out_path)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    vp, i32, f32, f64, u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uint64
+    L.orc_demod_bench_mt.restype = C.c_long
+    L.orc_demod_bench_mt.argtypes = [i32, f32, vp, i32, i32, vp, i32, i32, f64, C.POINTER(C.c_double)]
+    L.orc_demod_hash.restype = u64
+    L.orc_demod_hash.argtypes = [f32, vp, i32, i32, vp, i32]
+    return L
+
+
+def demod_hash(sps, symbols, stages, x, L=None):
+    """FNV-1a over the bits and tags of one channel through a fresh chain (orc_demod_hash)"""
+    s, a = _c64(symbols), _c64(x)
+    return int((L or lib()).orc_demod_hash(float(sps), _ptr(s), s.size, int(stages), _ptr(a), a.size))
+
+
+def demod_bench_mt(nthreads, sps, symbols, stages, xs, budget_s, L=None):
+    """CPU baseline: (channels completed, wall seconds) of `nthreads` C threads running whole
     channels (rows of xs) through the oracle chain for ~budget_s seconds."""
     s = _c64(symbols)
     x = np.ascontiguousarray(xs, dtype=np.complex64)
     wall = C.c_double(0)
-    done = lib().orc_demod_bench_mt(int(nthreads), float(sps), _ptr(s), s.size, int(stages), _ptr(x), x.shape[1], x.shape[0],
-                                    float(budget_s), C.byref(wall))
+    done = (L or lib()).orc_demod_bench_mt(int(nthreads), float(sps), _ptr(s), s.size, int(stages), _ptr(x), x.shape[1],
+                                           x.shape[0], float(budget_s), C.byref(wall))
     return int(done), wall.value
 
 

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(libpath):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     L.aisx_version.restype = C.c_int
-    assert L.aisx_version() == 210
+    assert L.aisx_version() == 300
 
 
 def test_binding_matches_header(libpath):

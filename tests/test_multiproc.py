@@ -106,6 +106,13 @@ def test_bench_launcher_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["dry"] is True and line["scaling"] == "weak"
     assert line["config"]["channels_per_gpu"] == 8192 and line["max_over_ranks_check"] == 2e-3
+    # BASELINE config 4 as one flag, four ranks: 8192 channels each, named in the workload
+    out4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry", "--config4"],
+                          env=env, capture_output=True, text=True, timeout=300)
+    assert out4.returncode == 0, out4.stderr[-2000:]
+    l4 = json.loads([ln for ln in out4.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l4["n_gpus"] == 4 and l4["config"]["channels_per_gpu"] == 8192 and "config 4" in l4["config"]["workload"]
+    assert l4["max_over_ranks_check"] == 4e-3 and l4["rank_ms_per_step"] == {"min": 1.0, "max": 4.0}
     # one rank, no launcher
     out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry"], env=env, capture_output=True, text=True,
                           timeout=300)
