@@ -71,6 +71,7 @@ def lib():
     sig("aisx_corr_kernel_ms_history", i32, [vp, C.POINTER(C.c_float), i32, pi32])
     sig("aisx_corr_tags_device", i32, [vp, pvp, pvp, pi32])
     sig("aisx_corr_read_tags", i32, [vp, vp, i32, pi32, vp])
+    sig("aisx_corr_read_tags_back", i32, [vp, i32, vp, i32, pi32, vp])
     sig("aisx_corr_work_host", i32, [vp, vp, vp, vp, i32, u64, vp, i32, pi32])
     sig("aisx_msk_create", i32, [pvp, f32, f32, f32, i32, i32, i32])
     sig("aisx_msk_destroy", i32, [vp])
@@ -111,6 +112,7 @@ def lib():
     sig("aisx_chain_wait", i32, [vp, C.c_longlong, vp, i32])
     sig("aisx_chain_wait_input", i32, [vp, C.c_longlong, vp, i32])
     sig("aisx_chain_synchronize", i32, [vp])
+    sig("aisx_chain_read_corr_output", i32, [vp, C.c_longlong, i32, i32, vp, lng, pi32, vp])
     sig("aisx_chain_stream", vp, [vp, i32])
     sig("aisx_pfb_create", i32, [pvp, i32, i32, vp, i32, i32, i32])
     sig("aisx_pfb_destroy", i32, [vp])

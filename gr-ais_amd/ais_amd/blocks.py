@@ -123,12 +123,14 @@ class corr_est_cc:
         check(_lib.lib().aisx_corr_tags_device(self._h, C.byref(t), C.byref(c), C.byref(cap)), "tags_device")
         return t, c, cap.value
 
-    def tags(self, stream=None, allow_overflow=False):
-        """Host copy of the last call's tags: structured array (offset,value,key,chan)."""
+    def tags(self, stream=None, allow_overflow=False, back=0):
+        """Host copy of the last call's tags (back = 1, 2: of the call before / two before):
+        structured array (offset,value,key,chan)."""
         cap = self.nchan * self._cap
         buf = np.zeros(cap, dtype=TAG_DTYPE)
         nt = C.c_int(0)
-        rc = _lib.lib().aisx_corr_read_tags(self._h, buf.ctypes.data_as(C.c_void_p), cap, C.byref(nt), _stream_ptr(stream))
+        rc = _lib.lib().aisx_corr_read_tags_back(self._h, int(back), buf.ctypes.data_as(C.c_void_p), cap, C.byref(nt),
+                                                 _stream_ptr(stream))
         if not (allow_overflow and rc == _lib.AISX_ERR_OVERFLOW):
             check(rc, "corr_est_cc.tags")
         return buf[: nt.value].copy()
@@ -519,6 +521,15 @@ class ais_demod:
 
     def synchronize(self):
         check(_lib.lib().aisx_chain_synchronize(self._chain_handle()), "ais_demod.synchronize")
+
+    def corr_output(self, step, chan0=0, nch=None, stream=None):
+        """corr_est's delayed output of `step` (one of the last AISX_CHAIN_DEPTH), rows chan0 .. chan0 + nch - 1"""
+        nch = self.nchan - chan0 if nch is None else nch
+        out = torch.empty((nch, self._max_items + self.fftlen), dtype=torch.complex64, device="cuda")
+        n = C.c_int(0)
+        check(_lib.lib().aisx_chain_read_corr_output(self._chain_handle(), step, chan0, nch, out.data_ptr(), out.stride(0),
+                                                     C.byref(n), _stream_ptr(stream)), "ais_demod.corr_output")
+        return out[:, : n.value]
 
     def chain_stream(self, which):
         """the chain's streams as raw hipStream_t values: 0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk"""

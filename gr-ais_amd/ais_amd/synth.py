@@ -146,6 +146,60 @@ def make_channel(seed, T, family="P", sps=4, amp=1.0, p_occ=0.5, ebn0_db=20.0, c
     return x.astype(np.complex64), infos
 
 
+def make_wideband(seed, nframes, lanes, fs=25e6, nlanes=1024, decim=512, amp=1.0, bursts_per_lane=3, cfo_max=300.0,
+                  noise_sigma=1.0, gen_osf=40, group_delay=30113, tail_frames=1400):
+    """BASELINE config 5's input: one wideband stream of nframes * decim samples at `fs` carrying
+    family-S bursts (9600 baud GMSK, the stock 224-symbol sync segment) on the channel centres
+    m * fs / nlanes of the given lanes, plus white noise.  Every burst is generated at gen_osf
+    samples per symbol and carried to the wideband rate by interpolating its phase and envelope
+    (constant-envelope CPM: both are smooth).  Bursts are placed so that, behind a channel filter
+    of the given group delay, they end tail_frames items before the end of their lane's nframes
+    output items (corr_est delays the stream by its template length before the bits come out).
+    cfo_max: one bound for all lanes or {lane: bound}.
+    Returns (complex64[nframes * decim], {lane: [burst info with 'start' in lane items]})."""
+    rng = np.random.default_rng(seed)
+    n = nframes * decim
+    x = np.zeros(n, dtype=np.complex128)
+    sps_w = fs / FS_BAUD  # wideband samples per symbol
+    infos = {}
+    for m in lanes:
+        infos[m] = []
+        f0 = m * fs / nlanes
+        if f0 >= fs / 2:
+            f0 -= fs
+        seg = (n - group_delay - tail_frames * decim) // bursts_per_lane
+        for b in range(bursts_per_lane):
+            iq, info = make_burst(rng, "S", gen_osf, osf_mult=1)
+            dur = int(info["nsyms"] * sps_w)
+            if dur + 64 * decim > seg:
+                raise ValueError("make_wideband: %d bursts of ~%d samples do not fit %d frames" % (bursts_per_lane, dur, nframes))
+            lo = b * seg + int(rng.integers(0, max(1, seg - dur - 64 * decim)))
+            t = np.arange(dur)
+            tg = t * (gen_osf / sps_w)  # position on the generator's grid
+            ph = np.interp(tg, np.arange(iq.size), np.unwrap(np.angle(iq)))
+            env = np.interp(tg, np.arange(iq.size), np.abs(iq))
+            cm = cfo_max[m] if isinstance(cfo_max, dict) else cfo_max
+            cfo = rng.uniform(-cm, cm)
+            ph0 = rng.uniform(-np.pi, np.pi)
+            x[lo:lo + dur] += amp * env * np.exp(1j * (ph + 2 * np.pi * ((f0 + cfo) / fs) * (lo + t) + ph0))
+            info.update(start=(lo + group_delay) / decim, cfo=cfo, phase=ph0, amp=amp, lane=m)
+            infos[m].append(info)
+    if noise_sigma > 0:
+        x += rng.normal(0, noise_sigma / np.sqrt(2), n) + 1j * rng.normal(0, noise_sigma / np.sqrt(2), n)
+    return x.astype(np.complex64), infos
+
+
+def resampled_template(template_hi, osf_hi, sps):
+    """The stock template, generated at osf_hi samples per symbol (modulate_vector_bc(gmsk_mod(osf_hi),
+    ...)), carried to a fractional `sps` by interpolating its phase: what a receiver whose channel
+    rate is not a whole multiple of the baud rate correlates against (corr_est_cc takes the template
+    as an argument, lib/corr_est_cc_impl.cc:48-63)."""
+    t = np.asarray(template_hi, dtype=np.complex128)
+    n = int(np.floor(t.size / osf_hi * sps))
+    ph = np.interp(np.arange(n) * (osf_hi / sps), np.arange(t.size), np.unwrap(np.angle(t)))
+    return np.exp(1j * ph).astype(np.complex64)
+
+
 def make_batch(nchan, T, family="P", sps=4, seed0=SEED0, **kw):
     """[nchan][T] complex64, channel-major, plus per-channel burst infos."""
     out = np.zeros((nchan, T), dtype=np.complex64)

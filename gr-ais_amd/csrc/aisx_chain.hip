@@ -28,6 +28,7 @@ struct aisx_chain {
     hipEvent_t ev_msk_done[NBUF] = {}; // s_msk: the step's recovery has read d_yc[par] and its tags
     hipEvent_t ev_done[NBUF] = {};     // the step's outputs are complete (bit tail included)
     long long nsteps = 0;
+    int m_of[NBUF] = {}; // items the correlator wrote per row in the step that owns d_yc[k]
     int npend = 0; // items the front end holds back (n % fftlen arithmetic of stream_to_vector)
     // what aisx_freqsync_estimate_ahead was last asked to prepare and has not been consumed yet
     const void* ahead_in = nullptr;
@@ -160,7 +161,10 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         // whatever their streams), the walk -- a strict recurrence, one lane per channel -- on
         // s_walk, beside this step's sample passes.  Otherwise behind the pass.
         const bool prepared = h->ahead_in == (const void*)d_in && h->ahead_stride == in_stride && h->ahead_n == n;
-        const bool early = !h->serial && h->npend == 0 && n % h->fftlen == 0;
+        // (a preparation for other arguments is still queued in the freq_sync handle: the pass below
+        // drops it and estimates for itself; nothing may be queued behind it before that)
+        const bool stale = h->ahead_in != nullptr && !prepared;
+        const bool early = !h->serial && !stale && h->npend == 0 && n % h->fftlen == 0;
         hipStream_t sw = h->serial ? sm : h->s_walk;
         if (early) {
             if (!prepared && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in, in_stride, n, sm, sw)) != AISX_OK)
@@ -211,6 +215,7 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         if (!h->serial && (rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
             return rc;
     }
+    h->m_of[par] = m;
     if (step)
         *step = h->nsteps;
     h->nsteps++;
@@ -241,6 +246,27 @@ extern "C" int aisx_chain_wait(aisx_chain* h, long long step, void* stream, int 
 extern "C" int aisx_chain_wait_input(aisx_chain* h, long long step, void* stream, int host_blocks)
 {
     return chain_wait_event(h, step, stream, !host_blocks, h ? h->ev_ready : nullptr, "aisx_chain_wait_input");
+}
+
+extern "C" int aisx_chain_read_corr_output(aisx_chain* h, long long step, int chan0, int nch, aisx_cf32* d_dst, long dst_stride,
+                                           int* n, void* stream)
+{
+    if (!h || step < 0 || step >= h->nsteps || h->nsteps - step > aisx_chain::NBUF || chan0 < 0 || nch < 1 ||
+        chan0 + nch > h->nchan || !d_dst) {
+        set_err("aisx_chain_read_corr_output: step %lld is not among the last %d, or bad channel range", step, aisx_chain::NBUF);
+        return AISX_ERR_INVALID;
+    }
+    const int par = (int)(step % aisx_chain::NBUF), m = h->m_of[par];
+    if (n)
+        *n = m;
+    if (m == 0)
+        return AISX_OK;
+    if (dst_stride < m)
+        return AISX_ERR_INVALID;
+    AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_ready[par], 0));
+    AISX_HIPCHK(hipMemcpy2DAsync(d_dst, sizeof(cf) * dst_stride, h->d_yc[par] + (size_t)chan0 * h->yc_stride, sizeof(cf) * h->yc_stride,
+                                 sizeof(cf) * m, nch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AISX_OK;
 }
 
 extern "C" int aisx_chain_synchronize(aisx_chain* h)

@@ -337,18 +337,38 @@ extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int
         // multiple, history (nsym + 1) and sample delay follow it.  The block's history: the
         // scheduler would hand the nsym items before the next new one; this handle holds the
         // last N of them -- kept right-aligned, older ones (nsym > N) read as zero.
+        // Transactional: every new buffer is allocated and filled first; the handle changes only
+        // once nothing can fail any more.
         const int Nold = h->N, keep = std::min(Nold, nsym);
-        cf* nh[2] = { nullptr, nullptr };
-        cf* ntaps = nullptr;
-        if ((rc = dev_alloc(&nh[0], (size_t)h->nchan * nsym)) != AISX_OK || (rc = dev_alloc(&nh[1], (size_t)h->nchan * nsym)) != AISX_OK ||
-            (rc = dev_alloc(&ntaps, nsym)) != AISX_OK) {
+        const int F = corr_pick_fft(nsym);
+        cf *nh[2] = { nullptr, nullptr }, *ntaps = nullptr, *npad = nullptr, *nH = nullptr, *nw = nullptr;
+        auto undo = [&](int r) {
             dev_free(nh[0]);
             dev_free(nh[1]);
             dev_free(ntaps);
-            return rc;
+            dev_free(npad);
+            dev_free(nH);
+            dev_free(nw);
+            return r;
+        };
+        if ((rc = dev_alloc(&nh[0], (size_t)h->nchan * nsym)) != AISX_OK || (rc = dev_alloc(&nh[1], (size_t)h->nchan * nsym)) != AISX_OK ||
+            (rc = dev_alloc(&ntaps, nsym)) != AISX_OK)
+            return undo(rc);
+        if (F != h->F) {
+            if ((rc = dev_alloc(&npad, F)) != AISX_OK || (rc = dev_alloc(&nH, F)) != AISX_OK || (rc = dev_alloc(&nw, F)) != AISX_OK)
+                return undo(rc);
+            std::vector<cf> w = corr_wtab(F);
+            if (hipMemcpy(nw, w.data(), sizeof(cf) * F, hipMemcpyHostToDevice) != hipSuccess) {
+                set_err("aisx_corr_set_symbols: twiddle upload failed");
+                return undo(AISX_ERR_HIP);
+            }
         }
-        AISX_HIPCHK(hipMemcpy2D(nh[0] + (nsym - keep), sizeof(cf) * nsym, h->d_hist[h->hist_cur] + (Nold - keep), sizeof(cf) * Nold,
-                                sizeof(cf) * keep, h->nchan, hipMemcpyDeviceToDevice));
+        if (hipMemcpy2D(nh[0] + (nsym - keep), sizeof(cf) * nsym, h->d_hist[h->hist_cur] + (Nold - keep), sizeof(cf) * Nold,
+                        sizeof(cf) * keep, h->nchan, hipMemcpyDeviceToDevice) != hipSuccess) {
+            set_err("aisx_corr_set_symbols: history copy failed");
+            return undo(AISX_ERR_HIP);
+        }
+        // commit
         dev_free(h->d_hist[0]);
         dev_free(h->d_hist[1]);
         dev_free(h->d_taps);
@@ -356,16 +376,13 @@ extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int
         h->d_hist[1] = nh[1];
         h->d_taps = ntaps;
         h->hist_cur = 0;
-        const int F = corr_pick_fft(nsym);
         if (F != h->F) {
             dev_free(h->d_tapspad);
             dev_free(h->d_Hpos);
             dev_free(h->d_wtab);
-            if ((rc = dev_alloc(&h->d_tapspad, F)) != AISX_OK || (rc = dev_alloc(&h->d_Hpos, F)) != AISX_OK ||
-                (rc = dev_alloc(&h->d_wtab, F)) != AISX_OK)
-                return rc;
-            std::vector<cf> w = corr_wtab(F);
-            AISX_HIPCHK(hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * F, hipMemcpyHostToDevice));
+            h->d_tapspad = npad;
+            h->d_Hpos = nH;
+            h->d_wtab = nw;
             h->F = F;
         }
         h->N = nsym;
@@ -571,13 +588,16 @@ extern "C" int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags
     return AISX_OK;
 }
 
-extern "C" int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_cap, int* ntags, void* stream)
+extern "C" int aisx_corr_read_tags_back(aisx_corr* h, int back, aisx_tag* host_tags, int host_cap, int* ntags, void* stream)
 {
-    if (!h || !ntags)
+    if (!h || !ntags || back < 0 || back >= aisx_corr::NTAGBUF)
         return AISX_ERR_INVALID;
+    const int bi = (h->tag_cur + aisx_corr::NTAGBUF - back) % aisx_corr::NTAGBUF;
+    const tag_rec* d_tags = h->d_tags2[bi];
+    const int* d_tag_count = h->d_tag_count2[bi];
     hipStream_t st = (hipStream_t)stream;
     std::vector<int> counts(h->nchan);
-    AISX_HIPCHK(hipMemcpyAsync(counts.data(), h->d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));
+    AISX_HIPCHK(hipMemcpyAsync(counts.data(), d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));
     AISX_HIPCHK(hipStreamSynchronize(st));
     int total = 0, rc = AISX_OK;
     long maxc = 0;
@@ -591,7 +611,7 @@ extern "C" int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_c
     if (maxc > 0 && host_tags) {
         // one strided copy of the used prefix of every channel's segment
         std::vector<tag_rec> tmp((size_t)h->nchan * maxc);
-        AISX_HIPCHK(hipMemcpy2DAsync(tmp.data(), sizeof(tag_rec) * maxc, h->d_tags, sizeof(tag_rec) * h->tag_cap,
+        AISX_HIPCHK(hipMemcpy2DAsync(tmp.data(), sizeof(tag_rec) * maxc, d_tags, sizeof(tag_rec) * h->tag_cap,
                                      sizeof(tag_rec) * maxc, h->nchan, hipMemcpyDeviceToHost, st));
         AISX_HIPCHK(hipStreamSynchronize(st));
         for (int c = 0; c < h->nchan; c++)
@@ -612,6 +632,11 @@ extern "C" int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_c
     if (rc == AISX_ERR_OVERFLOW)
         set_err("aisx_corr_read_tags: tag buffer overflow (%d tags)", total);
     return rc;
+}
+
+extern "C" int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_cap, int* ntags, void* stream)
+{
+    return aisx_corr_read_tags_back(h, 0, host_tags, host_cap, ntags, stream);
 }
 
 extern "C" int aisx_corr_work_host(aisx_corr* h, const aisx_cf32* in, aisx_cf32* out, aisx_cf32* corr,

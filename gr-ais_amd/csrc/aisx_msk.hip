@@ -325,13 +325,19 @@ extern "C" int aisx_msk_set_gain(aisx_msk* h, float gain)
 {
     if (!h)
         return AISX_ERR_INVALID;
-    h->gain = gain; // the reference stores first, then throws (:81-82)
     if (!(gain > 0)) {
+        h->gain = gain; // the reference stores first, then throws (:81-82): get_gain() shows the bad value
         set_err("Gain must be positive");
         return AISX_ERR_OUT_OF_RANGE;
     }
+    // a gain the kernel's rings are not sized for is refused BEFORE anything is stored (as
+    // set_limit / set_sps do): later calls keep running with the previous, valid loop gains
+    const int rc = msk_check_geometry(h->d_sps, gain, h->limit);
+    if (rc != AISX_OK)
+        return rc;
+    h->gain = gain;
     h->gain_omega = (float)(gain * gain * 0.25);
-    return msk_check_geometry(h->d_sps, gain, h->limit);
+    return AISX_OK;
 }
 extern "C" float aisx_msk_get_gain(const aisx_msk* h) { return h ? h->gain : 0.f; }
 extern "C" int aisx_msk_set_limit(aisx_msk* h, float limit)

@@ -263,6 +263,15 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
     m.sintab = h->d_sintab;
     hipLaunchKernelGGL(k_fs_mix, dim3((h->nchan + FSM_CPW - 1) / FSM_CPW), dim3(FSM_T), FSM_LDS_BYTES, st, m);
     AISX_HIPCHK(hipGetLastError());
+    if (h->ev_proc) {
+        // a handle that has been driven through the fused entry points on other streams: what they
+        // wait for before touching the pending items, slot 0's maxpos and the phase is THIS pass now
+        AISX_HIPCHK(hipEventRecord(h->ev_proc, st));
+        AISX_HIPCHK(hipEventRecord(h->ev_walk, st));
+        h->proc_pending = h->walk_pending = true;
+        AISX_HIPCHK(hipEventRecord(h->slot[0].ev_read, st));
+        h->slot[0].read_pending = true;
+    }
     h->npend = h->npend + n - nvec * h->fftlen;
     h->cur ^= 1;
     *n_out = nvec * h->fftlen;

@@ -124,6 +124,9 @@ int aisx_corr_tags_device(const aisx_corr* h, const aisx_tag** d_tags, const int
  * synchronises the stream.  Returns AISX_ERR_OVERFLOW if a channel overflowed
  * max_tags_per_chan or host_cap was too small (what fits is still returned). */
 int aisx_corr_read_tags(aisx_corr* h, aisx_tag* host_tags, int host_cap, int* ntags, void* stream);
+/* the same for the call `back` calls before the last one (0 = the last; up to 2: the handle keeps
+ * three sets) -- what a pipelined caller reads once several steps have been issued */
+int aisx_corr_read_tags_back(aisx_corr* h, int back, aisx_tag* host_tags, int host_cap, int* ntags, void* stream);
 /* GNU Radio path (nchan == 1): `in` = input_items[0] as the scheduler passes it
  * (history()-1 old items, then noutput_items new ones), out = output_items[0],
  * corr = output_items[1] or NULL, nitems_written = nitems_written(0). */
@@ -330,6 +333,12 @@ int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n,
 int aisx_chain_wait(aisx_chain* h, long long step, void* stream, int host_blocks);
 int aisx_chain_wait_input(aisx_chain* h, long long step, void* stream, int host_blocks);
 int aisx_chain_synchronize(aisx_chain* h); /* everything issued so far has run */
+/* corr_est's port-0 output of `step` (the conditioned samples delayed by the template length,
+ * lib/corr_est_cc_impl.cc:184, which the timing recovery consumed): rows chan0 .. chan0 + nch - 1
+ * are copied to d_dst[..][dst_stride] on `stream`, *n = items per row.  Valid for the last
+ * AISX_CHAIN_DEPTH steps. */
+int aisx_chain_read_corr_output(aisx_chain* h, long long step, int chan0, int nch, aisx_cf32* d_dst, long dst_stride, int* n,
+                                void* stream);
 /* the chain's streams (0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk), e.g. to
  * read a stage handle's results in order with the step that produced them */
 void* aisx_chain_stream(aisx_chain* h, int which);

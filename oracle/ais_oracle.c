@@ -1291,6 +1291,14 @@ int orc_pdu_to_nmea(const char *designator, const unsigned char *p, int len, cha
 void orc_freq_xlating_fir(const float *taps, int ntaps, int decim, double center_freq, double fs, const orc_cf *x,
                           long nx, long k0, int nout, orc_cf *out)
 {
+    /* the rotated taps depend on the tap index only: formed once per call */
+    double *hr = (double *)orc_big_alloc(sizeof(double) * (size_t)ntaps);
+    double *hi = (double *)orc_big_alloc(sizeof(double) * (size_t)ntaps);
+    for (int n = 0; n < ntaps; n++) {
+        double ph = 2.0 * M_PI * center_freq * (double)n / fs;
+        hr[n] = taps[n] * cos(ph);
+        hi[n] = taps[n] * sin(ph);
+    }
     for (int i = 0; i < nout; i++) {
         long k = k0 + i;
         double ar = 0, ai = 0;
@@ -1298,16 +1306,16 @@ void orc_freq_xlating_fir(const float *taps, int ntaps, int decim, double center
             long idx = k * decim - n;
             if (idx < 0 || idx >= nx)
                 continue;
-            double ph = 2.0 * M_PI * center_freq * (double)n / fs;
-            double hr = taps[n] * cos(ph), hi = taps[n] * sin(ph);
-            ar += hr * x[idx].re - hi * x[idx].im;
-            ai += hr * x[idx].im + hi * x[idx].re;
+            ar += hr[n] * x[idx].re - hi[n] * x[idx].im;
+            ai += hr[n] * x[idx].im + hi[n] * x[idx].re;
         }
         double rp = -2.0 * M_PI * center_freq * (double)decim * (double)k / fs;
         double cr = cos(rp), ci = sin(rp);
         out[i].re = (float)(ar * cr - ai * ci);
         out[i].im = (float)(ar * ci + ai * cr);
     }
+    orc_big_free(hr);
+    orc_big_free(hi);
 }
 
 /* [GR] firdes::low_pass(gain, fs, cutoff, transition, WIN_HAMMING) (python/radio.py:51) */

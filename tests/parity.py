@@ -106,7 +106,7 @@ def assert_aggregate_agreement(min_mean=0.9985, min_exact_share=0.7):
     assert f.size and f.mean() >= min_mean and np.mean(f == 1.0) >= min_exact_share, (f.mean(), np.mean(f == 1.0), f.min())
 
 
-def compare_detections(got, want, thr=None):
+def compare_detections(got, want, thr=None, near_rel=2e-5):
     """Non-asserting comparison of two tag lists of one channel and one call (the gates of
     BASELINE.md section 3, as numbers): detection groups are paired when their corr_start offsets
     are within +-1 sample; a group present on one side only is `lone` (and `lone_near_threshold`
@@ -133,7 +133,7 @@ def compare_detections(got, want, thr=None):
             continue
         lone = a if (b is None or (a is not None and a["start"] < b["start"])) else b
         r["lone"] += 1
-        if thr is not None and abs(lone["mag"] - thr) <= 2e-5 * thr:
+        if thr is not None and abs(lone["mag"] - thr) <= near_rel * thr:
             r["lone_near_threshold"] += 1
         if lone is a:
             i += 1

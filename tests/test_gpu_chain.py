@@ -1,0 +1,164 @@
+"""-m gpu: the pipelined demod step (aisx_chain_*, ais_demod.work_pipelined) -- the path bench.py
+times -- against the stages called one after the other on one stream (ais_demod.work), which the
+other GPU tests hold to the oracle.  python/ais_demod.py:56 is the chain; same bits, symbol
+counts and tags, bit for bit, is the gate."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from parity import compare_bursts, compare_detections
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(samples_per_symbol=4, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
+
+
+@pytest.fixture(scope="module")
+def ais():
+    import torch
+
+    assert torch.cuda.is_available()
+    import ais_amd
+
+    return ais_amd
+
+
+def _dev(x):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def _same(ra, rb, nchan):
+    pa, pb = ra["produced"].cpu().numpy(), rb["produced"].cpu().numpy()
+    assert np.array_equal(pa, pb)
+    ba, bb = ra["bits"].cpu().numpy(), rb["bits"].cpu().numpy()
+    for c in range(nchan):
+        assert np.array_equal(ba[c, :pa[c]], bb[c, :pb[c]]), c
+    return int(pa.sum())
+
+
+def _run_both(ais, stages, lens, xs, nchan, next_known, wrong_next_at=()):
+    """serial work() on one object, work_pipelined() on its twin, over the calls `lens`; every
+    AISX_CHAIN_DEPTH steps the pipelined results are collected (they rotate through that many sets)."""
+    a = ais.ais_demod(OPTS, nchan=nchan, max_items=max(lens), stages=stages)
+    b = ais.ais_demod(OPTS, nchan=nchan, max_items=max(lens), stages=stages)
+    chunks, k = [], 0
+    for L in lens:
+        chunks.append(_dev(xs[:, k:k + L]))
+        k += L
+    nbits, pend = 0, []
+    for i, x in enumerate(chunks):
+        ra = a.work(x)
+        ta = a.preamble_detect.tags() if ra["produced"] is not None else None
+        nxt = chunks[i + 1] if (i + 1 < len(chunks) and next_known(i)) else None
+        if i in wrong_next_at:  # a preparation the next call does not match: dropped, not used
+            nxt = chunks[0]
+        rb = b.work_pipelined(x, x_next=nxt)
+        pend.append((ra, ta, rb))
+        if len(pend) == 3 or i + 1 == len(chunks):
+            b.synchronize()
+            for j, (ra, ta, rb) in enumerate(pend):
+                if ra["produced"] is None:  # less than one fftlen-vector so far: nothing reaches corr_est
+                    assert int(rb["produced"].abs().sum()) == 0
+                    continue
+                nbits += _same(ra, rb, nchan)
+                # (tags of a step whose front end emitted nothing are not in the rotation)
+                back = sum(1 for q in pend[j + 1:] if q[0]["produced"] is not None)
+                assert ta.tobytes() == b.preamble_detect.tags(back=back).tobytes(), (i, j)
+            pend = []
+    assert b.clockrec.last_status() == 0
+    return nbits
+
+
+def test_pipelined_step_equals_the_serial_chain_ragged(ais):
+    # ragged calls: lengths that are not whole vectors (estimates prepared BEHIND the pass), a first
+    # call shorter than one vector (nothing reaches the correlator), whole vectors in a row
+    # (estimates two calls ahead), next input known for some steps only
+    from ais_amd import synth
+
+    nchan = 70
+    lens = [600, 4096, 2048, 1000, 24, 5000, 3 * 1024 + 7, 8192, 8192, 1024, 2041]
+    xs = np.stack([synth.make_channel(4100 + c, sum(lens), "S", 4, amp=0.3, cfo_max=500.0)[0] for c in range(nchan)])
+    nbits = _run_both(ais, "stock", lens, xs, nchan, lambda i: i % 4 != 2, wrong_next_at=(4, 7))
+    assert nbits > nchan * (sum(lens) - 2048) / 4 * 0.9
+
+
+def test_pipelined_core_chain(ais):
+    # corr_est -> msk only (fs = agc = NULL): the chain BASELINE.json's metric names
+    from ais_amd import synth
+
+    nchan = 33
+    lens = [8192, 5000, 12288, 100, 4096]
+    xs = np.stack([synth.make_channel(4300 + c, sum(lens), "S", 4, amp=1.0, cfo_max=3.0)[0] for c in range(nchan)])
+    nbits = _run_both(ais, "core", lens, xs, nchan, lambda i: True)
+    assert nbits > nchan * sum(lens) / 4 * 0.9
+
+
+def test_two_alternating_input_buffers_against_the_oracle(ais):
+    # A live source runs one block ahead through two buffers A, B, A, B ...: step k is issued when
+    # block k + 1 has arrived in the other buffer (x_next), and a buffer is refilled only after
+    # wait_input() of the step that read it.  The prepared estimates must belong to the block they
+    # were prepared for even though the POINTER repeats every other step: checked
+    # against the oracle's chain, which knows nothing of buffers.
+    import torch
+    from ais_amd import _lib, synth
+    import ctypes as C
+
+    nchan, K, T, steps = 24, 6, 16384, 6
+    made = [synth.make_channel(4500 + c, T * steps, "S", 4, amp=0.3, cfo_max=500.0) for c in range(nchan)]
+    xs = np.stack([m[0] for m in made])
+    dem = ais.ais_demod(OPTS, nchan=nchan, max_items=T, stages="stock")
+    tmpl = np.asarray(dem.mod_vector, dtype=np.complex64)
+    thr = dem.preamble_detect.threshold()
+    ora = [orc.Demod(4, tmpl, stages=3) for _ in range(K)]
+    gb, ob_all = [[] for _ in range(K)], [[] for _ in range(K)]
+    lone = near_thr = 0
+    buf = [torch.empty((nchan, T), dtype=torch.complex64, device="cuda") for _ in range(2)]
+    buf[0].copy_(_dev(xs[:, :T]))
+    ndet = 0
+    for s in range(steps):
+        if s + 1 < steps:
+            # refill the other buffer: its last reader was step s - 1
+            if s >= 1:
+                _lib.check(_lib.lib().aisx_chain_wait_input(dem._chain_handle(), s - 1, C.c_void_p(torch.cuda.current_stream().cuda_stream), 0),
+                           "wait_input")
+            buf[(s + 1) & 1].copy_(_dev(xs[:, (s + 1) * T:(s + 2) * T]))
+        r = dem.work_pipelined(buf[s & 1], x_next=buf[(s + 1) & 1] if s + 1 < steps else None)
+        dem.wait(host=True)
+        tags = dem.preamble_detect.tags()
+        prod, bits = r["produced"].cpu().numpy(), r["bits"].cpu().numpy()
+        for c in range(K):
+            ob, _, ot = ora[c].step(xs[c, s * T:(s + 1) * T])
+            d = compare_detections(tags[tags["chan"] == c], ot, thr)
+            ndet += d["matched"]
+            lone += d["lone"]
+            near_thr += d["lone_near_threshold"]
+            assert d["mag_rel_max"] <= 1e-5 and d["time_est_abs_max"] <= 1e-4, (s, c, d)
+            gb[c].append(bits[c, :prod[c]].copy())
+            ob_all[c].append(ob)
+    assert lone == near_thr and lone <= 2, (lone, near_thr)  # (stale estimates would move every detection)
+    ncmp = same = 0
+    for c in range(K):
+        a, b, _ = compare_bursts(np.concatenate(gb[c]), np.concatenate(ob_all[c]), made[c][1])
+        ncmp, same = ncmp + a, same + b
+    print("two alternating buffers: %d detections matched, %d of %d bursts identical in place" % (ndet, same, ncmp))
+    assert ndet > 5 * K * steps and ncmp > 2 * K * steps and same >= ncmp - 2 * max(1, lone) and dem.clockrec.last_status() == 0
+
+
+def test_chain_argument_checks(ais):
+    from ais_amd import synth
+
+    nchan, T = 4, 4096
+    dem = ais.ais_demod(OPTS, nchan=nchan, max_items=T, stages="stock")
+    x = _dev(np.stack([synth.make_channel(4700 + c, T, "S", 4, amp=0.3)[0] for c in range(nchan)]))
+    with pytest.raises(ValueError):
+        dem.work_pipelined(_dev(np.zeros((nchan, 2 * T), np.complex64)))  # n > max_items
+    with pytest.raises(ValueError):
+        dem.wait(step=5)  # never issued
+    r = dem.work_pipelined(x)
+    dem.wait(host=True)
+    assert r["step"] == 0 and int(r["produced"].min()) > (T - 1024) // 4 - 64
+    with pytest.raises(ValueError):
+        dem.corr_output(3)
+    assert dem.corr_output(0, 1, 2).shape == (2, T)

@@ -100,14 +100,19 @@ def test_config2_256_channels_corr_est_only(ais, family):
     assert ndet > 20 * nu and blk.nitems_written() == 2 * T
 
 
-def _stock_chain_against_oracle(ais, nchan, K, steps, seed0, base_noise_free=False):
-    """The whole flowgraph on `nchan` channels x 65536 samples per step.  Channels 0..K-1 carry their
-    own seeded waveform and are checked against the oracle with the gates of
-    test_gpu_stages.py::test_stock_chain_full_length_steps; the others are replicas of them."""
+def _stock_chain_against_oracle(ais, nchan, K, steps, seed0):
+    """The whole flowgraph on `nchan` channels x 65536 samples per step, through the PIPELINED step the
+    benchmark times (ais_demod.work_pipelined = aisx_chain_step: fused front end, frequency estimates
+    and NCO phase walk prepared a step ahead, timing recovery and bit tail on their own streams).
+    All `steps` steps are issued back to back -- nothing waits in between, the buffer rotation
+    wraps -- and compared afterwards.  Channels 0..K-1 carry their own seeded waveform and are
+    checked against the oracle with the gates of test_gpu_stages.py::test_stock_chain_full_length_steps;
+    the others are replicas of them."""
     import torch
     from ais_amd import synth
 
     T = 65536
+    assert steps <= 3  # (results of the last AISX_CHAIN_DEPTH steps stay readable)
     tmpl = _template(ais, "S")
     made = [synth.make_channel(seed0 + c, T * steps, "S", SPS, amp=0.3, cfo_max=500.0) for c in range(K)]
     xs = np.stack([m[0] for m in made])
@@ -121,24 +126,22 @@ def _stock_chain_against_oracle(ais, nchan, K, steps, seed0, base_noise_free=Fal
     tot = dict(detections=0, matched=0, lone=0, lone_near_threshold=0)
     mag = tim = 0.0
     nsym = 0
+    x_dev = [_replicated(xs[:, s * T:(s + 1) * T], nchan) for s in range(steps)]
+    torch.cuda.synchronize()
+    res = [dem.work_pipelined(x_dev[s], x_next=x_dev[s + 1] if s + 1 < steps else None, want_syms=True) for s in range(steps)]
+    dem.synchronize()
+    assert dem.clockrec.last_status() == 0
     for s in range(steps):
         chunk = xs[:, s * T:(s + 1) * T]
-        x = _replicated(chunk, nchan)
-        y, _ = dem.freq_sync.work(x)
-        y = dem.agc.work(y)
-        yo, _ = dem.preamble_detect.work(y)
-        tags = dem.preamble_detect.tags()
-        r = dem.clockrec.work(yo, tags_from=dem.preamble_detect, want_syms=True)
-        assert dem.clockrec.last_status() == 0
+        r = res[s]
+        tags = dem.preamble_detect.tags(back=steps - 1 - s)
         prod = r["produced"].cpu().numpy()
         # every channel: a symbol per ~sps samples, nothing truncated
         assert prod.min() > T // SPS - 64 and prod.max() < T // SPS + 64
         syms = r["syms"][:K].cpu().numpy()
         bits = r["bits"][:K].cpu().numpy()
-        yo_h = yo[:K].cpu().numpy()
-        # replica group 0 of every block of K channels is bit-identical to channels 0..K-1 only for
-        # rotation 0; what every replica shares is the frequency estimate and the symbol count
-        # (to within the few symbols a borderline detection moves)
+        yo_h = dem.corr_output(r["step"], 0, K).cpu().numpy()
+        assert yo_h.shape[1] == T
         for c in range(K):
             tc = tags[tags["chan"] == c]
             ob, _, ot = ora[c].step(chunk[c])
@@ -155,33 +158,137 @@ def _stock_chain_against_oracle(ais, nchan, K, steps, seed0, base_noise_free=Fal
             gbits[c].append(bits[c, : prod[c]].copy())
             obits[c].append(ob)
             nsym += prod[c]
-        del x, y, yo, r
-        torch.cuda.empty_cache()
     ncmp = same = near = 0
     for c in range(K):
         a, b, d = compare_bursts(np.concatenate(gbits[c]), np.concatenate(obits[c]), made[c][1])
         ncmp, same, near = ncmp + a, same + b, near + d
-    print("stock chain at %d channels x %d steps: %d symbols bit-exact given equal tags on %d channels; %d detections, %d "
-          "matched within +-1, %d seen by one side only (%d of them within 2e-5 of the threshold); mag rel max %.2e, time_est "
-          "abs max %.2e; %d decoded bursts compared, %d identical in place, %d within +-4 bits"
+    print("stock chain (pipelined step) at %d channels x %d steps: %d symbols bit-exact given equal tags on %d channels; %d "
+          "detections, %d matched within +-1, %d seen by one side only (%d of them within 2e-5 of the threshold); mag rel max "
+          "%.2e, time_est abs max %.2e; %d decoded bursts compared, %d identical in place, %d within +-4 bits"
           % (nchan, steps, nsym, K, tot["detections"], tot["matched"], tot["lone"], tot["lone_near_threshold"], mag, tim,
              ncmp, same, near))
     assert tot["matched"] > 50 * K * steps
     assert tot["lone"] == tot["lone_near_threshold"], "a detection away from the threshold is missing on one side"
     assert tot["lone"] <= max(2, tot["matched"] // 500)
     assert mag <= 1e-5 and tim <= 1e-4
-    # (achieved at 4096 x 2 steps: 3685 of 3685 detections, 453 of 453 bursts identical in place)
+    # (achieved at 4096 x 2 steps, round 2: 3685 of 3685 detections, 453 of 453 bursts identical in place)
     assert ncmp > 8 * K * steps and near >= ncmp - tot["lone"] and same >= ncmp - 2 * max(1, tot["lone"])
-    return dem
+    return dem, x_dev, res
 
 
 def test_config3_4096_channels_stock_chain(ais):
-    _stock_chain_against_oracle(ais, 4096, 16, 2, 3100)
+    """BASELINE config 3 through the path bench.py times; three steps so that the rotation wraps.
+    On top of the oracle gates: a twin object running the stages one after the other on one stream
+    (square_and_fft_sync_cc.work -> agc.work -> corr_est.work -> msk.work, the two-block front end)
+    gives the same bits on ALL 4096 channels."""
+    import torch
+
+    dem, x_dev, res = _stock_chain_against_oracle(ais, 4096, 16, 3, 3100)
+    twin = ais.ais_demod(OPTS, nchan=4096, max_items=65536, stages="stock", preamble_symbols=_template(ais, "S"))
+    for s, x in enumerate(x_dev):
+        r = twin.work(x)
+        torch.cuda.synchronize()
+        assert torch.equal(r["produced"], res[s]["produced"]), s
+        w = int(r["produced"].max())
+        idx = torch.arange(w, device="cuda").view(1, -1) < r["produced"].view(-1, 1)
+        assert torch.equal(r["bits"][:, :w][idx], res[s]["bits"][:, :w][idx]), s
+        a, b = twin.preamble_detect.tags(), dem.preamble_detect.tags(back=len(x_dev) - 1 - s)
+        assert np.array_equal(a, b), s
 
 
 def test_config4_per_gpu_shape_8192_channels(ais):
     # 65536 channels on 8 GPUs = 8192 per GPU (BASELINE config 4; the ranks share nothing)
-    _stock_chain_against_oracle(ais, 8192, 8, 1, 3300)
+    _stock_chain_against_oracle(ais, 8192, 8, 3, 3300)
+
+
+def test_config5_wideband_channelizer_to_nmea(ais):
+    """BASELINE config 5 end to end: 25 MS/s wideband IQ -> 1024-lane polyphase channelizer (decim 512:
+    48 828 S/s per lane, 5.086 samples per symbol) -> demod lanes -> HDLC deframer -> NMEA, against the
+    reference's structure for ONE channel repeated per lane (python/radio.py:49-57,64-73:
+    freq_xlating_fir_filter_ccf -> ais_demod -> hdlc_deframer_bp(11, 64) -> pdu_to_nmea) on the oracle.
+    Two chains: corr_est -> msk only on lanes whose carrier offset is a few Hz (no freq_sync in
+    front of the correlator), and the whole flowgraph (ais_rx's) on all signal lanes, through the
+    pipelined step.  The template is the stock 224-symbol one at the lanes' fractional rate.
+    Gates: every detection of the oracle on the GPU within +-1 item, peak values within 2e-4 (the
+    channelizer's own tolerance: its fp32 sums over 60 227 taps run in another order than the
+    oracle's double ones), every PDU the oracle recovers recovered by the GPU, every PDU equal to
+    what was transmitted."""
+    import concurrent.futures as cf
+
+    import torch
+    from ais_amd import synth
+
+    fs, M, D, nfr = 25e6, 1024, 512, 8192
+    sps = fs / D / 9600.0
+    quiet = [3, 100, 333, 511, 512, 777]          # carrier offset within +-3 Hz
+    drift = [200, 640, 900, 1023]                 # up to +-400 Hz: needs freq_sync
+    lanes = quiet + drift
+    cfo = {m: 3.0 for m in quiet}
+    cfo.update({m: 400.0 for m in drift})
+    x, infos = synth.make_wideband(55, nfr, lanes, fs=fs, nlanes=M, decim=D, amp=1.1, bursts_per_lane=2, cfo_max=cfo)
+    taps = ais.firdes_low_pass(1.0, fs, 11e3, 1e3)
+    tmpl = synth.resampled_template(ais.modulate_vector_bc(ais.gmsk_mod(40, 0.4), [1, 1, 0, 0] * 7, [1]), 40, sps)
+    assert tmpl.size == 1139
+    opts = dict(samples_per_symbol=sps, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
+
+    # GPU: one channelizer call, then 1024 demod lanes at once
+    pfb = ais.pfb_channelizer_ccf(M, taps, decim=D, max_frames=nfr)
+    lanes_dev = pfb.work(_dev(x))
+    assert tuple(lanes_dev.shape) == (M, nfr)
+    got = {}
+    for stages in ("core", "stock"):
+        dem = ais.ais_demod(opts, nchan=M, max_items=nfr, stages=stages, preamble_symbols=tmpl)
+        r = dem.work_pipelined(lanes_dev)
+        dem.wait(host=True)
+        assert dem.clockrec.last_status() == 0
+        got[stages] = (r["produced"].cpu().numpy(), r["bits"].cpu().numpy(), dem.preamble_detect.tags(),
+                       dem.preamble_detect.threshold())
+        del dem
+    lanes_host = lanes_dev[lanes].cpu().numpy()
+
+    # oracle: the reference's per-channel filter (double accumulation), then its chain, per lane
+    def ref_lane(m):
+        return orc.freq_xlating_fir(taps, D, m * fs / M, fs, x, 0, nfr)
+
+    with cf.ThreadPoolExecutor(len(lanes)) as ex:
+        yo = dict(zip(lanes, ex.map(ref_lane, lanes)))
+    worst = max(float(np.max(np.abs(lanes_host[i] - yo[m])) / np.max(np.abs(yo[m]))) for i, m in enumerate(lanes))
+    assert worst < 2e-4, worst
+    nm = ais.pdu_to_nmea("A")
+    stats = {}
+    for stages, st, which in (("core", 0, quiet), ("stock", 3, lanes)):
+        prod, bits, tags, thr = got[stages]
+        tot = dict(detections=0, matched=0, lone=0, lone_near_threshold=0)
+        mag = tim = 0.0
+        npdu = nsent = 0
+        for m in which:
+            ob, _, ot = orc.Demod(sps, tmpl, stages=st).step(yo[m])
+            d = compare_detections(tags[tags["chan"] == m], ot, thr, near_rel=5e-4)
+            for k in tot:
+                tot[k] += d[k]
+            mag, tim = max(mag, d["mag_rel_max"]), max(tim, d["time_est_abs_max"])
+            gb = bits[m, : prod[m]]
+            assert abs(int(prod[m]) - len(ob)) <= 1, (stages, m)
+            want = orc.Hdlc(11, 64).work(ob)
+            have = ais.hdlc_deframer_bp(11, 64).work(gb)
+            assert set(want) <= set(have), (stages, m, len(want), len(have))
+            sent = [np.packbits(np.array(i["payload"], np.uint8), bitorder="little").tobytes() for i in infos[m]]
+            assert set(have) <= set(sent), (stages, m)  # nothing decoded that was not transmitted
+            for p in have:
+                assert nm.msg_to_sentence(p) == orc.pdu_to_nmea("A", p)
+            npdu += len(have)
+            nsent += len(sent)
+        stats[stages] = (tot, mag, tim, npdu, nsent)
+        print("config 5 (%s, %d lanes of 1024): %d detections, %d matched within +-1, %d seen by one side only (%d near the "
+              "threshold); mag rel max %.2e, time_est abs max %.2e; %d of %d transmitted frames decoded to NMEA, channelizer vs "
+              "reference filter %.1e" % (stages, len(which), tot["detections"], tot["matched"], tot["lone"],
+                                         tot["lone_near_threshold"], mag, tim, npdu, nsent, worst))
+        assert tot["matched"] >= 2 * len(which) and tot["lone"] == tot["lone_near_threshold"]
+        assert mag <= 2e-4 and tim <= 2e-3
+        assert npdu >= nsent - 1
+    # the lanes that carry nothing find nothing
+    idle = np.setdiff1d(np.arange(M), lanes)
+    assert not np.isin(got["core"][2]["chan"], idle).any()
 
 
 def test_config4_rows_do_not_depend_on_their_position(ais):

@@ -203,6 +203,13 @@ def test_msk_api_and_errors(ais):
     assert abs(m.get_limit() - 0.02) < 1e-9 and abs(m.get_gain() - 0.05) < 1e-9
     with pytest.raises(IndexError):
         m.set_gain(-1.0)
+    assert m.get_gain() == -1.0  # the reference stores, then throws (:81-82)
+    m.set_gain(0.05)
+    # a gain the kernel's rings are not sized for is refused before anything is stored: the loop
+    # keeps running on the previous gain
+    with pytest.raises(ValueError):
+        m.set_gain(20.0)
+    assert abs(m.get_gain() - 0.05) < 1e-9
     m.set_sps(5.0)
     assert m.get_sps() == 2.5
 

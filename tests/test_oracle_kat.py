@@ -12,6 +12,8 @@ import pytest
 
 import oracle_py as orc
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _tagdict(tags):
     return [(orc.KEY_NAMES[int(t["key"])], int(t["offset"]), float(t["value"])) for t in tags]
@@ -219,3 +221,51 @@ def test_select_form_of_fast_atan2f_equals_the_ladder():
         a = np.float32(L.emu_fast_atan2f(y, x))
         b = np.float32(orc.fast_atan2f(y, x))
         assert a.tobytes() == b.tobytes() or (np.isnan(a) and np.isnan(b)), (y, x, a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# Structural self-checks of the regenerated GNU Radio tables (tools/gen_tables.py writes the same
+# numbers into oracle/orc_tables.h and gr-ais_amd/csrc/aisx_tables.h).  Not a pin -- the tables are
+# regenerated from upstream's published recipes, upstream's files are not in the image -- but
+# properties any correct copy of those tables has, checked on BOTH generated headers.
+# ---------------------------------------------------------------------------------------------
+def _parse_table(path, name):
+    import re
+
+    txt = open(path).read()
+    m = re.search(r"%s\s*\[[^=]*=\s*\{(.*?)\};" % name, txt, flags=re.S)
+    assert m, (path, name)
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", m.group(1), flags=re.S)
+    return np.array([float(v.rstrip("fF")) for v in re.findall(r"[-+]?\d[\d.]*(?:[eE][-+]?\d+)?[fF]?", body)], dtype=np.float64)
+
+
+@pytest.mark.parametrize("path,prefix", [("oracle/orc_tables.h", "orc"), ("gr-ais_amd/csrc/aisx_tables.h", "aisx")])
+def test_generated_tables_have_the_structure_of_upstreams(path, prefix):
+    full = os.path.join(ROOT, path)
+    # mmse_fir_interpolator taps: 129 rows of 8; row r reversed == row 128 - r (the interpolator for
+    # mu and for 1 - mu are mirror images); rows sum to ~1 (DC gain); rows 0 / 128 are pure delays;
+    # the centre row is symmetric
+    t = _parse_table(full, prefix + "_mmse_taps").reshape(129, 8)
+    assert np.array_equal(t[::-1, ::-1], t)
+    assert np.all(np.abs(t.sum(axis=1) - 1.0) < 2e-3)
+    assert t[0].tolist() == [0, 0, 0, 0, 1, 0, 0, 0] and t[128].tolist() == [0, 0, 0, 1, 0, 0, 0, 0]
+    assert np.array_equal(t[64], t[64][::-1])
+    # every tap is printed to six significant digits, as upstream's %12.5e file is
+    assert all(float("%.5e" % v) == v for v in t.ravel())
+    # the main taps move monotonically with mu
+    assert np.all(np.diff(t[:, 4]) < 0) and np.all(np.diff(t[:, 3]) > 0)
+    # fast_atan2f: 257 entries of atan(i / 255), last one repeated
+    a = _parse_table(full, prefix + "_atan_table")
+    assert a.size == 257 and a[0] == 0.0 and a[256] == a[255]
+    assert np.max(np.abs(a[:256] - np.arctan(np.arange(256) / 255.0))) < 5e-8
+    assert abs(a[255] - np.pi / 4) < 1e-7
+    # gr::fxpt sine table: 1024 x {slope, offset}; the line of entry i evaluated at the start of
+    # entry i + 1 continues into that entry's own line (continuity of the piecewise-linear sine),
+    # and its value at the entry's first angle is sin of that angle to table accuracy
+    st = _parse_table(full, prefix + "_sine_table").reshape(1024, 2)
+    x0 = (np.arange(1024, dtype=np.int64) << 22).astype(np.uint32).astype(np.int32).astype(np.float64)  # signed 32-bit angle
+    ux = (np.arange(1024, dtype=np.int64) << 22) >> 1  # fxpt::sin evaluates the line at (unsigned angle) >> 1
+    val = st[:, 0] * ux + st[:, 1]
+    assert np.max(np.abs(val - np.sin(x0 * np.pi / 2147483648.0))) < 3e-6  # (a min-max line fit: the chord error of a 2 pi / 1024 step, (pi/512)^2 / 16)
+    end = st[:, 0] * (ux + (1 << 21)) + st[:, 1]  # the line of entry i at the first angle of entry i + 1
+    assert np.max(np.abs(end[:-1] - val[1:])) < 6e-6 and abs(end[-1] - val[0]) < 6e-6
