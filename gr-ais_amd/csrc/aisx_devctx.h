@@ -18,6 +18,14 @@ struct DevCtx {
     // lanes of a wave run in lock step and LDS operations of a wave complete in order: nothing
     // to do (the CPU lane model needs a real barrier here)
     __device__ __forceinline__ void wave_sync() const { __builtin_amdgcn_wave_barrier(); }
+    // an LDS exchange among the lanes of ONE wave: the wave's LDS instructions are carried out in
+    // the order it issued them, so a read issued behind a write sees it; only the compiler has to
+    // be kept from moving one across the other
+    __device__ __forceinline__ void wave_lds_sync() const
+    {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     // a lane that leaves the kernel for good before its workgroup's barriers (nothing to do
     // on the device: the hardware counts waves, not lanes)
     __device__ __forceinline__ void retire() const {}
@@ -77,6 +85,14 @@ struct DevCtx {
         else
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
         return tocf(r);
+    }
+    // max(run, |a.re|, |a.im|) in one instruction (v_max3_f32 with the |.| source modifiers).  A NaN
+    // operand is ignored (the other operands win): callers that must see NaNs test for them apart.
+    __device__ __forceinline__ float max3_abs(float run, cf a) const
+    {
+        float r;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(run), "v"(a.re), "v"(a.im));
+        return r;
     }
     // lo = v of lane (i & ~W), hi = v of lane (i | W), W = 16 or 32: one row swap per 32 bits
     // (v_permlane16_swap / v_permlane32_swap with both operands = v)

@@ -110,10 +110,39 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 // grid-stride, no profiler attached) -- the practical ceiling next to the 8 TB/s spec peak the
 // correlator's roofline fraction is quoted against
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+// MODE 0: one 16-byte access per lane and grid-stride step; 1: four independent ones in flight
+// per lane; 2: four, non-temporal (streaming: no reuse, as the correlator's traffic)
+typedef float copy_v4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void k_copy16(const copy_v4* __restrict__ src, copy_v4* __restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (MODE >= 1) {
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            copy_v4 a, b, c, d;
+            if (MODE == 2) {
+                a = __builtin_nontemporal_load(src + i);
+                b = __builtin_nontemporal_load(src + i + stride);
+                c = __builtin_nontemporal_load(src + i + 2 * stride);
+                d = __builtin_nontemporal_load(src + i + 3 * stride);
+                __builtin_nontemporal_store(a, dst + i);
+                __builtin_nontemporal_store(b, dst + i + stride);
+                __builtin_nontemporal_store(c, dst + i + 2 * stride);
+                __builtin_nontemporal_store(d, dst + i + 3 * stride);
+            } else {
+                a = src[i];
+                b = src[i + stride];
+                c = src[i + 2 * stride];
+                d = src[i + 3 * stride];
+                dst[i] = a;
+                dst[i + stride] = b;
+                dst[i + 2 * stride] = c;
+                dst[i + 3 * stride] = d;
+            }
+        }
+    }
+    for (; i < n; i += stride)
         dst[i] = src[i];
 }
 
@@ -125,7 +154,7 @@ extern "C" int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs)
     if (rc != AISX_OK)
         return rc;
     const size_t n = bytes / 16;
-    float4 *a = nullptr, *b = nullptr;
+    copy_v4 *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto done = [&](int r) {
         dev_free(a);
@@ -140,18 +169,32 @@ extern "C" int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs)
         return done(rc);
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return done(AISX_ERR_HIP);
-    const int grid = 256 * 16; // 16 workgroups of four waves per CU
-    for (int k = 0; k < 2; k++)
-        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, a, b, n);
-    if (hipEventRecord(e0, 0) != hipSuccess)
-        return done(AISX_ERR_HIP);
-    for (int k = 0; k < iters; k++)
-        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, a, b, n);
-    float ms = 0.f;
-    if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
-        !(ms > 0.f))
-        return done(AISX_ERR_HIP);
-    *GBs = (float)(2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9); // bytes read + bytes written
+    // several launch shapes; the best one is the figure (bytes read + bytes written per second)
+    float best = 0.f;
+    for (int mode = 0; mode < 3; mode++)
+        for (int wg_per_cu : { 8, 16, 32 }) {
+            const int grid = 256 * wg_per_cu;
+            auto launch = [&] {
+                if (mode == 0)
+                    hipLaunchKernelGGL(k_copy16<0>, dim3(grid), dim3(256), 0, 0, a, b, n);
+                else if (mode == 1)
+                    hipLaunchKernelGGL(k_copy16<1>, dim3(grid), dim3(256), 0, 0, a, b, n);
+                else
+                    hipLaunchKernelGGL(k_copy16<2>, dim3(grid), dim3(256), 0, 0, a, b, n);
+            };
+            launch();
+            if (hipEventRecord(e0, 0) != hipSuccess)
+                return done(AISX_ERR_HIP);
+            for (int k = 0; k < iters; k++)
+                launch();
+            float ms = 0.f;
+            if (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f))
+                return done(AISX_ERR_HIP);
+            const float g = (float)(2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9);
+            best = g > best ? g : best;
+        }
+    *GBs = best;
     return done(AISX_OK);
 }
 
@@ -185,6 +228,11 @@ struct aisx_corr {
     uint64_t written = 0;
     int last_emit_port1 = 0;
     int corr_hist_zero = 0; // set by set_symbols(), consumed by the next call
+    // optional: the peak search (k_corr_resolve) on a stream of its own (aisx_corr_set_resolve_stream)
+    bool res_on = false;
+    hipStream_t res_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_resolved = nullptr;
+    bool resolved_set = false;
     int prof = 0; // aisx_corr_set_profiling
     static constexpr int NEV = 64; // ring of event pairs: one per call, read back after the timed region
     hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
@@ -303,6 +351,9 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
+    for (hipEvent_t e : { h->ev_main, h->ev_resolved })
+        if (e)
+            (void)hipEventDestroy(e);
     for (int k = 0; k < aisx_corr::NEV; k++) {
         if (h->ev0[k])
             (void)hipEventDestroy(h->ev0[k]);
@@ -457,6 +508,8 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         nseg = (ntiles + tps - 1) / tps;
     }
 
+    if (h->res_on && h->resolved_set) // the previous call's peak search still reads the bitmask and the scratch rows
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_resolved, 0));
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;
     p.in = (const cf*)d_in;
@@ -525,12 +578,51 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.tag_cap = h->tag_cap;
     r.tag_count = h->d_tag_count;
     r.atan_tab = h->d_atan;
-    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
+    hipStream_t rs = st;
+    if (h->res_on) { // the peak search beside whatever the caller queues next on `st`
+        AISX_HIPCHK(hipEventRecord(h->ev_main, st));
+        AISX_HIPCHK(hipStreamWaitEvent(h->res_stream, h->ev_main, 0));
+        rs = h->res_stream;
+    }
+    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, rs, r);
     AISX_HIPCHK(hipGetLastError());
+    if (h->res_on) {
+        AISX_HIPCHK(hipEventRecord(h->ev_resolved, rs));
+        h->resolved_set = true;
+    }
     h->hist_cur ^= 1;
     h->corr_hist_zero = 0;
     h->written += (uint64_t)n;
     h->last_emit_port1 = r.emit_port1;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream, int enable)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (!enable) {
+        if (h->res_on && h->resolved_set)
+            AISX_HIPCHK(hipEventSynchronize(h->ev_resolved));
+        h->res_on = false;
+        h->resolved_set = false;
+        return AISX_OK;
+    }
+    if (!h->ev_main) {
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_resolved, hipEventDisableTiming));
+    }
+    h->res_stream = (hipStream_t)resolve_stream;
+    h->res_on = true;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_wait_resolved(aisx_corr* h, void* stream)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (h->res_on && h->resolved_set)
+        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_resolved, 0));
     return AISX_OK;
 }
 
@@ -595,6 +687,8 @@ extern "C" int aisx_corr_read_tags_back(aisx_corr* h, int back, aisx_tag* host_t
     const int bi = (h->tag_cur + aisx_corr::NTAGBUF - back) % aisx_corr::NTAGBUF;
     const tag_rec* d_tags = h->d_tags2[bi];
     const int* d_tag_count = h->d_tag_count2[bi];
+    if (h->res_on && h->resolved_set)
+        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_resolved, 0));
     hipStream_t st = (hipStream_t)stream;
     std::vector<int> counts(h->nchan);
     AISX_HIPCHK(hipMemcpyAsync(counts.data(), d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));

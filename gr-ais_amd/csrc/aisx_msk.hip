@@ -35,6 +35,16 @@ __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
     bittail_body(cx, p);
 }
 
+// One wave that does nothing for `ticks` periods of the 100 MHz wall clock: queued on a stream
+// behind the event of aisx_msk_wait_prepass it gives the recovery kernel, which becomes ready
+// at that same event on its own stream, a head start at the dispatcher (see aisx_msk_wait_prepass).
+__global__ __launch_bounds__(64) void k_msk_headstart(unsigned ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
 {
     DevCtx cx{ nullptr };
@@ -596,8 +606,22 @@ extern "C" int aisx_msk_wait_prepass(aisx_msk* h, void* stream)
         AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
         return AISX_OK;
     }
-    if (h->ev_prep_set)
+    if (h->ev_prep_set) {
         AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_prep, 0));
+        // The event fires when the tag prepass ends -- the same moment the recovery kernel behind
+        // it becomes ready on its own stream: which of the two queues the dispatcher serves first
+        // is then a race (it used to be decided by two already-satisfied barrier packets that
+        // happened to stand behind this one on `stream`: ~10 us).  A wave that sleeps for
+        // AISX_MSK_HEADSTART_US (default 20) on `stream` decides it.
+        static const int us = [] {
+            const char* e = getenv("AISX_MSK_HEADSTART_US");
+            return e ? atoi(e) : 20;
+        }();
+        if (us > 0) {
+            hipLaunchKernelGGL(k_msk_headstart, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)(us * 100));
+            AISX_HIPCHK(hipGetLastError());
+        }
+    }
     return AISX_OK;
 }
 

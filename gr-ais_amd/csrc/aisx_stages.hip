@@ -517,8 +517,11 @@ static int fs_fused_prepare(aisx_freqsync* h)
 // frequency estimates (fs_est_body) and NCO phase walk (fs_walk_body) of the call that comes
 // next (depth 0) or of the one after it (depth 1: only behind a call that leaves no pending items),
 // into the slot it will use; the walk leaves the phase it ends on in an uncommitted copy
+// `first_channels` > 0 launches the estimates in two parts, channels [0, first_channels) and the
+// rest, with gate(gate_ctx, st) called in between (the caller queues a wait on `st` there).
 static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, hipStream_t st,
-                                 hipStream_t st_walk, int depth = 0)
+                                 hipStream_t st_walk, int depth = 0, int first_channels = 0,
+                                 int (*gate)(void*, void*) = nullptr, void* gate_ctx = nullptr)
 {
     const int npend = depth ? 0 : h->npend;
     const int nvec = (npend + n) / h->fftlen;
@@ -542,8 +545,21 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.maxpos_stride = h->max_vec;
     e.nvec = nvec;
     e.offset = h->offset;
-    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+    const int c1 = (first_channels > 0 && first_channels < h->nchan) ? first_channels : h->nchan;
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, c1), dim3(FS_T), FS_LDS_BYTES, st, e);
     AISX_HIPCHK(hipGetLastError());
+    if (gate) {
+        const int rc = gate(gate_ctx, (void*)st);
+        if (rc != AISX_OK)
+            return rc;
+    }
+    if (c1 < h->nchan) { // the other channels: the same launch on rows c1 ..
+        e.in += (long)c1 * in_stride;
+        e.pend += (long)c1 * h->fftlen;
+        e.maxpos += (long)c1 * h->max_vec;
+        hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan - c1), dim3(FS_T), FS_LDS_BYTES, st, e);
+        AISX_HIPCHK(hipGetLastError());
+    }
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
         AISX_HIPCHK(hipEventRecord(h->ev_est, st));
         AISX_HIPCHK(hipStreamWaitEvent(st_walk, h->ev_est, 0));
@@ -581,6 +597,14 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
 extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
                                             void* walk_stream)
 {
+    return aisx::freqsync_estimate_ahead_split(h, d_in, in_stride, n, stream, walk_stream, 0, nullptr, nullptr);
+}
+
+// (library-internal, aisx_host.h: the pipelined chain runs the first part of the estimates beside
+// the previous step's peak search and the rest behind the point where its recovery kernel has been placed)
+int aisx::freqsync_estimate_ahead_split(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
+                                        void* walk_stream, int first_channels, int (*gate)(void*, void*), void* gate_ctx)
+{
     if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n) {
         set_err("aisx_freqsync_estimate_ahead: bad argument");
         return AISX_ERR_INVALID;
@@ -598,7 +622,7 @@ extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d
     hipStream_t sw = walk_stream ? (hipStream_t)walk_stream : (hipStream_t)stream;
     const int depth = h->ahead_cnt;
     if ((rc = fs_fused_prepare(h)) != AISX_OK ||
-        (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw, depth)) != AISX_OK)
+        (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw, depth, first_channels, gate, gate_ctx)) != AISX_OK)
         return rc;
     h->ahead_q[depth].in = d_in;
     h->ahead_q[depth].stride = in_stride;

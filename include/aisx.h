@@ -108,6 +108,14 @@ int aisx_corr_reset(aisx_corr* h); /* zero history, nitems_written = 0 */
  * aisx_corr_read_tags). */
 int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
                       aisx_cf32* d_corr, long corr_stride, int n, void* stream);
+/* The peak search and tag emission (:193-271) read what the correlation pass left behind and have
+ * no part in the sample stream.  With a resolve stream set (enable != 0) aisx_corr_process queues
+ * them THERE, behind the call's main kernel, and returns `stream` to the caller right behind that
+ * kernel: d_out is complete on `stream`, the tags on the resolve stream (aisx_corr_wait_resolved
+ * makes another stream wait for them; aisx_corr_read_tags does so itself).  d_in must stay
+ * unchanged until the tags are complete (the search re-reads a few items of it).  Default: off. */
+int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream, int enable);
+int aisx_corr_wait_resolved(aisx_corr* h, void* stream);
 /* measurement hook: when on, aisx_corr_process brackets the main correlator
  * kernel with hipEvents on the launch stream; aisx_corr_last_kernel_ms waits for
  * the last bracket and returns its duration. */

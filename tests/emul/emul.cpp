@@ -56,6 +56,7 @@ struct EmuCtx {
     void sync() const { sh->bar.arrive_and_wait(); }
     void wsync() const { sh->wbar[tid_ >> 6]->arrive_and_wait(); }
     void wave_sync() const { wsync(); }
+    void wave_lds_sync() const { wsync(); } // (only the wave's own lanes meet: a cross-wave exchange would race here)
     // a lane that leaves the kernel for good: it stops counting in the barriers
     void retire() const
     {
@@ -90,6 +91,16 @@ struct EmuCtx {
                                 { 0.70710678118654752440f, 0.70710678118654752440f } };
         const float c = CNEG ? -K[KSEL][CS] : K[KSEL][CS], s = SNEG ? -K[KSEL][SS] : K[KSEL][SS];
         return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
+    }
+    float max3_abs(float run, cf a) const // (NaN operands are ignored, as v_max3_f32 does)
+    {
+        const float x = fabsf(a.re), y = fabsf(a.im);
+        float r = run;
+        if (x > r || r != r)
+            r = x;
+        if (y > r || r != r)
+            r = y;
+        return r;
     }
     void pin(float&) const {}
     void pin(int&) const {}
