@@ -105,6 +105,20 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
     corr_resolve_body(cx, p);
 }
 
+__global__ __launch_bounds__(64 * RS_SEG) void k_corr_resolve_par(ResolveParParams p)
+{
+    __shared__ __attribute__((aligned(16))) float atab[260];
+    DevCtx cx{ (char*)atab };
+    corr_resolve_par_body(cx, p);
+}
+
+__global__ __launch_bounds__(64) void k_corr_resolve_pack(ResolveParParams p)
+{
+    __shared__ __attribute__((aligned(16))) float atab[260];
+    DevCtx cx{ (char*)atab };
+    corr_resolve_pack_body(cx, p);
+}
+
 // ---------------------------------------------------------------------------
 // measurement hook: what a plain copy sustains on this chip (16 bytes per lane and access,
 // grid-stride, no profiler attached) -- the practical ceiling next to the 8 TB/s spec peak the
@@ -225,6 +239,12 @@ struct aisx_corr {
     tag_rec* d_tags = nullptr;
     int* d_tag_count = nullptr;
     float* d_atan = nullptr;
+    int* d_seg_count = nullptr; // [nchan][RS_SEG] (the peak search by RS_SEG waves per channel)
+    // the peak search by RS_SEG waves per channel (k_corr.h): off by default.  Measured (round 3):
+    // 0.33-0.39 ms per launch either way -- 4096 one-wave workgroups already put four waves on every
+    // SIMD, and what bounds them is their ~200 dependent instructions per detection, not how many
+    // detections one wave walks.  AISX_CORR_RESOLVE_PAR=1 switches it on.
+    bool resolve_par = false;
     uint64_t written = 0;
     int last_emit_port1 = 0;
     int corr_hist_zero = 0; // set by set_symbols(), consumed by the next call
@@ -319,6 +339,9 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->d_tags = h->d_tags2[0];
     h->d_tag_count = h->d_tag_count2[0];
     CK(dev_alloc(&h->d_atan, 257));
+    CK(dev_alloc(&h->d_seg_count, (size_t)nchan * RS_SEG));
+    if (const char* e = getenv("AISX_CORR_RESOLVE_PAR")) // (A/B runs: 0 = one wave per channel)
+        h->resolve_par = atoi(e) != 0;
     if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * h->F, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
         set_err("aisx_corr_create: table upload failed");
@@ -348,6 +371,7 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
         dev_free(h->d_tag_count2[k]);
     }
     dev_free(h->d_atan);
+    dev_free(h->d_seg_count);
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
@@ -584,7 +608,16 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         AISX_HIPCHK(hipStreamWaitEvent(h->res_stream, h->ev_main, 0));
         rs = h->res_stream;
     }
-    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, rs, r);
+    if (h->resolve_par && n >= RS_MIN_ITEMS && h->isps <= RS_MAX_ISPS && h->tag_cap >= 8 * RS_SEG) {
+        // RS_SEG waves per channel, each on its own stretch of the call, then one that closes the
+        // gaps between their tag lists (k_corr.h: corr_resolve_par_body)
+        ResolveParParams rp{ r, h->d_seg_count };
+        hipLaunchKernelGGL(k_corr_resolve_par, dim3(h->nchan), dim3(64 * RS_SEG), 0, rs, rp);
+        AISX_HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_corr_resolve_pack, dim3(h->nchan), dim3(64), 0, rs, rp);
+    } else {
+        hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, rs, r);
+    }
     AISX_HIPCHK(hipGetLastError());
     if (h->res_on) {
         AISX_HIPCHK(hipEventRecord(h->ev_resolved, rs));

@@ -142,6 +142,13 @@ AISX_DI void agc_body(Ctx& cx, const AgcParams& p)
 #ifndef AGC8_THREADS
 #define AGC8_THREADS 1024
 #endif
+// 1 = the stock 512-item window takes its sliding maximum over whole groups from wave-level scans
+// (one barrier instead of six), 0 = from the doubling table in LDS for every window.  Measured
+// (round 3, whole flowgraph, one box): 5.66 against 5.65 ms per step, the launch 1.96 against
+// 1.97 ms -- the pass is not bound by its barriers.  Off: the table serves every window.
+#ifndef AGC8_WAVE_SCAN
+#define AGC8_WAVE_SCAN 0
+#endif
 constexpr int AGC8_T = AGC8_THREADS;
 constexpr int AGC8_G = 8;
 constexpr int AGC8_TL = AGC8_G * AGC8_T;               // outputs per tile: one group per thread
@@ -247,6 +254,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     };
     cf own[AGC8_G];
     float sfx[AGC8_G]; // suffix maxima of the thread's output group: max(e[k .. 7])
+    float gmax1 = 0.f, gmax2 = 0.f; // maxima of the thread's output group and of its halo group (0: no such group)
     auto finish_group = [&](int g, bool keep, Grp& G) {
         cf (&v)[AGC8_G] = G.v;
         if (mixed) {
@@ -274,6 +282,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 PF[gp * AGC8_G + k] = pfx[k];
         }
         GA[g] = run;
+        (keep ? gmax1 : gmax2) = run;
         if (keep) {
             float r2 = e[AGC8_G - 1];
             sfx[AGC8_G - 1] = r2;
@@ -305,6 +314,42 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         if (have2)
             finish_group(AGC8_NG + t, false, G2);
     }
+    // ---- maximum over the Q - 1 whole groups t + 1 .. t + Q - 1 of every thread's window
+    float gw = 0.f;
+#if AGC8_WAVE_SCAN
+    if (Q == 64) {
+        // The stock window (512 items = 64 groups): the 63 groups behind group t are the rest of
+        // t's own wave (lanes l + 1 .. 63) and the first l groups of the next one -- a suffix
+        // maximum inside the wave and a prefix maximum of the neighbour, both by lane shifts; one
+        // value per thread crosses LDS, behind the barrier the prefix maxima of the end group
+        // need anyway.  (The doubling table below: five more barriers over sixteen waves and
+        // three LDS operations per thread and pass.)  A maximum does not care about the order.
+        const int l = t & 63;
+        auto scan = [&](float v, float& pre, float& suf) {
+            pre = suf = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float up = cx.shfl_up_f32(pre, d), dn = cx.shfl_down_f32(suf, d);
+                pre = (l >= d && pre < up) ? up : pre;
+                suf = (l + d < 64 && suf < dn) ? dn : suf;
+            }
+        };
+        float pre1, suf1;
+        scan(gmax1, pre1, suf1);
+        GA[t] = pre1; // prefix maxima of the wave's groups, for the wave before it
+        if (t < 64) { // (wave 0 also holds the halo groups NG .. NG + 63)
+            float pre2, suf2;
+            scan(gmax2, pre2, suf2);
+            GA[AGC8_NG + t] = pre2;
+        }
+        const float own_rest = cx.shfl_down_f32(suf1, 1); // max of lanes l + 1 .. 63
+        cx.sync();
+        const float nb = GA[t + 63]; // prefix maximum of the next wave's lanes 0 .. l - 1
+        gw = l < 63 ? own_rest : 0.f;
+        gw = (l >= 1 && gw < nb) ? nb : gw;
+    } else
+#endif
+    {
     for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC8_T)
         GA[g] = 0.f; // groups past the data: neutral
     cx.sync();
@@ -329,7 +374,10 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     if (nout > 0 && t * AGC8_G < nout) {
         // whole groups t+1 .. t+Q-1
         const float w1 = src[t + 1], w2 = src[t + Q - (1 << K)];
-        const float gw = w1 < w2 ? w2 : w1;
+        gw = w1 < w2 ? w2 : w1;
+    }
+    }
+    if (nout > 0 && t * AGC8_G < nout) {
         const float* pf = PF + t * AGC8_G; // prefix maxima of group t + Q, the one the window ends in
         cf o[AGC8_G];
 #pragma unroll
