@@ -17,6 +17,7 @@ import sched_policy as sp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIXTURE = os.path.join(ROOT, "tests", "golden", "config1_sched.bin")
 EXE = os.path.join(ROOT, "tests", "abi_cpp", "sched_harness")
+CHAIN_EXE = os.path.join(ROOT, "tests", "abi_cpp", "chain_harness")
 
 
 def _build():
@@ -57,5 +58,42 @@ def test_harness_compiles_against_the_header_and_library():
 def test_config1_through_the_compiled_caller():
     exe = _build()
     out = subprocess.run([exe, FIXTURE], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-1500:], out.stderr[-1500:])
+    assert out.returncode == 0 and "PASS" in out.stdout
+
+
+def _build_chain():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gr-ais_amd"), "-s"])
+    lib = os.path.join(ROOT, "gr-ais_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_cpp", "chain_harness.cpp"), "-L", lib,
+                           "-laisx", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", CHAIN_EXE])
+    return CHAIN_EXE
+
+
+def test_chain_harness_compiles_and_uses_the_chain_entry_points():
+    """tests/abi_cpp/chain_harness.cpp: the pipelined chain (aisx_chain_*) from a compiled C++ caller, device
+    buffers of its own (plain HIP runtime), against the four stage calls made one after the other."""
+    exe = _build_chain()
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", exe], text=True)
+    used = {ln.split()[-1] for ln in syms.splitlines() if " aisx_" in ln}
+    assert {"aisx_chain_create", "aisx_chain_step", "aisx_chain_wait", "aisx_chain_wait_input", "aisx_chain_synchronize",
+            "aisx_chain_destroy", "aisx_corr_read_tags_back", "aisx_freqsync_process", "aisx_agc_process", "aisx_corr_process",
+            "aisx_msk_process_stream"} <= used
+    # without a device it says so and fails: the library has no CPU path
+    import ctypes as C
+
+    n = C.c_int(0)
+    C.CDLL(os.path.join(ROOT, "gr-ais_amd", "lib", "libaisx.so")).aisx_device_count(C.byref(n))
+    if n.value <= 0:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 3 and "no device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_pipelined_chain_through_the_compiled_caller():
+    exe = _build_chain()
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     print(out.stdout[-1500:], out.stderr[-1500:])
     assert out.returncode == 0 and "PASS" in out.stdout
