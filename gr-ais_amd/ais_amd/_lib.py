@@ -40,6 +40,13 @@ def lib():
         raise ImportError(
             "libaisx.so not built (%s): run `make -C gr-ais_amd` or __graft_entry__.build(); "
             "there is no CPU fallback" % LIB_PATH)
+    # torch ships its own copy of the HIP runtime: load it FIRST, so that libaisx.so binds to the
+    # runtime that owns the devices torch hands out pointers of (the other order leaves this
+    # process with two runtimes, and the second one sees no device)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, f32, f64, u64, lng = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_uint64, C.c_long
     pvp, pi32 = C.POINTER(C.c_void_p), C.POINTER(C.c_int)

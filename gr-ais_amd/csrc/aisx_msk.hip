@@ -41,7 +41,8 @@ __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
 __global__ __launch_bounds__(64) void k_msk_headstart(unsigned ticks)
 {
     const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks)
+    // (bounded whatever the clock does: 2048 sleeps of 32 x 64 cycles are ~2 ms)
+    for (int k = 0; k < 2048 && wall_clock64() - t0 < ticks; k++)
         __builtin_amdgcn_s_sleep(32);
 }
 
