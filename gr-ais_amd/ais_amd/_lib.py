@@ -60,6 +60,7 @@ def lib():
     sig("aisx_last_error", C.c_char_p, [])
     sig("aisx_device_count", i32, [pi32])
     sig("aisx_set_device", i32, [i32])
+    sig("aisx_util_agc_rcp_mismatches", i32, [f32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)])
     sig("aisx_util_copy_GBs", i32, [C.c_size_t, i32, C.POINTER(C.c_float)])
     sig("aisx_corr_create", i32, [pvp, vp, i32, f32, u32, f32, i32, i32, i32])
     sig("aisx_corr_destroy", i32, [vp])

@@ -94,6 +94,10 @@ struct DevCtx {
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(run), "v"(a.re), "v"(a.im));
         return r;
     }
+    // nothing is scheduled across this point (keeps unrolled repetitions apart: register pressure)
+    __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
+    // v_rcp_f32: the reciprocal to 1 ulp (callers refine it, k_agc.h: agc_gain)
+    __device__ __forceinline__ float rcp_approx(float x) const { return __builtin_amdgcn_rcpf(x); }
     // lo = v of lane (i & ~W), hi = v of lane (i | W), W = 16 or 32: one row swap per 32 bits
     // (v_permlane16_swap / v_permlane32_swap with both operands = v)
     template <int W>

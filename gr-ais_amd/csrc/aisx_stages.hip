@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64) void k_fs_freqest(FsFreqestParams p)
     DevCtx cx{ nullptr };
     fs_freqest_body(cx, p);
 }
+// (two workgroups of sixteen waves per CU = eight waves per SIMD: at most 64 VGPRs)
 __global__ __launch_bounds__(AGC8_T) void k_agc8(AgcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,6 +56,64 @@ __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
     agc_body(cx, p);
+}
+
+// exhaustive check of agc_gain's reciprocal form against the float division (k_agc.h): every
+// float m in [AGC_RCP_LO, AGC_RCP_HI], one per lane and grid-stride step
+__global__ __launch_bounds__(256) void k_agc_rcp_sweep(float reference, unsigned lo_bits, unsigned hi_bits,
+                                                      unsigned long long* count, unsigned* example)
+{
+    DevCtx cx{ nullptr };
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)lo_bits + (unsigned long long)blockIdx.x * 256 + threadIdx.x; b <= hi_bits;
+         b += (unsigned long long)gridDim.x * 256) {
+        const float m = __uint_as_float((unsigned)b);
+        const float fast = agc_gain(cx, reference, m, true), exact = fdiv_rn(reference, m);
+        if (__float_as_uint(fast) != __float_as_uint(exact)) {
+            bad++;
+            atomicMax(example, (unsigned)b);
+        }
+    }
+    if (bad)
+        atomicAdd(count, bad);
+}
+
+extern "C" int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example)
+{
+    if (!count)
+        return AISX_ERR_INVALID;
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    if (!agc_fast_reference(reference)) {
+        set_err("aisx_util_agc_rcp_mismatches: %g is not a reference the reciprocal form serves", reference);
+        return AISX_ERR_INVALID;
+    }
+    unsigned long long* d_count = nullptr;
+    unsigned* d_ex = nullptr;
+    if ((rc = dev_alloc(&d_count, 1)) != AISX_OK || (rc = dev_alloc(&d_ex, 1)) != AISX_OK) {
+        dev_free(d_count);
+        return rc;
+    }
+    unsigned lo, hi, ex = 0;
+    const float flo = AGC_RCP_LO, fhi = AGC_RCP_HI;
+    memcpy(&lo, &flo, 4);
+    memcpy(&hi, &fhi, 4);
+    hipLaunchKernelGGL(k_agc_rcp_sweep, dim3(256 * 32), dim3(256), 0, 0, reference, lo, hi, d_count, d_ex);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy(count, d_count, sizeof(*count), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(&ex, d_ex, sizeof(ex), hipMemcpyDeviceToHost);
+    dev_free(d_count);
+    dev_free(d_ex);
+    if (e != hipSuccess) {
+        set_err("aisx_util_agc_rcp_mismatches: %s", hipGetErrorString(e));
+        return AISX_ERR_HIP;
+    }
+    if (example)
+        memcpy(example, &ex, 4);
+    return AISX_OK;
 }
 
 // ---------------------------------------------------------------------------

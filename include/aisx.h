@@ -69,6 +69,11 @@ int aisx_set_device(int device);
  * with hipEvents and no profiler attached: what "HBM-bound" can mean on this chip next to the
  * 8 TB/s spec peak */
 int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs);
+/* test hook: feedforward_agc_cc's gain reference / max_env is formed as a refined hardware
+ * reciprocal when the reference is a power of two (the stock 2): this sweeps EVERY float max_env
+ * in [2^-100, 2^100] on the device and counts those for which that differs from the correctly
+ * rounded float division (*count must come back 0; *example = the largest such value) */
+int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example);
 
 /* ------------------------------------------------------------------------ */
 /* corr_est_cc  (include/ais/corr_est_cc.h:85-106, lib/corr_est_cc_impl.cc)  */
