@@ -419,3 +419,63 @@ def test_ais_demod_fused_front_end_gives_the_same_bits(ais):
         nbits += int(pa.sum())
         k += L
     assert nbits > nchan * sum(lens) / 4 * 0.9
+
+
+def test_two_block_and_fused_calls_mixed_across_streams(ais):
+    # aisx_freqsync_process (the two-block form) used to record no event, so a fused
+    # call or an estimate prepared on ANOTHER stream right behind it could read the pending items,
+    # slot 0's maxpos and the NCO phase while k_fs_mix was still writing them.  One handle, calls
+    # alternating between the two forms and between two streams, no host synchronisation in between;
+    # the output must be the oracle's chain of freq_sync -> agc, bit for bit.
+    import torch
+    from ais_amd import synth
+
+    nchan = 70
+    lens = [4096, 3000, 2048, 5000, 1024, 8192, 1000, 4096]
+    xs = np.stack([synth.make_channel(5100 + c, sum(lens), "S", 4, amp=0.4, cfo_max=500.0)[0] for c in range(nchan)])
+    fs = ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens))
+    agc = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024)
+    agc2 = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024)
+    sA, sB, sW = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    chunks, k = [], 0
+    for L in lens:
+        chunks.append(_dev(xs[:, k:k + L]))
+        k += L
+    torch.cuda.synchronize()
+    outs = []
+    for i, x in enumerate(chunks):
+        if i % 2 == 0:  # two-block form on stream A; its AGC on the same stream
+            with torch.cuda.stream(sA):
+                y, _ = fs.work(x, stream=sA)
+                o = agc2.work(y, stream=sA) if y.shape[1] else y
+                done = torch.cuda.Event()
+                done.record(sA)
+            if i + 1 < len(chunks) and i % 4 == 0:  # ... and the next call's estimates prepared at once on B / W
+                fs.estimate_ahead(chunks[i + 1], stream=sB, walk_stream=sW)
+        else:  # fused form on stream B (it consumes the preparation, or estimates for itself)
+            with torch.cuda.stream(sB):
+                sB.wait_event(done)  # (the AGC handles are two objects: order their histories by hand)
+                o, _ = ais.freq_sync_agc(fs, agc, x, stream=sB)
+        outs.append(o)
+    torch.cuda.synchronize()
+    # the two AGC objects each saw every other call: compare the freq_sync half through a fresh oracle
+    # per form -- simplest exact statement: rerun the same call sequence serially on fresh handles
+    fs_r = ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens))
+    agc_r, agc2_r = (ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024) for _ in range(2))
+    for i, x in enumerate(chunks):
+        if i % 2 == 0:
+            y, _ = fs_r.work(x)
+            r = agc2_r.work(y) if y.shape[1] else y
+        else:
+            r, _ = ais.freq_sync_agc(fs_r, agc_r, x)
+        torch.cuda.synchronize()
+        assert r.shape == outs[i].shape and torch.equal(r.view(torch.float32), outs[i].view(torch.float32)), i
+    # and the freq_sync stream itself against the oracle (fhat decides everything downstream)
+    o = [orc.FreqSync(38400.0, 9600.0, 1024) for _ in range(4)]
+    fs_o = ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens))
+    for i, x in enumerate(chunks):
+        y, _ = fs_o.work(x)
+        yh = y[:4].cpu().numpy()
+        for c in range(4):
+            want, _ = o[c].process(xs[c, sum(lens[:i]):sum(lens[:i + 1])])
+            assert np.array_equal(yh[c].view(np.uint32), want.view(np.uint32)), (i, c)
