@@ -102,6 +102,9 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
     __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
     DevCtx cx{ (char*)atab };
+#ifdef RESOLVE_PRIO
+    __builtin_amdgcn_s_setprio(RESOLVE_PRIO); // (experiments: the search beside the next estimates)
+#endif
     corr_resolve_body(cx, p);
 }
 
