@@ -60,7 +60,6 @@ def lib():
     sig("aisx_last_error", C.c_char_p, [])
     sig("aisx_device_count", i32, [pi32])
     sig("aisx_set_device", i32, [i32])
-    sig("aisx_util_agc_rcp_mismatches", i32, [f32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)])
     sig("aisx_util_copy_GBs", i32, [C.c_size_t, i32, C.POINTER(C.c_float)])
     sig("aisx_corr_create", i32, [pvp, vp, i32, f32, u32, f32, i32, i32, i32])
     sig("aisx_corr_destroy", i32, [vp])
@@ -74,8 +73,6 @@ def lib():
     sig("aisx_corr_nitems_written", u64, [vp])
     sig("aisx_corr_reset", i32, [vp])
     sig("aisx_corr_process", i32, [vp, vp, lng, vp, lng, vp, lng, i32, vp])
-    sig("aisx_corr_set_resolve_stream", i32, [vp, vp, i32])
-    sig("aisx_corr_wait_resolved", i32, [vp, vp])
     sig("aisx_corr_set_profiling", i32, [vp, i32])
     sig("aisx_corr_last_kernel_ms", i32, [vp, C.POINTER(C.c_float)])
     sig("aisx_corr_kernel_ms_history", i32, [vp, C.POINTER(C.c_float), i32, pi32])

@@ -16,11 +16,8 @@ struct aisx_chain {
     aisx_msk* msk = nullptr;     // borrowed
     int nchan = 0, max_items = 0, fftlen = 0;
     int serial = 0; // AISX_CHAIN_SERIAL: every stage on s_main (A/B runs)
-    // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead |
-    // corr_est's peak search
-    hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr, s_res = nullptr;
-    int est_first = 0;        // channels whose estimates run beside the previous step's peak search
-    bool prepass_owed = false; // s_main has not yet waited for the last step's tag prepass
+    // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead
+    hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr;
     static constexpr int NBUF = AISX_CHAIN_DEPTH;
     cf* d_y = nullptr; // front-end output (stock chain): one buffer, written and read on s_main
     long y_stride = 0;
@@ -45,9 +42,7 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
-    if (h->corr)
-        (void)aisx_corr_set_resolve_stream(h->corr, nullptr, 0);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_res })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamSynchronize(s);
     dev_free(h->d_y);
@@ -59,7 +54,7 @@ static void chain_free(aisx_chain* h)
     }
     if (h->ev_in)
         (void)hipEventDestroy(h->ev_in);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_res })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamDestroy(s);
     delete h;
@@ -125,29 +120,6 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             chain_free(h);
             return rc;
         }
-        // Experiment switch, off by default: corr_est's peak search (one wave per channel walking its
-        // detections: latency, not throughput) on a stream of its own, with the first
-        // AISX_CHAIN_EST_SPLIT percent of the next estimates' channels running beside it and the
-        // rest behind the tag prepass.  Measured (round 3, one box): 5.81-5.86 ms per step at 25 /
-        // 40 / 60 percent against 5.68 with everything behind the prepass -- the search stretches
-        // from 0.35 to 0.55 ms beside the estimates, and the recovery kernel waits for it.
-        int pct = 0;
-        if (const char* e = getenv("AISX_CHAIN_EST_SPLIT"))
-            pct = atoi(e);
-        if (pct > 0 && pct < 100 && fs) {
-            h->est_first = (int)((long)nchan * pct / 100);
-            if (h->est_first > 0) {
-                if (hipStreamCreateWithFlags(&h->s_res, hipStreamNonBlocking) != hipSuccess) {
-                    set_err("aisx_chain_create: stream creation failed");
-                    chain_free(h);
-                    return AISX_ERR_HIP;
-                }
-                if ((rc = aisx_corr_set_resolve_stream(corr, h->s_res, 1)) != AISX_OK) {
-                    chain_free(h);
-                    return rc;
-                }
-            }
-        }
     }
     *out = h;
     return AISX_OK;
@@ -160,15 +132,6 @@ extern "C" int aisx_chain_destroy(aisx_chain* h)
 }
 
 extern "C" int aisx_chain_depth(void) { return aisx_chain::NBUF; }
-
-// queued between the two parts of an estimate launch: the sample passes go on behind the point
-// where the previous step's recovery kernel stands at the head of its queue
-static int chain_prepass_gate(void* ctx, void* stream)
-{
-    aisx_chain* h = (aisx_chain*)ctx;
-    h->prepass_owed = false;
-    return aisx_msk_wait_prepass(h->msk, stream);
-}
 
 extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next,
                                long next_stride, int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride,
@@ -191,11 +154,6 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
     const cf* y = (const cf*)d_in;
     long ys = in_stride;
     int m = n;
-    if (!h->fs && h->prepass_owed) {
-        if ((rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
-            return rc;
-        h->prepass_owed = false;
-    }
     if (h->fs) {
         // The frequency estimates and the NCO phase walk of step k + 1 are issued BEFORE the
         // front-end pass of step k when two preparations may wait (whole vectors, nothing pending):
@@ -208,26 +166,11 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         const bool stale = h->ahead_in != nullptr && !prepared;
         const bool early = !h->serial && !stale && h->npend == 0 && n % h->fftlen == 0;
         hipStream_t sw = h->serial ? sm : h->s_walk;
-        if (h->prepass_owed && h->est_first == 0) { // (round 2's order: everything behind the tag prepass)
-            if ((rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
-                return rc;
-            h->prepass_owed = false;
-        }
         if (early) {
             if (!prepared && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in, in_stride, n, sm, sw)) != AISX_OK)
                 return rc;
-            if (d_in_next) {
-                // part one beside the previous step's peak search, the rest behind its tag prepass
-                const bool split = h->prepass_owed && h->est_first > 0;
-                if ((rc = freqsync_estimate_ahead_split(h->fs, d_in_next, next_stride, n_next, sm, sw, split ? h->est_first : 0,
-                                                        split ? chain_prepass_gate : nullptr, h)) != AISX_OK)
-                    return rc;
-            }
-        }
-        if (h->prepass_owed) { // (no estimate to split this step: the wait comes before the sample pass)
-            if ((rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
+            if (d_in_next && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, sm, sw)) != AISX_OK)
                 return rc;
-            h->prepass_owed = false;
         }
         int nout = 0;
         if ((rc = aisx_freqsync_agc_process(h->fs, h->agc, d_in, in_stride, n, (aisx_cf32*)h->d_y, h->y_stride, nullptr, 0, &nout,
@@ -260,11 +203,7 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         int tcap = 0;
         if ((rc = aisx_corr_tags_device(h->corr, &tags, &counts, &tcap)) != AISX_OK)
             return rc;
-        if (h->est_first > 0) { // the tags are complete on s_res (aisx_corr_set_resolve_stream), d_out on sm
-            AISX_HIPCHK(hipEventRecord(h->ev_ready[par], h->s_res));
-        } else {
-            AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
-        }
+        AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
         if (sk != sm)
             AISX_HIPCHK(hipStreamWaitEvent(sk, h->ev_ready[par], 0));
         if ((rc = aisx_msk_process_stream(h->msk, (const aisx_cf32*)h->d_yc[par], h->yc_stride, m, tags, counts, tcap, d_syms, nullptr,
@@ -273,9 +212,10 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         AISX_HIPCHK(hipEventRecord(h->ev_msk_done[par], sk));
         // the bit tail (if any) was queued on s_tail behind the recovery
         AISX_HIPCHK(hipEventRecord(h->ev_done[par], (d_bits && !h->serial) ? h->s_tail : sk));
-        // the next step's sample passes start behind this step's tag prepass (aisx_msk_wait_prepass):
-        // queued at the start of the next step, behind the part of its estimates that may run earlier
-        h->prepass_owed = !h->serial;
+        // the next step's sample passes start behind this step's tag prepass, i.e. when the recovery
+        // kernel stands at the head of its queue (aisx_msk_wait_prepass; include/aisx.h)
+        if (!h->serial && (rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
+            return rc;
     }
     h->m_of[par] = m;
     if (step)
@@ -335,9 +275,8 @@ extern "C" int aisx_chain_synchronize(aisx_chain* h)
 {
     if (!h)
         return AISX_ERR_INVALID;
-    for (hipStream_t s : { h->s_main, h->s_walk, h->s_res, h->s_msk, h->s_tail })
-        if (s)
-            AISX_HIPCHK(hipStreamSynchronize(s));
+    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail })
+        AISX_HIPCHK(hipStreamSynchronize(s));
     return AISX_OK;
 }
 

@@ -86,18 +86,6 @@ struct DevCtx {
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
         return tocf(r);
     }
-    // max(run, |a.re|, |a.im|) in one instruction (v_max3_f32 with the |.| source modifiers).  A NaN
-    // operand is ignored (the other operands win): callers that must see NaNs test for them apart.
-    __device__ __forceinline__ float max3_abs(float run, cf a) const
-    {
-        float r;
-        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(run), "v"(a.re), "v"(a.im));
-        return r;
-    }
-    // nothing is scheduled across this point (keeps unrolled repetitions apart: register pressure)
-    __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
-    // v_rcp_f32: the reciprocal to 1 ulp (callers refine it, k_agc.h: agc_gain)
-    __device__ __forceinline__ float rcp_approx(float x) const { return __builtin_amdgcn_rcpf(x); }
     // lo = v of lane (i & ~W), hi = v of lane (i | W), W = 16 or 32: one row swap per 32 bits
     // (v_permlane16_swap / v_permlane32_swap with both operands = v)
     template <int W>

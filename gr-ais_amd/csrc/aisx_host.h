@@ -54,10 +54,6 @@ inline int dev_alloc(T** p, size_t count, bool zero = true)
     return AISX_OK;
 }
 
-// library-internal entry points shared between translation units (not part of the C ABI)
-int freqsync_estimate_ahead_split(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
-                                  void* walk_stream, int first_channels, int (*gate)(void*, void*), void* gate_ctx);
-
 template <class T>
 inline void dev_free(T*& p)
 {

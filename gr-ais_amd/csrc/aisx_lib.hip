@@ -102,24 +102,7 @@ __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
     __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
     DevCtx cx{ (char*)atab };
-#ifdef RESOLVE_PRIO
-    __builtin_amdgcn_s_setprio(RESOLVE_PRIO); // (experiments: the search beside the next estimates)
-#endif
     corr_resolve_body(cx, p);
-}
-
-__global__ __launch_bounds__(64 * RS_SEG) void k_corr_resolve_par(ResolveParParams p)
-{
-    __shared__ __attribute__((aligned(16))) float atab[260];
-    DevCtx cx{ (char*)atab };
-    corr_resolve_par_body(cx, p);
-}
-
-__global__ __launch_bounds__(64) void k_corr_resolve_pack(ResolveParParams p)
-{
-    __shared__ __attribute__((aligned(16))) float atab[260];
-    DevCtx cx{ (char*)atab };
-    corr_resolve_pack_body(cx, p);
 }
 
 // ---------------------------------------------------------------------------
@@ -242,20 +225,9 @@ struct aisx_corr {
     tag_rec* d_tags = nullptr;
     int* d_tag_count = nullptr;
     float* d_atan = nullptr;
-    int* d_seg_count = nullptr; // [nchan][RS_SEG] (the peak search by RS_SEG waves per channel)
-    // the peak search by RS_SEG waves per channel (k_corr.h): off by default.  Measured (round 3):
-    // 0.33-0.39 ms per launch either way -- 4096 one-wave workgroups already put four waves on every
-    // SIMD, and what bounds them is their ~200 dependent instructions per detection, not how many
-    // detections one wave walks.  AISX_CORR_RESOLVE_PAR=1 switches it on.
-    bool resolve_par = false;
     uint64_t written = 0;
     int last_emit_port1 = 0;
     int corr_hist_zero = 0; // set by set_symbols(), consumed by the next call
-    // optional: the peak search (k_corr_resolve) on a stream of its own (aisx_corr_set_resolve_stream)
-    bool res_on = false;
-    hipStream_t res_stream = nullptr;
-    hipEvent_t ev_main = nullptr, ev_resolved = nullptr;
-    bool resolved_set = false;
     int prof = 0; // aisx_corr_set_profiling
     static constexpr int NEV = 64; // ring of event pairs: one per call, read back after the timed region
     hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
@@ -342,9 +314,6 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->d_tags = h->d_tags2[0];
     h->d_tag_count = h->d_tag_count2[0];
     CK(dev_alloc(&h->d_atan, 257));
-    CK(dev_alloc(&h->d_seg_count, (size_t)nchan * RS_SEG));
-    if (const char* e = getenv("AISX_CORR_RESOLVE_PAR")) // (A/B runs: 0 = one wave per channel)
-        h->resolve_par = atoi(e) != 0;
     if (hipMemcpy(h->d_wtab, w.data(), sizeof(cf) * h->F, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_atan, aisx_atan_table, sizeof(float) * 257, hipMemcpyHostToDevice) != hipSuccess) {
         set_err("aisx_corr_create: table upload failed");
@@ -374,13 +343,9 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
         dev_free(h->d_tag_count2[k]);
     }
     dev_free(h->d_atan);
-    dev_free(h->d_seg_count);
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
-    for (hipEvent_t e : { h->ev_main, h->ev_resolved })
-        if (e)
-            (void)hipEventDestroy(e);
     for (int k = 0; k < aisx_corr::NEV; k++) {
         if (h->ev0[k])
             (void)hipEventDestroy(h->ev0[k]);
@@ -535,8 +500,6 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         nseg = (ntiles + tps - 1) / tps;
     }
 
-    if (h->res_on && h->resolved_set) // the previous call's peak search still reads the bitmask and the scratch rows
-        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_resolved, 0));
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;
     p.in = (const cf*)d_in;
@@ -605,60 +568,12 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.tag_cap = h->tag_cap;
     r.tag_count = h->d_tag_count;
     r.atan_tab = h->d_atan;
-    hipStream_t rs = st;
-    if (h->res_on) { // the peak search beside whatever the caller queues next on `st`
-        AISX_HIPCHK(hipEventRecord(h->ev_main, st));
-        AISX_HIPCHK(hipStreamWaitEvent(h->res_stream, h->ev_main, 0));
-        rs = h->res_stream;
-    }
-    if (h->resolve_par && n >= RS_MIN_ITEMS && h->isps <= RS_MAX_ISPS && h->tag_cap >= 8 * RS_SEG) {
-        // RS_SEG waves per channel, each on its own stretch of the call, then one that closes the
-        // gaps between their tag lists (k_corr.h: corr_resolve_par_body)
-        ResolveParParams rp{ r, h->d_seg_count };
-        hipLaunchKernelGGL(k_corr_resolve_par, dim3(h->nchan), dim3(64 * RS_SEG), 0, rs, rp);
-        AISX_HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_corr_resolve_pack, dim3(h->nchan), dim3(64), 0, rs, rp);
-    } else {
-        hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, rs, r);
-    }
+    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
     AISX_HIPCHK(hipGetLastError());
-    if (h->res_on) {
-        AISX_HIPCHK(hipEventRecord(h->ev_resolved, rs));
-        h->resolved_set = true;
-    }
     h->hist_cur ^= 1;
     h->corr_hist_zero = 0;
     h->written += (uint64_t)n;
     h->last_emit_port1 = r.emit_port1;
-    return AISX_OK;
-}
-
-extern "C" int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream, int enable)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (!enable) {
-        if (h->res_on && h->resolved_set)
-            AISX_HIPCHK(hipEventSynchronize(h->ev_resolved));
-        h->res_on = false;
-        h->resolved_set = false;
-        return AISX_OK;
-    }
-    if (!h->ev_main) {
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_resolved, hipEventDisableTiming));
-    }
-    h->res_stream = (hipStream_t)resolve_stream;
-    h->res_on = true;
-    return AISX_OK;
-}
-
-extern "C" int aisx_corr_wait_resolved(aisx_corr* h, void* stream)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (h->res_on && h->resolved_set)
-        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_resolved, 0));
     return AISX_OK;
 }
 
@@ -723,8 +638,6 @@ extern "C" int aisx_corr_read_tags_back(aisx_corr* h, int back, aisx_tag* host_t
     const int bi = (h->tag_cur + aisx_corr::NTAGBUF - back) % aisx_corr::NTAGBUF;
     const tag_rec* d_tags = h->d_tags2[bi];
     const int* d_tag_count = h->d_tag_count2[bi];
-    if (h->res_on && h->resolved_set)
-        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_resolved, 0));
     hipStream_t st = (hipStream_t)stream;
     std::vector<int> counts(h->nchan);
     AISX_HIPCHK(hipMemcpyAsync(counts.data(), d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));

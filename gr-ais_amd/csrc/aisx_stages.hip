@@ -58,64 +58,6 @@ __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
     agc_body(cx, p);
 }
 
-// exhaustive check of agc_gain's reciprocal form against the float division (k_agc.h): every
-// float m in [AGC_RCP_LO, AGC_RCP_HI], one per lane and grid-stride step
-__global__ __launch_bounds__(256) void k_agc_rcp_sweep(float reference, unsigned lo_bits, unsigned hi_bits,
-                                                      unsigned long long* count, unsigned* example)
-{
-    DevCtx cx{ nullptr };
-    unsigned long long bad = 0;
-    for (unsigned long long b = (unsigned long long)lo_bits + (unsigned long long)blockIdx.x * 256 + threadIdx.x; b <= hi_bits;
-         b += (unsigned long long)gridDim.x * 256) {
-        const float m = __uint_as_float((unsigned)b);
-        const float fast = agc_gain(cx, reference, m, true), exact = fdiv_rn(reference, m);
-        if (__float_as_uint(fast) != __float_as_uint(exact)) {
-            bad++;
-            atomicMax(example, (unsigned)b);
-        }
-    }
-    if (bad)
-        atomicAdd(count, bad);
-}
-
-extern "C" int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example)
-{
-    if (!count)
-        return AISX_ERR_INVALID;
-    int rc = require_device();
-    if (rc != AISX_OK)
-        return rc;
-    if (!agc_fast_reference(reference)) {
-        set_err("aisx_util_agc_rcp_mismatches: %g is not a reference the reciprocal form serves", reference);
-        return AISX_ERR_INVALID;
-    }
-    unsigned long long* d_count = nullptr;
-    unsigned* d_ex = nullptr;
-    if ((rc = dev_alloc(&d_count, 1)) != AISX_OK || (rc = dev_alloc(&d_ex, 1)) != AISX_OK) {
-        dev_free(d_count);
-        return rc;
-    }
-    unsigned lo, hi, ex = 0;
-    const float flo = AGC_RCP_LO, fhi = AGC_RCP_HI;
-    memcpy(&lo, &flo, 4);
-    memcpy(&hi, &fhi, 4);
-    hipLaunchKernelGGL(k_agc_rcp_sweep, dim3(256 * 32), dim3(256), 0, 0, reference, lo, hi, d_count, d_ex);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpy(count, d_count, sizeof(*count), hipMemcpyDeviceToHost);
-    if (e == hipSuccess)
-        e = hipMemcpy(&ex, d_ex, sizeof(ex), hipMemcpyDeviceToHost);
-    dev_free(d_count);
-    dev_free(d_ex);
-    if (e != hipSuccess) {
-        set_err("aisx_util_agc_rcp_mismatches: %s", hipGetErrorString(e));
-        return AISX_ERR_HIP;
-    }
-    if (example)
-        memcpy(example, &ex, 4);
-    return AISX_OK;
-}
-
 // ---------------------------------------------------------------------------
 struct aisx_freqsync {
     int nchan = 0, fftlen = 0, max_items = 0, offset = 0, max_vec = 0;
@@ -576,11 +518,8 @@ static int fs_fused_prepare(aisx_freqsync* h)
 // frequency estimates (fs_est_body) and NCO phase walk (fs_walk_body) of the call that comes
 // next (depth 0) or of the one after it (depth 1: only behind a call that leaves no pending items),
 // into the slot it will use; the walk leaves the phase it ends on in an uncommitted copy
-// `first_channels` > 0 launches the estimates in two parts, channels [0, first_channels) and the
-// rest, with gate(gate_ctx, st) called in between (the caller queues a wait on `st` there).
 static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, hipStream_t st,
-                                 hipStream_t st_walk, int depth = 0, int first_channels = 0,
-                                 int (*gate)(void*, void*) = nullptr, void* gate_ctx = nullptr)
+                                 hipStream_t st_walk, int depth = 0)
 {
     const int npend = depth ? 0 : h->npend;
     const int nvec = (npend + n) / h->fftlen;
@@ -604,21 +543,8 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.maxpos_stride = h->max_vec;
     e.nvec = nvec;
     e.offset = h->offset;
-    const int c1 = (first_channels > 0 && first_channels < h->nchan) ? first_channels : h->nchan;
-    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, c1), dim3(FS_T), FS_LDS_BYTES, st, e);
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
     AISX_HIPCHK(hipGetLastError());
-    if (gate) {
-        const int rc = gate(gate_ctx, (void*)st);
-        if (rc != AISX_OK)
-            return rc;
-    }
-    if (c1 < h->nchan) { // the other channels: the same launch on rows c1 ..
-        e.in += (long)c1 * in_stride;
-        e.pend += (long)c1 * h->fftlen;
-        e.maxpos += (long)c1 * h->max_vec;
-        hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan - c1), dim3(FS_T), FS_LDS_BYTES, st, e);
-        AISX_HIPCHK(hipGetLastError());
-    }
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
         AISX_HIPCHK(hipEventRecord(h->ev_est, st));
         AISX_HIPCHK(hipStreamWaitEvent(st_walk, h->ev_est, 0));
@@ -656,14 +582,6 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
 extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
                                             void* walk_stream)
 {
-    return aisx::freqsync_estimate_ahead_split(h, d_in, in_stride, n, stream, walk_stream, 0, nullptr, nullptr);
-}
-
-// (library-internal, aisx_host.h: the pipelined chain runs the first part of the estimates beside
-// the previous step's peak search and the rest behind the point where its recovery kernel has been placed)
-int aisx::freqsync_estimate_ahead_split(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
-                                        void* walk_stream, int first_channels, int (*gate)(void*, void*), void* gate_ctx)
-{
     if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n) {
         set_err("aisx_freqsync_estimate_ahead: bad argument");
         return AISX_ERR_INVALID;
@@ -681,7 +599,7 @@ int aisx::freqsync_estimate_ahead_split(aisx_freqsync* h, const aisx_cf32* d_in,
     hipStream_t sw = walk_stream ? (hipStream_t)walk_stream : (hipStream_t)stream;
     const int depth = h->ahead_cnt;
     if ((rc = fs_fused_prepare(h)) != AISX_OK ||
-        (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw, depth, first_channels, gate, gate_ctx)) != AISX_OK)
+        (rc = fs_estimate_into_slot(h, d_in, in_stride, n, (hipStream_t)stream, sw, depth)) != AISX_OK)
         return rc;
     h->ahead_q[depth].in = d_in;
     h->ahead_q[depth].stride = in_stride;

@@ -43,44 +43,6 @@ struct AgcParams {
 
 constexpr float AGC_FLOOR_DEFAULT = 1e-4f;
 
-// reference / max_env, correctly rounded (the reference block divides in float).  The stock
-// reference is 2 (python/ais_demod.py:35): a power of two, so the quotient is the correctly rounded
-// RECIPROCAL of max_env scaled exactly, and that is one Newton step from the hardware's 1-ulp
-// v_rcp_f32: e = fma(-m, r0, 1), r1 = fma(e, r0, r0) -- four issue slots where the IEEE division
-// sequence (two scales, reciprocal, four fmas, fmas, fixup) takes fourteen, per sample.  Where
-// that is the correctly rounded quotient was settled exhaustively on the device: every float m
-// in [2^-100, 2^100] (tests/test_gpu_stages.py::test_agc_fast_reciprocal_is_the_division runs the
-// sweep again); outside that range, for other references and for any build without AGC_FAST_RCP
-// the division itself is used.  `fast` is wave-uniform.
-// Measured (round 3): exact (the sweep finds no mismatch for references 2, 1 and 1/4) and ten issue
-// slots fewer per sample, but the pass takes the same 1.97-1.98 ms in the chain and the step the
-// same 5.66 ms (config 4: 11.11 against 11.07): the division is not what bounds it.  Off: the
-// division sequence needs no proof.
-#ifndef AGC_FAST_RCP
-#define AGC_FAST_RCP 0
-#endif
-constexpr float AGC_RCP_LO = 7.888609052210118e-31f, AGC_RCP_HI = 1.2676506002282294e30f; // 2^-100, 2^100
-template <class Ctx>
-AISX_DI float agc_gain(const Ctx& cx, float reference, float max_env, bool fast)
-{
-#if AGC_FAST_RCP
-    if (fast) {
-        const float r0 = cx.rcp_approx(max_env);
-        const float e = fmaf(-max_env, r0, 1.0f);
-        const float r1 = fmaf(e, r0, r0);
-        return r1 * reference; // (an exact scaling)
-    }
-#endif
-    return fdiv_rn(reference, max_env);
-}
-// is `reference` a power of two whose scaling of a reciprocal in [2^-100, 2^100] can neither overflow nor go subnormal?
-AISX_HD bool agc_fast_reference(float reference)
-{
-    int ex = 0;
-    const float m = frexpf(reference, &ex);
-    return m == 0.5f && ex > -20 && ex < 20;
-}
-
 AISX_HD float agc_envelope(cf x)
 {
     const float r_abs = fabsf(x.re), i_abs = fabsf(x.im);
@@ -179,20 +141,6 @@ AISX_DI void agc_body(Ctx& cx, const AgcParams& p)
 // launch in the chain at 512 threads, the step 1.7 % shorter at 1024; -DAGC8_THREADS rebuilds)
 #ifndef AGC8_THREADS
 #define AGC8_THREADS 1024
-#endif
-// 1 = the stock 512-item window takes its sliding maximum over whole groups from wave-level scans
-// (one barrier instead of six), 0 = from the doubling table in LDS for every window.  Measured
-// (round 3, whole flowgraph, one box): 5.66 against 5.65 ms per step, the launch 1.96 against
-// 1.97 ms -- the pass is not bound by its barriers.  Off: the table serves every window.
-// 1 = groups whose eight items are all to be mixed, in every lane, are mixed without exec masking.
-// Measured (round 3): 78 VGPRs instead of 62 even with scheduling fences and pinned results (92
-// without), i.e. one workgroup of sixteen waves per CU instead of two: 5.85-5.92 against 5.66 ms per
-// step; capped at 64 VGPRs the build spills 159 registers.  Off.
-#ifndef AGC8_UNIFORM_MIX
-#define AGC8_UNIFORM_MIX 0
-#endif
-#ifndef AGC8_WAVE_SCAN
-#define AGC8_WAVE_SCAN 0
 #endif
 constexpr int AGC8_T = AGC8_THREADS;
 constexpr int AGC8_G = 8;
@@ -299,33 +247,13 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     };
     cf own[AGC8_G];
     float sfx[AGC8_G]; // suffix maxima of the thread's output group: max(e[k .. 7])
-    float gmax1 = 0.f, gmax2 = 0.f; // maxima of the thread's output group and of its halo group (0: no such group)
     auto finish_group = [&](int g, bool keep, Grp& G) {
         cf (&v)[AGC8_G] = G.v;
         if (mixed) {
-#if AGC8_UNIFORM_MIX
-            // Nearly every group lies wholly inside the new samples: all eight of its items are to be
-            // mixed, in every lane of the wave.  One ballot then replaces eight exec-masked blocks
-            // (s_and_saveexec, branch, restore around ~25 instructions each) by straight-line code;
-            // the scheduling fences keep the eight evaluations apart, so that the registers of one
-            // are free before the next begins (without them the compiler hoists all sixteen table
-            // reads: 98 VGPRs instead of 62 and half the occupancy)
-            if (cx.ballot(G.mx != 0xffu) == 0ull) {
 #pragma unroll
-                for (int k = 0; k < AGC8_G; k++) {
+            for (int k = 0; k < AGC8_G; k++)
+                if ((G.mx >> k) & 1u)
                     v[k] = mix(v[k], G.f[k]);
-                    cx.pin(v[k].re); // (also keeps the vectoriser from pairing evaluations)
-                    cx.pin(v[k].im);
-                    cx.sched_fence();
-                }
-            } else
-#endif
-            {
-#pragma unroll
-                for (int k = 0; k < AGC8_G; k++)
-                    if ((G.mx >> k) & 1u)
-                        v[k] = mix(v[k], G.f[k]);
-            }
         }
         float e[AGC8_G];
 #pragma unroll
@@ -346,7 +274,6 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 PF[gp * AGC8_G + k] = pfx[k];
         }
         GA[g] = run;
-        (keep ? gmax1 : gmax2) = run;
         if (keep) {
             float r2 = e[AGC8_G - 1];
             sfx[AGC8_G - 1] = r2;
@@ -378,42 +305,6 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         if (have2)
             finish_group(AGC8_NG + t, false, G2);
     }
-    // ---- maximum over the Q - 1 whole groups t + 1 .. t + Q - 1 of every thread's window
-    float gw = 0.f;
-#if AGC8_WAVE_SCAN
-    if (Q == 64) {
-        // The stock window (512 items = 64 groups): the 63 groups behind group t are the rest of
-        // t's own wave (lanes l + 1 .. 63) and the first l groups of the next one -- a suffix
-        // maximum inside the wave and a prefix maximum of the neighbour, both by lane shifts; one
-        // value per thread crosses LDS, behind the barrier the prefix maxima of the end group
-        // need anyway.  (The doubling table below: five more barriers over sixteen waves and
-        // three LDS operations per thread and pass.)  A maximum does not care about the order.
-        const int l = t & 63;
-        auto scan = [&](float v, float& pre, float& suf) {
-            pre = suf = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float up = cx.shfl_up_f32(pre, d), dn = cx.shfl_down_f32(suf, d);
-                pre = (l >= d && pre < up) ? up : pre;
-                suf = (l + d < 64 && suf < dn) ? dn : suf;
-            }
-        };
-        float pre1, suf1;
-        scan(gmax1, pre1, suf1);
-        GA[t] = pre1; // prefix maxima of the wave's groups, for the wave before it
-        if (t < 64) { // (wave 0 also holds the halo groups NG .. NG + 63)
-            float pre2, suf2;
-            scan(gmax2, pre2, suf2);
-            GA[AGC8_NG + t] = pre2;
-        }
-        const float own_rest = cx.shfl_down_f32(suf1, 1); // max of lanes l + 1 .. 63
-        cx.sync();
-        const float nb = GA[t + 63]; // prefix maximum of the next wave's lanes 0 .. l - 1
-        gw = l < 63 ? own_rest : 0.f;
-        gw = (l >= 1 && gw < nb) ? nb : gw;
-    } else
-#endif
-    {
     for (int g = ngroups + t; g < AGC8_GROUPS; g += AGC8_T)
         GA[g] = 0.f; // groups past the data: neutral
     cx.sync();
@@ -438,24 +329,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     if (nout > 0 && t * AGC8_G < nout) {
         // whole groups t+1 .. t+Q-1
         const float w1 = src[t + 1], w2 = src[t + Q - (1 << K)];
-        gw = w1 < w2 ? w2 : w1;
-    }
-    }
-    // the reciprocal form of the gain serves window maxima in [2^-100, 2^100] (agc_gain): every
-    // maximum of a thread is at least the floor and at most max(sfx[0], gw, pf[7]); one ballot per
-    // wave and tile decides (every lane takes part in it)
-    const bool has_out = nout > 0 && t * AGC8_G < nout;
-    bool fast_rcp = false;
-    if (agc_fast_reference(p.reference) && p.floor_env >= AGC_RCP_LO) { // (uniform)
-        float top = 0.f;
-        if (has_out) {
-            const float pe = PF[t * AGC8_G + AGC8_G - 1];
-            top = sfx[0] < gw ? gw : sfx[0];
-            top = top < pe ? pe : top;
-        }
-        fast_rcp = cx.ballot(!(top <= AGC_RCP_HI)) == 0ull;
-    }
-    if (has_out) {
+        const float gw = w1 < w2 ? w2 : w1;
         const float* pf = PF + t * AGC8_G; // prefix maxima of group t + Q, the one the window ends in
         cf o[AGC8_G];
 #pragma unroll
@@ -466,7 +340,7 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 mx = mx < pe ? pe : mx;
             }
             mx = (p.floor_env < mx) ? mx : p.floor_env;
-            const float gain = agc_gain(cx, p.reference, mx, fast_rcp);
+            const float gain = fdiv_rn(p.reference, mx);
             o[k] = mk(gain * own[k].re, gain * own[k].im);
         }
         const int i0 = t * AGC8_G;

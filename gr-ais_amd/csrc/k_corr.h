@@ -69,9 +69,8 @@ AISX_DI void corr_emit_hits(Ctx& cx, const CorrParams& p, unsigned hit, unsigned
 {
     // (the hit masks of lane - 1 and lane + 1; 0 past the ends of the wave)
     const unsigned nb = (cx.lane_prev_u32(hit) | cx.lane_next_u32(hit)) & vmask & ~hit;
-    // (One atomic per hit lane.  The hit bits of a slice as one ballot and two atomics per wave were
-    // measured in round 3: 1.31 against 1.28 ms per launch on the chain's data -- sixteen ballots
-    // cost a wave with a hit more than the atomics of its few hit lanes.)
+    // (One atomic per hit lane.  The hit bits of a slice as one ballot and two atomics per wave:
+    // 1.31 against 1.28 ms per launch on the chain's data, DESIGN_APPENDIX.md A.)
 #pragma unroll
     for (int n1 = 0; n1 < 16; n1++) {
         if (((hit | nb) >> n1) & 1u) {
@@ -339,7 +338,7 @@ AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk,
     // accumulation) for the below-threshold neighbours k = pk - 1 / pk + 1 of a peak; only
     // feeds the 3-point centre of mass.  Both neighbours in one pass over the taps (one
     // memory round trip, not two).
-    const int lane = cx.tid() & 63;
+    const int lane = cx.tid();
     const cf* xin = p.in + (long)c * p.in_stride;
     const cf* hist = p.hist_in + (long)c * p.N;
     double ar0 = 0.0, ai0 = 0.0, ar2 = 0.0, ai2 = 0.0;
@@ -391,21 +390,24 @@ AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk,
     }
 }
 
-// The peak search of lib/corr_est_cc_impl.cc:193-271 over the items [i0, i1) of channel c, by one
-// wave, as the sequential scan would do it from a point where it stands at i0 looking for the next
-// item above the threshold (i0 = 0, or a split point of corr_resolve_split).  Tags go to
-// tags[0 .. cap); returns the number of tags the range holds (more than cap: truncated).
 template <class Ctx>
-AISX_DI int corr_resolve_range(Ctx& cx, const ResolveParams& p, const int c, const int i0, const int i1, tag_rec* tags,
-                               const int cap, const float* atab)
+AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
 {
-    const int lane = cx.tid() & 63;
+    const int lane = cx.tid();
+    const int c = cx.bx();
     const unsigned long long* A = p.abits + (long)c * p.abits_stride;
     const cf* corr = p.corr + (long)c * p.corr_stride;
+    tag_rec* tags = p.tags + (long)c * p.tag_cap;
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
+    // fast_atan2f's table next to the wave (a detection is a chain of dependent memory round
+    // trips; this one becomes an LDS read)
+    float* atab = (float*)cx.lds();
+    for (int k = lane; k < 257; k += 64)
+        atab[k] = p.atan_tab[k];
+    cx.sync();
     int ntag = 0;
-    int i = i0;
+    int i = 0;
     // the window in hand: items wq0 .. wq0 + 63 (lane j: value, mag^2), the lanes whose value is in
     // hand, the lanes from which the climb steps on
     bool win = false;
@@ -413,7 +415,7 @@ AISX_DI int corr_resolve_range(Ctx& cx, const ResolveParams& p, const int c, con
     cf wcv = mk(0.f, 0.f);
     float wmg = 0.f;
     unsigned long long wHV = 0ull, wC = 0ull;
-    for (int base = (i0 >> 6) & ~63; (long)base * 64 < (long)i1; base += 64) {
+    for (int base = 0; base < nwords; base += 64) {
         if ((long)(base + 64) * 64 <= (long)i)
             continue;
         const int wi = base + lane;
@@ -425,10 +427,6 @@ AISX_DI int corr_resolve_range(Ctx& cx, const ResolveParams& p, const int c, con
                 we = 0ull;
             else if (lo < (long)i)
                 we &= (~0ull) << (i - lo);
-            if (lo >= (long)i1) // (items at or beyond i1 belong to the next range)
-                we = 0ull;
-            else if (lo + 64 > (long)i1)
-                we &= (~0ull) >> (64 - (i1 - lo));
             const unsigned long long nz = cx.ballot(we != 0ull);
             if (!nz)
                 break;
@@ -521,13 +519,13 @@ AISX_DI int corr_resolve_range(Ctx& cx, const ResolveParams& p, const int c, con
             if (lane == 0) {
                 const unsigned long long o0 = p.written + (unsigned long long)pk;
                 const unsigned long long o1 = o0 + p.mark_delay;
-                if (ntag + 4 <= cap) {
+                if (ntag + 4 <= p.tag_cap) {
                     tags[ntag + 0] = tag_rec{ o0, (double)mp, KEY_CORR_START, c };
                     tags[ntag + 1] = tag_rec{ o1, (double)phase, KEY_PHASE_EST, c };
                     tags[ntag + 2] = tag_rec{ o1, center, KEY_TIME_EST, c };
                     tags[ntag + 3] = tag_rec{ o1, (double)mp, KEY_CORR_EST, c };
                 }
-                if (p.emit_port1 && ntag + 7 <= cap) {
+                if (p.emit_port1 && ntag + 7 <= p.tag_cap) {
                     tags[ntag + 4] = tag_rec{ o0, (double)phase, KEY_PHASE_EST | 0x100, c };
                     tags[ntag + 5] = tag_rec{ o0, center, KEY_TIME_EST | 0x100, c };
                     tags[ntag + 6] = tag_rec{ o0, (double)mp, KEY_CORR_EST | 0x100, c };
@@ -539,157 +537,8 @@ AISX_DI int corr_resolve_range(Ctx& cx, const ResolveParams& p, const int c, con
                 break;
         }
     }
-    return ntag;
-}
-
-// one wave per channel: the whole call in one range
-template <class Ctx>
-AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
-{
-    const int c = cx.bx();
-    // fast_atan2f's table next to the wave (a detection is a chain of dependent memory round
-    // trips; this one becomes an LDS read)
-    float* atab = (float*)cx.lds();
-    for (int k = cx.tid(); k < 257; k += cx.nthreads())
-        atab[k] = p.atan_tab[k];
-    cx.sync();
-    const int ntag = corr_resolve_range(cx, p, c, 0, p.n, p.tags + (long)c * p.tag_cap, p.tag_cap, atab);
-    if ((cx.tid() & 63) == 0)
+    if (lane == 0)
         p.tag_count[c] = ntag;
 }
-
-// ---- the same search by RS_SEG waves per channel --------------------------------------------
-// A detection is a chain of dependent memory round trips (~3 us), a channel of the stock chain
-// holds ~100 of them per call, and one wave per channel walks them one after the other: 0.35 ms
-// of a 5.6 ms step in which the chip does little else.  The scan is sequential only through its
-// position: once it has seen isps items in a row at or below the threshold it is looking for
-// the next item above it, with nothing carried over (:197-200, :270) -- from such a point on it
-// can be restarted.  corr_resolve_split(q) = the first such point at or behind item q; wave s of
-// a channel's workgroup searches [split(s n / RS_SEG), split((s + 1) n / RS_SEG)) into its own
-// share of the channel's tag row, and corr_resolve_pack_body closes the gaps between the shares
-// (or, when a share overflowed or no split point was found, redoes the channel with one wave as
-// above: same tags either way).
-constexpr int RS_SEG = 4;        // waves per channel
-constexpr int RS_MAX_ISPS = 16;  // (longer skips: one wave per channel)
-constexpr int RS_MIN_ITEMS = 4096;
-
-// first item p >= q such that the isps items before p are all at or below the threshold (bits
-// clear), looking at most 4096 items ahead; n if the call ends first; -1 if not found
-template <class Ctx>
-AISX_DI int corr_resolve_split(Ctx& cx, const ResolveParams& p, const int c, const int q)
-{
-    const int lane = cx.tid() & 63;
-    const unsigned long long* A = p.abits + (long)c * p.abits_stride;
-    const int n = p.n, nwords = (n + 63) >> 6;
-    if (q <= 0)
-        return 0;
-    if (q >= n)
-        return n;
-    // r = first item >= q - isps (>= 0) with bits [r, r + isps) clear; p = max(q, r + isps) would
-    // do, but any r with r + isps >= q is as good: take the first r >= q - isps
-    const int r0 = q - p.isps > 0 ? q - p.isps : 0;
-    const int w0 = r0 >> 6;
-    const int wi = w0 + lane;
-    const unsigned long long w = wi < nwords ? A[wi] : 0ull; // (beyond the call: clear)
-    const unsigned long long wn = cx.shfl_u64(w, (lane + 1) & 63);
-    const unsigned long long nxt = lane < 63 ? wn : ~0ull; // (the window ends here: nothing starts in its last items)
-    // bit k of `run` = items lo + k .. lo + k + isps - 1 are all clear
-    unsigned long long run = ~w;
-    for (int k = 1; k < p.isps; k++)
-        run &= ~((w >> k) | (nxt << (64 - k)));
-    const long lo = (long)wi * 64;
-    if (lo + 64 <= (long)r0)
-        run = 0ull;
-    else if (lo < (long)r0)
-        run &= (~0ull) << (r0 - lo);
-    const unsigned long long nz = cx.ballot(run != 0ull);
-    if (!nz)
-        return ((long)(w0 + 63) * 64 >= (long)n) ? n : -1;
-    const int src = cx.ctz64(nz);
-    const unsigned long long word = cx.shfl_u64(run, src);
-    const long r = (long)(w0 + src) * 64 + cx.ctz64(word);
-    const long pp = r + p.isps;
-    return pp >= (long)n ? n : (int)pp;
-}
-
-struct ResolveParParams {
-    ResolveParams r;
-    int* seg_count; // [nchan][RS_SEG]: tags of each share, -1 = this channel needs the one-wave search
-};
-
-template <class Ctx>
-AISX_DI void corr_resolve_par_body(Ctx& cx, const ResolveParParams& pp)
-{
-    const ResolveParams& p = pp.r;
-    const int c = cx.bx();
-    const int wave = cx.tid() >> 6;
-    float* atab = (float*)cx.lds();
-    for (int k = cx.tid(); k < 257; k += cx.nthreads())
-        atab[k] = p.atan_tab[k];
-    cx.sync();
-    const int subcap = p.tag_cap / RS_SEG;
-    const int i0 = corr_resolve_split(cx, p, c, (int)((long)p.n * wave / RS_SEG));
-    const int i1 = wave == RS_SEG - 1 ? p.n : corr_resolve_split(cx, p, c, (int)((long)p.n * (wave + 1) / RS_SEG));
-    int ntag = -1;
-    if (i0 >= 0 && i1 >= 0) {
-        ntag = 0;
-        if (i0 < i1)
-            ntag = corr_resolve_range(cx, p, c, i0, i1, p.tags + (long)c * p.tag_cap + (long)wave * subcap, subcap, atab);
-        if (ntag > subcap)
-            ntag = -1;
-    }
-    if ((cx.tid() & 63) == 0)
-        pp.seg_count[c * RS_SEG + wave] = ntag;
-}
-
-// one wave per channel: shares -> one gap-free list (tags[c * cap + k], k < tag_count[c])
-template <class Ctx>
-AISX_DI void corr_resolve_pack_body(Ctx& cx, const ResolveParParams& pp)
-{
-    const ResolveParams& p = pp.r;
-    const int c = cx.bx();
-    const int lane = cx.tid() & 63;
-    int cnt[RS_SEG];
-    bool redo = false;
-#pragma unroll
-    for (int s = 0; s < RS_SEG; s++) {
-        cnt[s] = pp.seg_count[c * RS_SEG + s];
-        redo |= cnt[s] < 0;
-    }
-    tag_rec* row = p.tags + (long)c * p.tag_cap;
-    if (redo) { // (wave-uniform)
-        float* atab = (float*)cx.lds();
-        for (int k = cx.tid(); k < 257; k += cx.nthreads())
-            atab[k] = p.atan_tab[k];
-        cx.sync();
-        const int ntag = corr_resolve_range(cx, p, c, 0, p.n, row, p.tag_cap, atab);
-        if (lane == 0)
-            p.tag_count[c] = ntag;
-        return;
-    }
-    const int subcap = p.tag_cap / RS_SEG;
-    int total = cnt[0];
-#pragma unroll
-    for (int s = 1; s < RS_SEG; s++) {
-        // share s moves down to `total` (never up): chunks of 64 records, each read before it is written
-        const tag_rec* src = row + (long)s * subcap;
-        if (total != s * subcap) {
-            for (int k0 = 0; k0 < cnt[s]; k0 += 64) {
-                const bool live = k0 + lane < cnt[s];
-                tag_rec t = tag_rec{ 0, 0.0, 0, 0 };
-                if (live)
-                    t = src[k0 + lane];
-                cx.wave_sync();
-                if (live)
-                    row[total + k0 + lane] = t;
-                cx.wave_sync();
-            }
-        }
-        total += cnt[s];
-    }
-    if (lane == 0)
-        p.tag_count[c] = total;
-}
-
 
 } // namespace aisx

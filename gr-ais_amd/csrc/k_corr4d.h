@@ -63,21 +63,6 @@ constexpr int CD_IMG = 16 * CF4_ROW;               // complex slots per window i
 #ifndef CD_WAVE_EXCHANGE
 #define CD_WAVE_EXCHANGE 1
 #endif
-//   CD_TW16           1 = the W_256 table is laid out [n3][k2] and read two twiddles at a time
-//                     (ds_read_b128, the 16-byte chunk index XOR-ed with n3 >> 1 so that the sixteen
-//                     rows a 16-lane group reads fall into distinct banks): 8 LDS reads per pass
-//                     instead of 15.  0 = [k2][n3], one ds_read_b64 per twiddle (round 2).
-#ifndef CD_TW16
-#define CD_TW16 0
-#endif
-//   CD_MAXNORM        1 = interior tiles ask "can any output of this wave be above the threshold" with
-//                     one v_max3_f32 per output instead of mag^2 + compare (five instructions):
-//                     re^2 + im^2 > thresh needs max(|re|, |im|) > sqrt(thresh / 2).  A wave that
-//                     passes this (a superset of the waves with a hit) then does the exact test of
-//                     lib/corr_est_cc_impl.cc:191,197 as before.  0 = the exact test on every output.
-#ifndef CD_MAXNORM
-#define CD_MAXNORM 0
-#endif
 constexpr int CD_LDS_ELEMS = 2 * CD_IMG + (CD_W2_REGS ? 0 : 256); // two images (+ the W_256 table)
 constexpr int CD_LDS_BYTES = CD_LDS_ELEMS * 8;     // 69632 / 71680 B: two workgroups per CU
 constexpr int CD_PIECE = 128;                      // items per DMA wave-instruction (64 lanes x 16 B)
@@ -129,30 +114,14 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     auto tw2 = [&](int k2) -> cf { return w2[k2]; };
 #else
     cf* const ldsT = lds + 2 * CD_IMG;
-#if CD_TW16
-    {
-        const int k2 = t >> 4, n3 = t & 15; // W_256^{k2 n3} at row n3, chunk (k2 >> 1) ^ (n3 >> 1), half k2 & 1
-        ldsT[n3 * 16 + 2 * ((k2 >> 1) ^ (n3 >> 1)) + (k2 & 1)] = p.wtab[(16 * k2 * n3) & (CF4_F - 1)];
-    }
-    const cf* const myT = ldsT + (t & 15) * 16;
-    const int tsw = (t & 15) >> 1;
-    // the pair (W^{2 pr n3}, W^{(2 pr + 1) n3}) of this thread's n3
-    auto tw2pair = [&](int pr, cf& a, cf& b) { ld16(myT + 2 * (pr ^ tsw), a, b); };
-#else
     ldsT[t] = p.wtab[(16 * (t >> 4) * (t & 15)) & (CF4_F - 1)]; // W_256^{k2 n3}, index k2*16+n3
     const cf* const myT = ldsT + (t & 15);
     auto tw2 = [&](int k2) -> cf { return ld8(myT + k2 * 16); };
-#endif
 #endif
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++)
         H[k3] = p.Hpos[t * 16 + k3];
 
-#if CD_MAXNORM
-    // re^2 + im^2 > thresh (as floats: fl(fl(re^2) + fl(im^2))) implies max(|re|, |im|) > tau; a
-    // threshold that is not a positive number sends every wave to the exact test
-    const float tau = (p.thresh > 0.f) ? sqrtf(0.5f * p.thresh) * 0.9999f : -1.f;
-#endif
     unsigned vmask_int = 0; // value n1 of this thread is window item t + 256 n1: an output iff >= N
 #pragma unroll
     for (int n1 = 0; n1 < 16; n1++)
@@ -303,20 +272,9 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
             for (int n2 = 0; n2 < 16; n2++)
                 x[n2] = ld8(A + cf4_pos(k1, n2 * 16 + n3));
             dft16<false>(cx, x);
-#if CD_TW16 && !CD_W2_REGS
-#pragma unroll
-            for (int pr = 0; pr < 8; pr++) {
-                cf wa, wb;
-                tw2pair(pr, wa, wb);
-                if (pr > 0)
-                    x[2 * pr] = cmul_fma(x[2 * pr], wa);
-                x[2 * pr + 1] = cmul_fma(x[2 * pr + 1], wb);
-            }
-#else
 #pragma unroll
             for (int k2 = 1; k2 < 16; k2++)
                 x[k2] = cmul_fma(x[k2], tw2(k2));
-#endif
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++)
                 st8(A + cf4_pos(k1, k2 * 16 + n3), x[k2]);
@@ -353,22 +311,11 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
 #endif
         {
             const int k1 = t >> 4, n3 = t & 15;
-#if CD_TW16 && !CD_W2_REGS
-#pragma unroll
-            for (int pr = 0; pr < 8; pr++) {
-                cf wa, wb;
-                tw2pair(pr, wa, wb);
-                const cf a = ld8(A + cf4_pos(k1, (2 * pr) * 16 + n3)), b = ld8(A + cf4_pos(k1, (2 * pr + 1) * 16 + n3));
-                x[2 * pr] = (pr == 0) ? a : cmul_conj_fma(a, wa);
-                x[2 * pr + 1] = cmul_conj_fma(b, wb);
-            }
-#else
 #pragma unroll
             for (int k2 = 0; k2 < 16; k2++) {
                 cf a = ld8(A + cf4_pos(k1, k2 * 16 + n3));
                 x[k2] = (k2 == 0) ? a : cmul_conj_fma(a, tw2(k2));
             }
-#endif
             dft16<true>(cx, x);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++)
@@ -393,17 +340,6 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
         const int kb = k0 + t - N; // output index of value n1: kb + 256 n1
         if (interior && !p.dense_corr) {
             bool any = false;
-#if CD_MAXNORM
-            // A non-finite input makes EVERY output of the transform non-finite: an infinity wins
-            // the maximum, a NaN is ignored by it -- value 15 is tested for one apart.  (Lanes of the
-            // slice N ends in that hold no output can only add false alarms.)
-            float run = 0.f;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; n1++)
-                if (CF4_T * n1 + CF4_T - 1 >= N)
-                    run = cx.max3_abs(run, x[n1]);
-            any = !(run <= tau) || x[15].re != x[15].re || x[15].im != x[15].im;
-#else
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) {
                 if (CF4_T * n1 + CF4_T - 1 < N)
@@ -415,7 +351,6 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
                 else
                     any |= above && (t + CF4_T * n1 >= N);
             }
-#endif
             if (cx.ballot(any) != 0ull) {
                 unsigned hit = 0;
 #pragma unroll

@@ -69,12 +69,6 @@ int aisx_set_device(int device);
  * with hipEvents and no profiler attached: what "HBM-bound" can mean on this chip next to the
  * 8 TB/s spec peak */
 int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs);
-/* test hook: feedforward_agc_cc's gain reference / max_env is formed as a refined hardware
- * reciprocal when the reference is a power of two (the stock 2): this sweeps EVERY float max_env
- * in [2^-100, 2^100] on the device and counts those for which that differs from the correctly
- * rounded float division (*count must come back 0; *example = the largest such value) */
-int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example);
-
 /* ------------------------------------------------------------------------ */
 /* corr_est_cc  (include/ais/corr_est_cc.h:85-106, lib/corr_est_cc_impl.cc)  */
 /* ------------------------------------------------------------------------ */
@@ -113,14 +107,6 @@ int aisx_corr_reset(aisx_corr* h); /* zero history, nitems_written = 0 */
  * aisx_corr_read_tags). */
 int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
                       aisx_cf32* d_corr, long corr_stride, int n, void* stream);
-/* The peak search and tag emission (:193-271) read what the correlation pass left behind and have
- * no part in the sample stream.  With a resolve stream set (enable != 0) aisx_corr_process queues
- * them THERE, behind the call's main kernel, and returns `stream` to the caller right behind that
- * kernel: d_out is complete on `stream`, the tags on the resolve stream (aisx_corr_wait_resolved
- * makes another stream wait for them; aisx_corr_read_tags does so itself).  d_in must stay
- * unchanged until the tags are complete (the search re-reads a few items of it).  Default: off. */
-int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream, int enable);
-int aisx_corr_wait_resolved(aisx_corr* h, void* stream);
 /* measurement hook: when on, aisx_corr_process brackets the main correlator
  * kernel with hipEvents on the launch stream; aisx_corr_last_kernel_ms waits for
  * the last bracket and returns its duration. */
@@ -215,7 +201,10 @@ int aisx_msk_wait_tail(aisx_msk* h, void* stream);
  * fill every CU first and the recovery waits for a contiguous 90 KB until they drain (measured:
  * 1.6 ms of a 6 ms step, every other step).  A caller that pipelines the next step's sample passes
  * beside the recovery calls this on their stream right after aisx_msk_process_stream.  The first
- * call only arms the event (returns at once). */
+ * call only arms the event (returns at once).  The event fires for both queues at the same instant;
+ * a one-wave kernel that sleeps AISX_MSK_HEADSTART_US (environment, default 20) is queued on `stream`
+ * behind the wait, so that the recovery kernel reaches the dispatcher first (without it: a race, and
+ * 0.3 ms per 5.6 ms step when it is lost). */
 int aisx_msk_wait_prepass(aisx_msk* h, void* stream);
 /* GNU Radio path (nchan == 1), host pointers as general_work() receives them
  * (impl :107-206): tags = the time_est tags get_tags_in_range would return or

@@ -92,18 +92,6 @@ struct EmuCtx {
         const float c = CNEG ? -K[KSEL][CS] : K[KSEL][CS], s = SNEG ? -K[KSEL][SS] : K[KSEL][SS];
         return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
     }
-    float max3_abs(float run, cf a) const // (NaN operands are ignored, as v_max3_f32 does)
-    {
-        const float x = fabsf(a.re), y = fabsf(a.im);
-        float r = run;
-        if (x > r || r != r)
-            r = x;
-        if (y > r || r != r)
-            r = y;
-        return r;
-    }
-    void sched_fence() const {}
-    float rcp_approx(float x) const { return 1.0f / x; } // (the lane model's is correctly rounded; the device's is within 1 ulp)
     void pin(float&) const {}
     void pin(int&) const {}
     void pin_mask(unsigned long long&) const {}
@@ -245,27 +233,8 @@ void emu_corr_main(const CorrParams* p, int nchan, int F)
         run_grid(p->nseg, nchan, CF4_T, CD_LDS_BYTES, [&](EmuCtx& cx) { corr4d_main_body<EmuCtx, 0>(cx, *p); });
 }
 
-int g_resolve_par = 1; // emu_set_resolve_par: 0 = one wave per channel whatever the size
-int g_resolve_redone = 0, g_resolve_par_calls = 0; // channels redone by one wave / calls that took the RS_SEG-wave path
-void emu_set_resolve_par(int on) { g_resolve_par = on; }
-int emu_resolve_redone(void) { return g_resolve_redone; }
-int emu_resolve_par_calls(void) { return g_resolve_par_calls; }
 void emu_corr_resolve(const ResolveParams* p, int nchan)
 {
-    if (g_resolve_par && p->n >= RS_MIN_ITEMS && p->isps <= RS_MAX_ISPS && p->tag_cap >= 8 * RS_SEG) {
-        std::vector<int> seg((size_t)nchan * RS_SEG, 0);
-        ResolveParParams rp{ *p, seg.data() };
-        run_grid(nchan, 1, 64 * RS_SEG, 260 * 4, [&](EmuCtx& cx) { corr_resolve_par_body(cx, rp); });
-        g_resolve_par_calls++;
-        for (int c = 0; c < nchan; c++)
-            for (int k = 0; k < RS_SEG; k++)
-                if (seg[(size_t)c * RS_SEG + k] < 0) {
-                    g_resolve_redone++;
-                    break;
-                }
-        run_grid(nchan, 1, 64, 260 * 4, [&](EmuCtx& cx) { corr_resolve_pack_body(cx, rp); });
-        return;
-    }
     run_grid(nchan, 1, 64, 260 * 4, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
 }
 

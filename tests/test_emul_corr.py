@@ -138,68 +138,3 @@ def test_emul_corr_f4096_builds(mode, N):
     finally:
         emu.lib().emu_corr_set_dma(1)
 
-
-def _tags_par_and_serial(tmpl, sps, md, thr, x, tag_cap=None):
-    out = []
-    for par in (1, 0):
-        emu.lib().emu_set_resolve_par(par)
-        try:
-            e = emu.CorrEst(tmpl, sps, md, thr, nchan=x.shape[0])
-            kw = {} if tag_cap is None else dict(tag_cap=tag_cap)
-            _, _, tags, cnt, _ = e.work(x, want_corr=False, **kw)
-            out.append((tags, list(cnt)))
-        finally:
-            emu.lib().emu_set_resolve_par(1)
-    return out
-
-
-@pytest.mark.parametrize("thr,sps", [(1e-4, 4.0), (0.02, 4.0), (0.05, 5.2083), (0.2, 3.0), (0.9, 4.0)])
-def test_emul_resolver_by_four_waves_per_channel(thr, sps):
-    # corr_resolve_par_body + corr_resolve_pack_body (k_corr.h): RS_SEG waves per channel, each on
-    # its own stretch between split points, against one wave per channel and against the oracle --
-    # from "every isps-th item fires" (no split point exists: the channel is redone by one wave)
-    # through thresholds where detections and gaps alternate, to the stock 0.9; peaks planted right
-    # at the nominal split positions n / 4, n / 2, 3 n / 4
-    rng = np.random.default_rng(int(1000 * thr) + 17)
-    N = 24
-    tmpl = unit_template(rng, N)
-    n = 9000
-    q = [n // 4, n // 2, 3 * n // 4]
-    pos = [[q[0] - N - 3, q[0] - N, q[0] - N + 2, q[1] - N + 1, q[2] - N - 1, q[2] - N + 5, 100, n - N - 2],
-           [q[1] - N - 2, q[1] - N + 3, 4000], []]
-    x = planted(rng, 3, n, tmpl, pos, noise=0.25)
-    r0, c0 = emu.lib().emu_resolve_redone(), emu.lib().emu_resolve_par_calls()
-    (tp, cp), (ts, cs) = _tags_par_and_serial(tmpl, sps, 1, thr, x, tag_cap=4 * n)
-    redone, calls = emu.lib().emu_resolve_redone() - r0, emu.lib().emu_resolve_par_calls() - c0
-    assert calls == 1 and (redone == 3 if thr < 1e-3 else redone == 0), (redone, calls)  # (only "everything fires" has no split point)
-    assert cp == cs
-    nd = 0
-    for c in range(3):
-        assert np.array_equal(tp[c], ts[c]), c
-        o = orc.CorrEst(tmpl, sps, 1, thr)
-        _, _, ot = o.work(x[c])
-        nd += assert_tags_match(tp[c], ot)
-    assert nd >= 8
-
-
-def test_emul_resolver_share_overflow_falls_back_to_one_wave():
-    # all detections in the first quarter of the call: more than that wave's share of the tag row,
-    # fewer than the row -- the channel is redone by one wave and nothing is lost; and a row that is
-    # too small altogether is truncated exactly as before
-    rng = np.random.default_rng(77)
-    N = 20
-    tmpl = unit_template(rng, N)
-    n = 8192
-    x = (0.02 * (rng.normal(size=(2, n)) + 1j * rng.normal(size=(2, n)))).astype(np.complex64)
-    for k in range(30):  # 30 bursts in the first 1800 items of channel 0
-        p0 = 10 + 60 * k
-        x[0, p0:p0 + N] += tmpl
-    x[1, 5000:5000 + N] += tmpl
-    for cap in (160, 40):  # share = 40 resp. 10 tags; channel 0 holds 30 detections = 120 tags
-        r0 = emu.lib().emu_resolve_redone()
-        (tp, cp), (ts, cs) = _tags_par_and_serial(tmpl, 4.0, 1, 0.9, x, tag_cap=cap)
-        assert emu.lib().emu_resolve_redone() - r0 == 1  # channel 0 only
-        assert cp == cs and cp[0] >= 120
-        for c in range(2):
-            assert np.array_equal(tp[c], ts[c]), (cap, c)
-        assert len(tp[0]) == min(cap, cp[0])

@@ -163,15 +163,3 @@ def test_chain_argument_checks(ais):
         dem.corr_output(3)
     assert dem.corr_output(0, 1, 2).shape == (2, T)
 
-
-def test_resolve_stream_and_split_estimates_give_the_same_results(ais, monkeypatch):
-    # the experiment switch of aisx_chain_create (corr_est's peak search on its own stream, the next
-    # estimates launched in two parts around the tag prepass): slower, but it must stay correct
-    from ais_amd import synth
-
-    monkeypatch.setenv("AISX_CHAIN_EST_SPLIT", "40")
-    nchan = 70
-    lens = [4096, 2048, 8192, 8192, 1000, 3072, 4096]
-    xs = np.stack([synth.make_channel(4900 + c, sum(lens), "S", 4, amp=0.3, cfo_max=500.0)[0] for c in range(nchan)])
-    nbits = _run_both(ais, "stock", lens, xs, nchan, lambda i: True)
-    assert nbits > nchan * (sum(lens) - 2048) / 4 * 0.9
