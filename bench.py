@@ -6,12 +6,13 @@ and a CPU baseline.
   python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the chain over one batch: CHANNELS_PER_GPU channels x
-SAMPLES complex samples per GPU, already resident in HBM.  Weak scaling: every
-rank owns its own channels, no data-path collective (channels are independent,
-SURVEY.md section 8e); torch.distributed (RCCL) is used only for the timing
-barrier and the max-over-ranks reduction.  With --gpus N > 1 and no launcher
-environment the script starts its N ranks itself (torch.distributed.run on
-127.0.0.1), one process per GPU.
+SAMPLES complex samples per GPU, already resident in HBM, through the PRODUCT's
+pipelined chain (ais_amd.ais_demod.work_pipelined = aisx_chain_step, include/aisx.h:
+the path the config 3 / 4 / 5 tests run).  Weak scaling: every rank owns its own
+channels, no data-path collective (channels are independent, SURVEY.md section 8e);
+torch.distributed (RCCL) is used only for the timing barrier and the max / min
+over ranks.  With --gpus N > 1 and no launcher environment the script starts its
+N ranks itself (torch.distributed.run on 127.0.0.1), one process per GPU.
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 4096
 batched channels, 65536 samples each, sps = 4, stock template (N = 896, SURVEY
@@ -22,11 +23,16 @@ run also times `--chain core` (corr_est -> msk_timing only, the two blocks the
 metric string names) and the correlator alone at BASELINE config 2's shapes
 (256 and 4096 channels, N = 896 and 112) and reports them under
 "corr_est_to_msk_only" and "corr_only".  BASELINE config 4 (65536 channels on
-8 GPUs) is `--gpus 8 --channels-per-gpu 8192`.
+8 GPUs) is `--gpus 8 --config4`.
 
-After the timed region the last step of PARITY_CHANNELS channels is compared with
-the CPU oracle replaying the same steps on the same samples ("parity": tag
-offsets, peak magnitudes, time_est, decoded bursts -- BASELINE.md section 3).
+"roofline" is the correlator's main kernel: algorithmic 16 B per sample over its
+launch time by hipEvents on its own stream inside the timed region, next to the
+8 TB/s spec peak and to what the best plain copy sustains on this box
+("copy_ceiling_GBs").  After the timed region the last step of PARITY_CHANNELS
+channels is compared with the CPU oracle replaying the same steps on the same
+samples ("parity": tag offsets, peak magnitudes, time_est, decoded bursts --
+BASELINE.md section 3).  "cpu_baseline": the oracle built on this host with -O3
+-march=native, one thread and all hardware threads.
 """
 import argparse
 import json
