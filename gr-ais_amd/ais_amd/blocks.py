@@ -491,7 +491,11 @@ class ais_demod:
         h = self._chain_handle()
         x = _dev_c64(x, self.nchan)
         nx = _dev_c64(x_next, self.nchan) if x_next is not None else None
-        self._chain_keep = (x, nx)  # (the chain reads them asynchronously)
+        # (the chain reads its inputs asynchronously, on streams torch's allocator does not know of:
+        # the tensors of the steps that may still be in flight stay referenced here)
+        keep = getattr(self, "_chain_keep", None) or []
+        keep.append((x, nx))
+        self._chain_keep = keep[-(_lib.lib().aisx_chain_depth() + 1):]
         cap = self.clockrec.out_capacity
         if outs is None:
             depth = _lib.lib().aisx_chain_depth()
