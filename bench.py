@@ -348,9 +348,10 @@ def spawn_ranks(args):
 
 def corr_kernel_name(n):
     """the correlator kernel aisx_corr_process launches for an n-item template (aisx_lib.hip)"""
+    dma = os.environ.get("AISX_CORR_DMA", "1") != "0"
     if n <= 512:
-        return "k_corr_main"
-    return "k_corr4_main" if os.environ.get("AISX_CORR_DMA", "1") == "0" else "k_corr4d_main"
+        return "k_corr2d_main" if dma else "k_corr_main"
+    return "k_corr4d_main" if dma else "k_corr4_main"
 
 
 def main():

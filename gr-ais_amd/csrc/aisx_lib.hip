@@ -98,6 +98,25 @@ static void (*corr4d_pick(int N))(CorrParams)
     }
 }
 
+// the F = 2048 correlator with the next tile's window prefetched by LDS-DMA (k_corr2d.h): four
+// workgroups of two waves per CU (two 17 KB window images each), up to 256 VGPRs
+template <int NC>
+__global__ __launch_bounds__(CF_T, 2) void k_corr2d_main(CorrParams p) // (second argument: waves per SIMD)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr2d_main_body<DevCtx, NC>(cx, p);
+}
+// builds with the template length folded in: the 28-symbol preamble at 4 and at 5 samples per symbol
+static void (*corr2d_pick(int N))(CorrParams)
+{
+    switch (N) {
+    case 112: return k_corr2d_main<112>;
+    case 140: return k_corr2d_main<140>;
+    default: return k_corr2d_main<0>;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
 {
     __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
@@ -487,9 +506,9 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool dma = h->dma && h->F == CF4_F;
+    const bool dma = h->dma; // the builds with the window prefetched by LDS-DMA (k_corr4d.h, k_corr2d.h)
     int nseg, tps;
-    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, dma ? 2 : 0);
+    corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, dma ? (h->F == CF4_F ? 2 : 4) : 0);
     static const int force_nseg = [] { // (experiments: segments per channel, AISX_CORR_NSEG)
         const char* e = getenv("AISX_CORR_NSEG");
         return e ? atoi(e) : 0;
@@ -525,7 +544,9 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
-    if (h->F == CF_F) {
+    if (h->F == CF_F && dma) {
+        hipLaunchKernelGGL(corr2d_pick(h->N), dim3(nseg, h->nchan), dim3(CF_T), C2_LDS_BYTES, st, p);
+    } else if (h->F == CF_F) {
         hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
     } else if (dma) {
         void (*kern)(CorrParams) = corr4d_pick(h->N);

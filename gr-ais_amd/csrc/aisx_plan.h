@@ -11,6 +11,7 @@
 #include "k_corr.h"
 #include "k_corr4k.h"
 #include "k_corr4d.h"
+#include "k_corr2d.h"
 
 namespace aisx {
 

@@ -221,8 +221,14 @@ void emu_corr_set_dma(int mode) { g_corr_dma = mode; }
 
 void emu_corr_main(const CorrParams* p, int nchan, int F)
 {
-    if (F == CF_F)
+    if (F == CF_F && g_corr_dma == 0)
         run_grid(p->nseg, nchan, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_main_body(cx, *p); });
+    else if (F == CF_F && g_corr_dma == 1 && p->N == 112)
+        run_grid(p->nseg, nchan, CF_T, C2_LDS_BYTES, [&](EmuCtx& cx) { corr2d_main_body<EmuCtx, 112>(cx, *p); });
+    else if (F == CF_F && g_corr_dma == 1 && p->N == 140)
+        run_grid(p->nseg, nchan, CF_T, C2_LDS_BYTES, [&](EmuCtx& cx) { corr2d_main_body<EmuCtx, 140>(cx, *p); });
+    else if (F == CF_F)
+        run_grid(p->nseg, nchan, CF_T, C2_LDS_BYTES, [&](EmuCtx& cx) { corr2d_main_body<EmuCtx, 0>(cx, *p); });
     else if (g_corr_dma == 0)
         run_grid(p->nseg, nchan, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_main_body(cx, *p); });
     else if (g_corr_dma == 1 && p->N == 896)

@@ -138,3 +138,41 @@ def test_emul_corr_f4096_builds(mode, N):
     finally:
         emu.lib().emu_corr_set_dma(1)
 
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("N", [112, 140, 99, 1, 128, 129, 511, 512])
+def test_emul_corr_f2048_builds(mode, N):
+    # the three F = 2048 builds -- k_corr.h (0), k_corr2d.h with the template length folded in where
+    # such a build exists (1) and with it at run time (2): several tiles per segment (the window
+    # images alternate, what lies below the first DMA piece is copied across, the rest arrives by
+    # "DMA"), several segments, a ragged last tile, calls with carried history, peaks on call and
+    # tile edges, odd lengths (a DMA pair split between history and stream), N a whole piece
+    emu.lib().emu_corr_set_dma(mode)
+    try:
+        rng = np.random.default_rng(17 * N + mode)
+        tmpl = unit_template(rng, N)
+        L = 2048 - N
+        lens = [3 * L + 517, max(1, N // 3), 2 * L + 1, 40]
+        total = sum(lens)
+        e0 = lens[0]
+        pos = [[300, e0 - N, e0 + 30, total - N - 2, L - N, L - N + 1], [L - 5, 2 * L + 100, e0 - N // 2, 0]]
+        xs = planted(rng, 2, total, tmpl, pos, noise=0.03)
+        for nseg in (1, 2):
+            e = emu.CorrEst(tmpl, 4.0, 1, 0.9, nchan=2)
+            o = [orc.CorrEst(tmpl, 4.0, 1, 0.9) for _ in range(2)]
+            k = ndet = 0
+            for i, Ln in enumerate(lens):
+                chunk = xs[:, k:k + Ln]
+                dense = (i == 2)
+                out, corr, tags, cnt, _ = e.work(chunk, want_corr=dense, force_nseg=nseg)
+                for c in range(2):
+                    oo, oc, ot = o[c].work(chunk[c], want_corr=dense)
+                    assert np.array_equal(out[c], oo), (mode, N, nseg, i, c)
+                    if dense:
+                        assert np.max(np.abs(corr[c] - oc)) / (np.max(np.abs(oc)) + 1e-30) < 2e-6
+                    ndet += assert_tags_match(tags[c], ot)
+                k += Ln
+            assert ndet >= 6 or N == 1
+    finally:
+        emu.lib().emu_corr_set_dma(1)
