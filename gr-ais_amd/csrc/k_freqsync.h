@@ -84,7 +84,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++)
         X[k1 * FS_ROW + l] = x[k1];
-    cx.sync();
+    cx.sync(); // (the W_64 table wave 0 wrote is now in place for every wave; from here on a wave only meets its own rows)
     {
         const int k1 = l >> 2, n3 = l & 3;
 #pragma unroll
@@ -98,7 +98,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
         for (int k2 = 0; k2 < 16; k2++)
             X[k1 * FS_ROW + k2 * 4 + n3] = x[k2];
     }
-    cx.sync();
+    cx.wave_lds_sync();
     float a[16];
     int kk[16];
 #pragma unroll
@@ -117,13 +117,13 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
         kk[4 * h + 2] = kb + 512;
         kk[4 * h + 3] = kb + 768;
     }
-    cx.sync();
+    cx.wave_lds_sync();
     // |X| in fft-shifted order: out[j] = X[(j + F/2) mod F]  <=>  j = (k + F/2) mod F
     float* A = (float*)X;
 #pragma unroll
     for (int e = 0; e < 16; e++)
         A[(kk[e] + FS_F / 2) & (FS_F - 1)] = a[e];
-    cx.sync();
+    cx.wave_lds_sync();
     // freqest search (lib/freqest_impl.cc:74-83)
     float best = 0.f;
     int bestj = -1;
