@@ -303,8 +303,9 @@ typedef struct aisx_chain aisx_chain;
  * aisx_msk_create(sps, clockrec_gain, omega_relative_limit, 1), the last three sized for
  * max_items + fftlen items per call.  fs = agc = NULL gives the chain BASELINE.json's metric
  * names (corr_est -> msk timing recovery only).  The handles stay the caller's (tags, status,
- * setters, profiling go through them) and must outlive the chain; while a chain drives them
- * they must not be called directly.
+ * setters, profiling go through them) and must outlive the chain; they must be fresh or reset
+ * when the chain is created (it keeps count of the items stream_to_vector holds back), and while
+ * a chain drives them they must not be called directly.  One thread at a time per chain.
  * The chain owns four streams, AISX_CHAIN_DEPTH sets of inter-stage buffers and the events that
  * order them: the sample passes of step k + 1 (one stream) run beside the timing recovery of step
  * k (a strict recurrence per channel, on its own stream), its bit tail and the NCO phase walk of
