@@ -67,6 +67,38 @@ def test_corr_dense_matches_oracle(ais, N):
         assert ndet >= 6
 
 
+@pytest.mark.parametrize("N", [20, 112, 512, 896, 1500])
+def test_corr_round1_builds_still_agree(ais, N, monkeypatch):
+    # AISX_CORR_DMA=0 selects round 1's correlators (k_corr_main, k_corr4_main: plain window loads,
+    # H and twiddles from L2) -- the A/B partners of k_corr2d_main / k_corr4d_main.  Same contract:
+    # the same input through both builds gives the same pass-through bits, the same tags to the
+    # tolerance of two FFT orderings, and both match the oracle.
+    rng = np.random.default_rng(300 + N)
+    tmpl = unit_template(rng, N)
+    lens = [9000, N // 2 + 1, 7000]
+    pos = [[700, 2900, 9000 - N // 2], [5, 12000], []]
+    x = planted(rng, 3, sum(lens), tmpl, pos)
+    monkeypatch.setenv("AISX_CORR_DMA", "0")
+    old = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=3, max_items=max(lens), max_tags_per_chan=512)
+    monkeypatch.setenv("AISX_CORR_DMA", "1")
+    new = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=3, max_items=max(lens), max_tags_per_chan=512)
+    ora = [orc.CorrEst(tmpl, 4.0, 1, 0.9) for _ in range(3)]
+    k = ndet = 0
+    for L in lens:
+        xd = _dev(x[:, k:k + L])
+        oo, _ = old.work(xd)
+        on, _ = new.work(xd)
+        assert np.array_equal(oo.cpu().numpy().view(np.uint32), on.cpu().numpy().view(np.uint32))
+        to, tn = _per_chan(old.tags(), 3), _per_chan(new.tags(), 3)
+        for c in range(3):
+            want_out, _, want_tags = ora[c].work(x[c, k:k + L])
+            assert np.array_equal(on[c].cpu().numpy(), want_out)
+            assert_tags_match(to[c], want_tags)
+            ndet += assert_tags_match(tn[c], want_tags)
+        k += L
+    assert ndet >= 4
+
+
 @pytest.mark.parametrize("N", [112, 896])
 def test_corr_sparse_streaming(ais, N):
     # port 1 not connected (sparse scratch + direct-form neighbours), successive
