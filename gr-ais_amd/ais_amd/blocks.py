@@ -267,6 +267,20 @@ class msk_timing_recovery_cc:
         check(_lib.lib().aisx_msk_last_status(self._h, C.byref(st), _stream_ptr(stream)), "last_status")
         return st.value
 
+    def set_max_noutput_items(self, m):
+        """gr::block::set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)."""
+        check(_lib.lib().aisx_msk_set_max_noutput_items(self._h, int(m)), "set_max_noutput_items")
+
+    def max_noutput_items(self):
+        return _lib.lib().aisx_msk_get_max_noutput_items(self._h)
+
+    def restart_stats(self, stream=None):
+        """What the time-parallel recovery made of the last call (sums over the channels)."""
+        a = (C.c_longlong * 6)()
+        check(_lib.lib().aisx_msk_restart_stats(self._h, a, _stream_ptr(stream)), "restart_stats")
+        return dict(restart_points=a[0], units_taken=a[1], symbols_from_units=a[2], units_ended_at_next=a[3],
+                    units_ended_elsewhere=a[4], calls=a[5])
+
     def general_work_host(self, noutput_items, ninput_items, buf, in_off, tags, nitems_read, in_has_lookahead=True):
         """GNU Radio path: in = &buf[in_off]; tags: structured array (TAG_DTYPE)."""
         buf = np.ascontiguousarray(buf, dtype=np.complex64)

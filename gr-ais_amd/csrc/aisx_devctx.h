@@ -110,6 +110,13 @@ struct DevCtx {
     __device__ __forceinline__ unsigned lane_next_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
+    // lane-wise select by a wave mask, as one v_cndmask_b32 the optimiser cannot look into
+    __device__ __forceinline__ float sel_f32(unsigned long long m, float if_set, float if_clear) const
+    {
+        float r;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+        return r;
+    }
     // scheduling fences: the value is materialised here, in program order with the other pins
     // (keeps speculated arithmetic above the branch that may discard it)
     __device__ __forceinline__ void pin(float& v) const { asm volatile("" : "+v"(v)); }
@@ -174,6 +181,13 @@ struct DevCtx {
     }
     // all of this wave's vector-memory operations (DMA included) have completed
     __device__ __forceinline__ void wait_dma() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // ... all but the N youngest (they complete in order)
+    template <int N>
+    __device__ __forceinline__ void wait_vm() const
+    {
+        static_assert(N >= 0 && N < 64, "vmcnt");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    }
     // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
     // outstanding global stores or for DMA still in flight
     __device__ __forceinline__ void lds_barrier() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

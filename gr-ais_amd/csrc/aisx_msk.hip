@@ -11,6 +11,7 @@
 #include "aisx_plan.h"
 #include "aisx_tables.h"
 #include "k_msk.h"
+#include "k_mskp.h"
 
 using namespace aisx;
 
@@ -50,6 +51,33 @@ __global__ __launch_bounds__(256) void k_msk_tagprep(TagPrepParams p)
 {
     DevCtx cx{ nullptr };
     tagprep_body(cx, p);
+}
+
+// ---- the time-parallel recovery (k_mskp.h): prepass, units, join, gather
+__global__ __launch_bounds__(64) void k_mskp_prep(MskpPrepParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[MSKP_PREP_LDS_TAGS * 8];
+    DevCtx cx{ smem };
+    mskp_prep_body(cx, p);
+}
+__global__ __launch_bounds__(64) void k_mskp_units(MskpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    mskp_body<DevCtx, false>(cx, p);
+}
+__global__ __launch_bounds__(64) void k_mskp_join(MskpParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    // one lane per channel, a recurrence: its waves go first on their SIMDs
+    __builtin_amdgcn_s_setprio(3);
+    mskp_body<DevCtx, true>(cx, p);
+}
+__global__ __launch_bounds__(256) void k_mskp_gather(MskpGatherParams p)
+{
+    DevCtx cx{ nullptr };
+    mskp_gather_body(cx, p);
 }
 
 // launch the timing-recovery build for (err/mu ports connected, osps == 2, channels per wave)
@@ -123,6 +151,22 @@ struct aisx_msk {
     int cur = 0;
     int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
     float *d_mmse = nullptr, *d_atan = nullptr;
+    // time-parallel path (k_mskp.h)
+    int tp_smax = 16;      // restart points per channel at most (0: the serial kernel)
+    int tp_min_gap = 0;    // items between restart points at least (0: max_items / tp_smax)
+    int max_noutput = 0;   // set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)
+    unsigned long long total_in = 0; // items handed to the block so far = absolute offset of the next row's item 0
+    msk_ctag* d_ctl = nullptr;
+    int* d_ctl_n = nullptr;
+    int ctl_cap = 0;
+    int* d_nrst = nullptr;
+    mskp_rst* d_rst = nullptr;
+    mskp_res* d_res = nullptr;
+    cf* d_stage[2] = { nullptr, nullptr };
+    long stage_stride = 0;
+    mskp_piece* d_pieces[2] = { nullptr, nullptr };
+    int* d_npieces[2] = { nullptr, nullptr };
+    long tp_calls = 0;
     // GNU Radio path staging
     cf *d_st_in = nullptr, *d_st_sym = nullptr;
     float *d_st_err = nullptr, *d_st_mu = nullptr;
@@ -182,6 +226,7 @@ static int msk_init_state(aisx_msk* h)
         AISX_HIPCHK(hipMemset(h->d_ctag_n[k], 0, sizeof(int) * nc));
     }
     h->cur = 0;
+    h->total_in = 0;
     return AISX_OK;
 }
 
@@ -226,6 +271,10 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         h->lpw = 8;
         if (const char* e = getenv("AISX_MSK_INLINE_TAGS"))
             h->inline_tags = atoi(e) != 0;
+        if (const char* e = getenv("AISX_MSK_TP_SMAX")) // restart points per channel (0: the serial kernel)
+            h->tp_smax = std::max(0, std::min(atoi(e), (int)MSKP_SMAX));
+        if (const char* e = getenv("AISX_MSK_TP_GAP"))
+            h->tp_min_gap = std::max(0, atoi(e));
         if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
@@ -309,6 +358,16 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
         (void)hipEventDestroy(h->ev_prep);
     dev_free(h->d_ct);
     dev_free(h->d_ct_n);
+    dev_free(h->d_ctl);
+    dev_free(h->d_ctl_n);
+    dev_free(h->d_nrst);
+    dev_free(h->d_rst);
+    dev_free(h->d_res);
+    for (int k = 0; k < 2; k++) {
+        dev_free(h->d_stage[k]);
+        dev_free(h->d_pieces[k]);
+        dev_free(h->d_npieces[k]);
+    }
     dev_free(h->d_nread);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_carry[k]);
@@ -381,6 +440,14 @@ extern "C" int aisx_msk_forecast(const aisx_msk* h, int noutput_items)
 {
     return h ? msk_forecast(h->d_sps, noutput_items) : AISX_ERR_INVALID;
 }
+extern "C" int aisx_msk_set_max_noutput_items(aisx_msk* h, int max_noutput_items)
+{
+    if (!h || max_noutput_items < 0)
+        return AISX_ERR_INVALID;
+    h->max_noutput = max_noutput_items;
+    return AISX_OK;
+}
+extern "C" int aisx_msk_get_max_noutput_items(const aisx_msk* h) { return h ? h->max_noutput : AISX_ERR_INVALID; }
 extern "C" int aisx_msk_out_capacity(const aisx_msk* h) { return h ? h->out_cap : AISX_ERR_INVALID; }
 extern "C" int aisx_msk_reset(aisx_msk* h)
 {
@@ -429,6 +496,7 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.tq_private = 0;
     p.lds_ring_off = msk_lds_ringoff(h->lpw);
     p.inline_tags = h->inline_tags;
+    p.max_noutput = h->max_noutput;
 }
 
 // compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows
@@ -489,6 +557,47 @@ static int msk_launch_bittail(aisx_msk* h, const cf* syms, long sym_stride, cons
     return AISX_OK;
 }
 
+// ---- the time-parallel path -------------------------------------------------------------------
+static bool msk_tp_applies(const aisx_msk* h, const float* d_err, const float* d_mu)
+{
+    // (osps = 2 and the err / mu ports stay with the serial kernel: after a restart the first err
+    // of a unit would need the previous unit's last nlin_out)
+    return h->tp_smax > 0 && h->osps == 1 && !d_err && !d_mu &&
+           mskp_geometry_ok(h->d_sps, h->gain, h->limit, h->max_items + aisx_msk::carry_cap);
+}
+
+static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
+{
+    int rc;
+    const int need = MSKP_TPRE + tag_cap + 1;
+    bool fresh = false;
+    if (need > h->ctl_cap || !h->d_ctl) {
+        AISX_HIPCHK(hipStreamSynchronize(st));
+        dev_free(h->d_ctl);
+        h->d_ctl = nullptr;
+        h->ctl_cap = 0;
+        if ((rc = dev_alloc(&h->d_ctl, (size_t)h->nchan * (size_t)need)) != AISX_OK)
+            return rc;
+        h->ctl_cap = need;
+        fresh = true;
+    }
+    if (!h->d_rst) {
+        const size_t nc = (size_t)h->nchan;
+        h->stage_stride = mskp_stage_stride(h->max_items + aisx_msk::carry_cap, h->d_sps, h->gain, h->limit);
+        if ((rc = dev_alloc(&h->d_ctl_n, nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, nc)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_rst, nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, nc * MSKP_SMAX)) != AISX_OK)
+            return rc;
+        for (int k = 0; k < 2; k++)
+            if ((rc = dev_alloc(&h->d_stage[k], nc * (size_t)h->stage_stride)) != AISX_OK ||
+                (rc = dev_alloc(&h->d_pieces[k], nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_npieces[k], nc)) != AISX_OK)
+                return rc;
+        fresh = true;
+    }
+    if (fresh) // dev_alloc's zero fill runs on the null stream: it must not trail into the kernels on `st`
+        AISX_HIPCHK(hipDeviceSynchronize());
+    return AISX_OK;
+}
+
 extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
                                        const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
                                        float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
@@ -502,34 +611,56 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         set_err("aisx_msk_process_stream: out_stride < 1");
         return AISX_ERR_INVALID;
     }
-    int rc;
-    if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, (hipStream_t)stream)) != AISX_OK)
-        return rc;
-    if (h->ev_prep) {
-        AISX_HIPCHK(hipEventRecord(h->ev_prep, (hipStream_t)stream));
-        h->ev_prep_set = true;
-    }
-    MskParams p;
-    msk_fill_common(h, p);
-    p.in = (const cf*)d_in;
-    p.in_stride = in_stride;
-    p.n = n;
-    p.stream_mode = 1;
-    p.gr_ninput = 0;
-    p.gr_noutput = 0;
-    cf* syms = (cf*)d_syms;
     if (out_stride >= (1L << 23)) {
         set_err("aisx_msk_process_stream: out_stride %ld too large (the 64 rows of a wave must lie within 4 GiB)", out_stride);
         return AISX_ERR_INVALID;
     }
+    hipStream_t st = (hipStream_t)stream;
+    const bool tp = msk_tp_applies(h, d_err, d_mu);
+    int rc, t_smax = 0;
+    if (tp) {
+        if ((rc = msk_tp_buffers(h, d_tags ? tag_cap : 0, st)) != AISX_OK)
+            return rc;
+        MskpPrepParams t;
+        t.nchan = h->nchan;
+        t.tags = (const tag_rec*)d_tags;
+        t.tag_count = d_tag_counts;
+        t.tag_cap = tag_cap;
+        t.W = h->total_in;
+        t.n = n;
+        t.d_sps = h->d_sps;
+        t.gain = h->gain;
+        t.limit = h->limit;
+        t.ctl = h->d_ctl;
+        t.ctl_n = h->d_ctl_n;
+        t.ctl_cap = h->ctl_cap;
+        // (units run blind to the general_work calls: with a max_noutput_items the call boundaries must
+        // leave an un-blocked loop alone, which needs d_sps >= 2 -- see mskp_body's walk)
+        t.smax = (h->max_noutput > 0 && h->d_sps < 2.0f) ? 0 : h->tp_smax;
+        t_smax = t.smax;
+        t.nrst = h->d_nrst;
+        t.rst = h->d_rst;
+        t.stage_stride = h->stage_stride;
+        t.tail = mskp_tail(h->d_sps);
+        t.min_gap = h->tp_min_gap > 0 ? h->tp_min_gap : std::max(64, n / std::max(1, h->tp_smax));
+        hipLaunchKernelGGL(k_mskp_prep, dim3(h->nchan), dim3(64), 0, st, t);
+        AISX_HIPCHK(hipGetLastError());
+    } else if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st)) != AISX_OK) {
+        return rc;
+    }
+    if (h->ev_prep) {
+        AISX_HIPCHK(hipEventRecord(h->ev_prep, st));
+        h->ev_prep_set = true;
+    }
+    cf* syms = (cf*)d_syms;
     const int par = h->callpar;
     h->callpar ^= 1;
     if (h->tail_on && h->ev_tail_set[par]) // the bit tail of two calls ago may still read this parity's buffers
-        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_tail[par], 0));
+        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_tail[par], 0));
     if (!syms) { // the kernel always writes symbols (the bit tail reads them back): give them a home
         const size_t need = (size_t)h->nchan * (size_t)out_stride;
         if (need > h->symscratch_len[par]) {
-            AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            AISX_HIPCHK(hipStreamSynchronize(st));
             dev_free(h->d_symscratch[par]);
             h->d_symscratch[par] = nullptr;
             h->symscratch_len[par] = 0;
@@ -540,27 +671,121 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         }
         syms = h->d_symscratch[par];
     }
-    p.syms = syms;
-    p.err = d_err;
-    p.mu_out = d_mu;
-    p.out_stride = out_stride;
-    p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
-    p.out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
-    p.produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
-    if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), (hipStream_t)stream)) != AISX_OK)
-        return rc;
+    int* produced = d_produced ? d_produced : (par ? h->d_produced2 : h->d_produced);
+    const int out_cap = (int)std::min<long>(out_stride, 0x7fffffff);
+    if (tp) {
+        MskpParams p;
+        p.nchan = h->nchan;
+        p.d_sps = h->d_sps;
+        p.gain = h->gain;
+        p.gain_omega = h->gain_omega;
+        p.limit = h->limit;
+        p.mu = h->d_mu;
+        p.omega = h->d_omega;
+        p.div = h->d_div;
+        p.dly1 = h->d_dly1;
+        p.dly2 = h->d_dly2;
+        p.diff1 = h->d_diff1;
+        p.nread = h->d_nread;
+        p.in = (const cf*)d_in;
+        p.in_stride = in_stride;
+        p.n = n;
+        p.carry_in = h->d_carry[h->cur];
+        p.carry_out = h->d_carry[h->cur ^ 1];
+        p.carry_len_in = h->d_carry_len[h->cur];
+        p.carry_len_out = h->d_carry_len[h->cur ^ 1];
+        p.carry_cap = aisx_msk::carry_cap;
+        p.ctag_in = h->d_ctag[h->cur];
+        p.ctag_n_in = h->d_ctag_n[h->cur];
+        p.ctag_out = h->d_ctag[h->cur ^ 1];
+        p.ctag_n_out = h->d_ctag_n[h->cur ^ 1];
+        p.ctag_cap = aisx_msk::ctag_cap;
+        p.ctl = h->d_ctl;
+        p.ctl_n = h->d_ctl_n;
+        p.ctl_cap = h->ctl_cap;
+        p.smax = h->tp_smax;
+        p.nrst = h->d_nrst;
+        p.rst = h->d_rst;
+        p.res = h->d_res;
+        p.stage = h->d_stage[par];
+        p.stage_stride = h->stage_stride;
+        p.syms = syms;
+        p.out_stride = out_stride;
+        p.out_cap = out_cap;
+        p.pieces = h->d_pieces[par];
+        p.npieces = h->d_npieces[par];
+        p.produced = produced;
+        p.consumed = h->d_consumed;
+        p.status = h->d_status;
+        p.mmse = h->d_mmse;
+        p.W = h->total_in;
+        p.look = mskp_look(h->d_sps, h->limit);
+        p.tail = mskp_tail(h->d_sps);
+        p.max_noutput = h->max_noutput;
+        static bool attr_set = false;
+        if (!attr_set) {
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)k_mskp_units, hipFuncAttributeMaxDynamicSharedMemorySize, MSKP_LDS_BYTES));
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)k_mskp_join, hipFuncAttributeMaxDynamicSharedMemorySize, MSKP_LDS_BYTES));
+            attr_set = true;
+        }
+        if (t_smax > 0) {
+            const long units = (long)h->nchan * h->tp_smax;
+            hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64)), dim3(64), MSKP_LDS_BYTES, st, p);
+            AISX_HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + 63) / 64), dim3(64), MSKP_LDS_BYTES, st, p);
+        AISX_HIPCHK(hipGetLastError());
+        h->tp_calls++;
+    } else {
+        MskParams p;
+        msk_fill_common(h, p);
+        p.in = (const cf*)d_in;
+        p.in_stride = in_stride;
+        p.n = n;
+        p.stream_mode = 1;
+        p.gr_ninput = 0;
+        p.gr_noutput = 0;
+        p.syms = syms;
+        p.err = d_err;
+        p.mu_out = d_mu;
+        p.out_stride = out_stride;
+        p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
+        p.out_cap = out_cap;
+        p.produced = produced;
+        if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), st)) != AISX_OK)
+            return rc;
+    }
     h->cur ^= 1;
+    h->total_in += (unsigned long long)n;
+    MskpGatherParams g;
+    if (tp) {
+        g.nchan = h->nchan;
+        g.pieces = h->d_pieces[par];
+        g.npieces = h->d_npieces[par];
+        g.stage = h->d_stage[par];
+        g.stage_stride = h->stage_stride;
+        g.syms = syms;
+        g.out_stride = out_stride;
+        if (d_syms || !d_bits || !h->tail_on) { // the caller's own symbol rows are complete when `stream` is
+            hipLaunchKernelGGL(k_mskp_gather, dim3(MSKP_GATHER_X, h->nchan), dim3(256), 0, st, g);
+            AISX_HIPCHK(hipGetLastError());
+        }
+    }
     if (d_bits) {
         // a call produces at most forecast^-1(n + carry) symbols; out_cap bounds it too
         const double wmin = (double)h->d_sps - fabs((double)h->limit);
-        const int max_out = std::min<long>(p.out_cap, (long)ceil((n + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16);
-        hipStream_t ts = (hipStream_t)stream;
+        const int max_out = std::min<long>(out_cap, (long)ceil((n + aisx_msk::carry_cap) / (2.0 * wmin)) * h->osps + 16);
+        hipStream_t ts = st;
         if (h->tail_on) { // the bit tail has no part in the recurrence: let the next call start
-            AISX_HIPCHK(hipEventRecord(h->ev_msk, (hipStream_t)stream));
+            AISX_HIPCHK(hipEventRecord(h->ev_msk, st));
             AISX_HIPCHK(hipStreamWaitEvent(h->tail_stream, h->ev_msk, 0));
             ts = h->tail_stream;
+            if (tp && !d_syms) { // the units' symbols join the others on the tail stream
+                hipLaunchKernelGGL(k_mskp_gather, dim3(MSKP_GATHER_X, h->nchan), dim3(256), 0, ts, g);
+                AISX_HIPCHK(hipGetLastError());
+            }
         }
-        if ((rc = msk_launch_bittail(h, syms, out_stride, p.produced, d_bits, out_stride, max_out, ts)) != AISX_OK)
+        if ((rc = msk_launch_bittail(h, syms, out_stride, produced, d_bits, out_stride, max_out, ts)) != AISX_OK)
             return rc;
         if (h->tail_on) {
             AISX_HIPCHK(hipEventRecord(h->ev_tail[par], h->tail_stream));
@@ -621,6 +846,39 @@ extern "C" int aisx_msk_wait_prepass(aisx_msk* h, void* stream)
         if (us > 0) {
             hipLaunchKernelGGL(k_msk_headstart, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)(us * 100));
             AISX_HIPCHK(hipGetLastError());
+        }
+    }
+    return AISX_OK;
+}
+
+// what the time-parallel path made of the last call (diagnostics; waits for `stream`)
+extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream)
+{
+    if (!h || !out6)
+        return AISX_ERR_INVALID;
+    for (int i = 0; i < 6; i++)
+        out6[i] = 0;
+    out6[5] = h->tp_calls;
+    if (!h->d_rst || h->tp_calls == 0)
+        return AISX_OK;
+    const int par = h->callpar ^ 1; // the call before this one
+    const size_t nc = (size_t)h->nchan;
+    std::vector<int> nrst(nc), np(nc);
+    std::vector<mskp_piece> pc(nc * MSKP_SMAX);
+    std::vector<mskp_res> rs(nc * MSKP_SMAX);
+    AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    AISX_HIPCHK(hipMemcpy(nrst.data(), h->d_nrst, sizeof(int) * nc, hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(np.data(), h->d_npieces[par], sizeof(int) * nc, hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(pc.data(), h->d_pieces[par], sizeof(mskp_piece) * pc.size(), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(rs.data(), h->d_res, sizeof(mskp_res) * rs.size(), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < nc; c++) {
+        out6[0] += nrst[c];                     // restart points chosen
+        out6[1] += np[c];                       // units whose run was taken over
+        for (int i = 0; i < np[c]; i++)
+            out6[2] += pc[c * MSKP_SMAX + i].cnt; // symbols that came from units
+        for (int i = 0; i < nrst[c]; i++) {
+            out6[3] += rs[c * MSKP_SMAX + i].kind == MSKP_KIND_NEXT;    // units that ended at the next restart point
+            out6[4] += rs[c * MSKP_SMAX + i].kind == MSKP_KIND_HANDOFF; // ... somewhere else (stale tag, end of the row)
         }
     }
     return AISX_OK;

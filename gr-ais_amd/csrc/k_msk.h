@@ -133,6 +133,7 @@ struct MskParams {
     int sym_al16;      // every output row starts 16-byte aligned (syms pointer and out_stride both even in items)
     int lpw;           // channels per wave, = the build's LPW: 4, 8, 16, 32 or 64
     int inline_tags;   // tag resets inside the lock-step runs (0: every tag through the general steps)
+    int max_noutput;   // gr::block::set_max_noutput_items(): output items a general_work call is offered at most (0: what fits)
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -366,6 +367,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 while (noutput > 0 && msk_forecast(d_sps, noutput) > ninput)
                     noutput--;
             }
+            if (p.max_noutput > 0 && noutput > p.max_noutput)
+                noutput = p.max_noutput;
             if (noutput > p.out_cap - ototal) {
                 noutput = p.out_cap - ototal;
                 status |= MSK_ST_OUT_FULL;

@@ -1,0 +1,968 @@
+// k_mskp.h -- msk_timing_recovery_cc (reference: lib/msk_timing_recovery_cc_impl.cc:107-206),
+// parallel in time.
+//
+// The reference loop is a recurrence through (d_mu, d_omega, iidx, the two delay registers).  But a
+// time_est tag resets d_mu, iidx, d_div and d_omega from the tag alone (:140-164), and corr_est
+// leaves its time_est tags in PAIRS one symbol apart (two preamble peaks): when tag A resets the
+// loop, the iteration after it (A: d_div even, no loop filter, :179) and the next one (B) read
+// samples at positions that follow from tag A only, and when tag B then resets the loop two
+// iterations later the whole state -- d_mu, iidx, d_div = 0, d_omega = d_sps from tag B;
+// d_dly_conj_2 = y_B; d_dly_diff_1 = y_B^2 conj(y_A^2) -- is a function of the two tags and the
+// samples.  Such a pair is a RESTART POINT: the loop can be entered there without knowing
+// anything that came before.  Whether the serial loop really does pass through that state is
+// history (tag B is stepped over when iteration B advances by three samples, or blocked behind
+// an older stale tag, :142), so it is CHECKED, bit for bit, and what does not check is re-run.
+//
+//   mskp_prep_body : one wave per channel.  Compacts this call's time_est tags to (row offset,
+//                    float value), picks restart points about n / smax samples apart.
+//   mskp_body<SPEC>: one LANE per (channel, restart point): enters at the restart point and runs
+//                    the reference iteration to the next restart point; leaves its symbols in a
+//                    staging row and its end state in memory.  Needs nothing from the previous
+//                    call (row coordinates: item 0 = first new item of this call).
+//   mskp_body<JOIN>: one lane per channel: the scheduler of the stream contract (DESIGN.md
+//                    section 2) and the serial loop from the carried state.  When the front tag
+//                    is a restart point's tag B about to fire and the two delay registers equal
+//                    the ones that unit assumed, the unit's run IS the serial loop's: the lane
+//                    takes the unit's symbol count and end state and goes on from there -- through
+//                    the following units too while each one ended on the next one's assumption.
+//                    Anything else (a junction that does not check, a stale tag, the end of the
+//                    general_work call) it runs itself.
+//   mskp_gather_body: copies the accepted units' symbols from the staging rows into the output row.
+//
+// Both kernels run the same engine: every lane keeps the last 64 samples of ITS stream in an
+// LDS ring (slot-major: ring[slot][lane], conflict-free however far the lanes are apart), the
+// rings are refilled in lock step (block L of eight samples of every lane at once, by LDS-DMA --
+// `buffer_load_dwordx4 ... lds`, 16 bytes per lane straight into the ring row, no registers --
+// issued MSKP_D blocks ahead and awaited with an exact s_waitcnt vmcnt(n): the symbol stores and
+// the younger blocks stay in flight), and a trip of the loop runs one even and one odd iteration per
+// lane with the tag tests in line, predicated, no divergence.  All arithmetic is the
+// reference's float sequence, unfused: symbols are bit-identical to the serial kernel's
+// (k_msk.h), which stays for osps = 2, the err / mu ports and the GNU Radio work call.
+#pragma once
+#include "aisx_common.h"
+#include "k_msk.h"
+
+namespace aisx {
+
+#ifndef MSKP_R
+#define MSKP_R 64                        // ring slots per lane (power of two)
+#endif
+#ifndef MSKP_D
+#define MSKP_D 3                         // blocks in flight (LDS-DMA) ahead of the last one readable
+#endif
+constexpr int MSKP_NB = MSKP_R / 8;      // blocks of eight samples in the ring
+constexpr int MSKP_ROWS = MSKP_R / 2;    // ring rows: row r = two consecutive samples of every lane, [row][lane] 16 bytes each
+constexpr int MSKP_SLOTS = MSKP_R + 8;   // + 4 mirror rows: five rows from any row never wrap
+static_assert(MSKP_NB - MSKP_D >= 4, "readable window of the rings");
+constexpr int MSKP_TQ = 8;               // time_est tags staged in LDS per lane
+constexpr int MSKP_TPRE = 64;            // room in front of a channel's new-tag list for the carried tags
+constexpr int MSKP_SMAX = 32;            // restart points per channel at most
+constexpr int MSKP_PREP_LDS_TAGS = 2048; // tags of a channel the restart search looks at
+constexpr int MSKP_GATHER_X = 4;         // workgroups per channel of the gather kernel
+constexpr int MSKP_WALK_EVERY = 32;      // trips a lane waits at a junction at most while others still run
+constexpr int MSKP_LDS_RING = MSKP_SLOTS * 64 * 8;
+constexpr int MSKP_LDS_TQ = MSKP_TQ * 64 * 8;
+constexpr int MSKP_LDS_BYTES = MSKP_LDS_RING + MSKP_LDS_TQ + MSK_LDS_MMSE;
+
+enum { MSKP_KIND_NONE = 0, MSKP_KIND_NEXT = 1, MSKP_KIND_HANDOFF = 2 };
+
+// restart point k of a channel: tags jA and jA + 1 of the channel's list of new time_est tags
+struct mskp_rst {
+    int jA;
+    int relA, relB; // row offsets of the two tags
+    int q0, cap;    // the unit's slots in the channel's staging row
+    int pad[3];
+};
+// the loop at the top of an iteration, before the tag test (:138-140)
+struct mskp_snap {
+    int a;          // iidx, as a row offset
+    float mu, omega;
+    int div;
+    cf y;           // d_dly_conj_1 = d_dly_conj_2 (:194-195)
+    cf nl;          // d_dly_diff_1
+    int cur;        // index of the front tag in the new-tag list
+    int cnt;        // symbols emitted
+};
+// what a unit leaves behind
+struct mskp_res {
+    mskp_snap end;
+    cf ay, anl;     // the delay registers it assumed at its restart point
+    int kind;       // MSKP_KIND_*: ended where the next restart point's tag B is about to fire / somewhere else
+    int status;
+};
+struct mskp_piece {
+    int out0, src0, cnt; // symbols [out0, out0 + cnt) of the output row = staging row [src0, src0 + cnt)
+};
+
+struct MskpParams {
+    int nchan;
+    float d_sps, gain, gain_omega, limit; // loop constants (set_sps / set_gain / set_limit, :69-96)
+    // per-channel loop state and carry, as k_msk.h keeps them (the two kernels are interchangeable call by call)
+    float* mu; float* omega; int* div;
+    cf* dly1; cf* dly2; cf* diff1;
+    unsigned long long* nread;
+    const cf* in; long in_stride; int n;
+    const cf* carry_in; cf* carry_out; const int* carry_len_in; int* carry_len_out; int carry_cap;
+    const tag_rec* ctag_in; const int* ctag_n_in; tag_rec* ctag_out; int* ctag_n_out; int ctag_cap;
+    // this call's time_est tags, compacted by the prepass: entry k of channel c at ctl[c * ctl_cap + MSKP_TPRE + k]
+    msk_ctag* ctl; const int* ctl_n; int ctl_cap;
+    // restart points and what the units made of them
+    int smax; const int* nrst; const mskp_rst* rst; mskp_res* res;
+    cf* stage; long stage_stride;
+    // output
+    cf* syms; long out_stride; int out_cap;
+    mskp_piece* pieces; int* npieces;
+    int* produced; int* consumed; int* status;
+    const float* mmse;          // [129][8]
+    unsigned long long W;       // absolute offset of row item 0 (items handed to the block before this call)
+    int look;                   // samples a trip may read beyond in[iidx]
+    int tail;                   // units stop this many items before the end of the row
+    int max_noutput;            // set_max_noutput_items(): output items a general_work call is offered at most (0: what fits)
+};
+
+struct MskpPrepParams {
+    int nchan;
+    const tag_rec* tags; const int* tag_count; int tag_cap; // this call's tags, any keys (may be null)
+    unsigned long long W;
+    int n;
+    float d_sps, gain, limit;
+    msk_ctag* ctl; int* ctl_n; int ctl_cap;
+    int smax; int* nrst; mskp_rst* rst;
+    long stage_stride;
+    int tail;
+    int min_gap;    // restart points at least this many items apart
+};
+
+struct MskpGatherParams {
+    int nchan;
+    const mskp_piece* pieces; const int* npieces;
+    const cf* stage; long stage_stride;
+    cf* syms; long out_stride;
+};
+
+// ---- what the host derives from the loop constants
+// lanes of the speculative kernel test `offset < iidx + d_sps` (:142) with iidx counted from the
+// start of the row, the reference from nitems_read: the float sum must round to the same side of
+// every integer for both, i.e. d_sps is an integer or well away from one (iidx < 2^18: ulp 2^-6)
+AISX_HD bool mskp_geometry_ok(float d_sps, float gain, float limit, int max_items)
+{
+    const float fr = d_sps - floorf(d_sps);
+    const bool coord_ok = fr == 0.f || (fr > 0.04f && fr < 0.96f);
+    const bool lock_ok = 3.0f * fabsf(gain) + fabsf(limit) + 0.01f < d_sps; // mu + omega stays positive
+    const float m = 2.0f * (d_sps - fabsf(limit)) - 3.0f * fabsf(gain);
+    return coord_ok && lock_ok && m > 1.0f && d_sps <= 12.f && max_items <= (1 << 18) - 1024;
+}
+AISX_HD int mskp_look(float d_sps, float limit) { return (int)ceilf(d_sps) + (int)floorf(1.f + d_sps + fabsf(limit)) + 8; }
+AISX_HD int mskp_tail(float d_sps) { return 64 + (int)ceilf(3.f * d_sps) + (int)ceilf(d_sps); }
+// staging slots per channel (the prepass drops restart points that would not fit)
+AISX_HD long mskp_stage_stride(int max_items, float d_sps, float gain, float limit)
+{
+    const float m = 2.0f * (d_sps - fabsf(limit)) - 3.0f * fabsf(gain);
+    return (long)((float)(max_items + 16 * MSKP_SMAX) / m) + 2 * MSKP_PREP_LDS_TAGS + 17 * MSKP_SMAX + 64;
+}
+
+AISX_HD bool mskp_tame(float v) { return v >= -1.0f && v <= 1.0f; } // (false for NaN)
+AISX_HD bool mskp_same_bits(cf a, cf b)
+{
+    unsigned ar, ai, br, bi;
+    __builtin_memcpy(&ar, &a.re, 4);
+    __builtin_memcpy(&ai, &a.im, 4);
+    __builtin_memcpy(&br, &b.re, 4);
+    __builtin_memcpy(&bi, &b.im, 4);
+    return ar == br && ai == bi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Prepass: one wave per channel.
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+AISX_DI void mskp_prep_body(Ctx& cx, const MskpPrepParams& p)
+{
+    const int l = cx.tid() & 63;
+    const int c = cx.bx() * (cx.nthreads() >> 6) + (cx.tid() >> 6);
+    msk_ctag* const lt = (msk_ctag*)cx.lds() + (cx.tid() >> 6) * MSKP_PREP_LDS_TAGS;
+    if (c >= p.nchan)
+        return;
+    msk_ctag* out = p.ctl + (long)c * p.ctl_cap + MSKP_TPRE;
+    const int room = p.ctl_cap - MSKP_TPRE;
+    int w = 0; // wave-uniform
+    bool wild = false, trunc = false;
+    if (p.tags) {
+        int nn = p.tag_count[c];
+        if (nn > p.tag_cap) { // the producer (corr_est) ran out of room: the list is incomplete
+            nn = p.tag_cap;
+            trunc = true;
+        }
+        const tag_rec* list = p.tags + (long)c * p.tag_cap;
+        for (int k0 = 0; k0 < nn; k0 += 64) {
+            const int k = k0 + l;
+            tag_rec t;
+            t.offset = 0;
+            t.value = 0;
+            t.key = -1;
+            if (k < nn)
+                t = list[k];
+            const bool keep = (k < nn) && t.key == KEY_TIME_EST; // (:125-130 asks for that key only)
+            const float tv = (float)t.value;
+            if (cx.ballot(keep && !mskp_tame(tv)) != 0ull)
+                wild = true;
+            const unsigned long long m = cx.ballot(keep);
+            const int pos = w + aisx_popc64(m & ((1ull << l) - 1ull));
+            if (keep && pos < room) {
+                const long long d = (long long)(t.offset - p.W);
+                msk_ctag e;
+                e.rel = d > 0x3ffffff0ll ? 0x3ffffff0 : (d < -0x3ffffff0ll ? -0x3ffffff0 : (int)d);
+                e.val = tv;
+                out[pos] = e;
+                if (pos < MSKP_PREP_LDS_TAGS)
+                    lt[pos] = e;
+            }
+            w += aisx_popc64(m);
+        }
+    }
+    if (w > room) {
+        w = room;
+        trunc = true;
+    }
+    cx.wave_lds_sync();
+    if (l != 0)
+        return;
+    p.ctl_n[c] = w | (trunc ? MSK_CTN_TRUNC : 0) | (wild ? MSK_CTN_WILD : 0);
+    // ---- restart points: pairs (k, k + 1) the loop is expected to pass as A, B, reset (see the header)
+    mskp_rst* rs = p.rst + (long)c * MSKP_SMAX;
+    int K = 0;
+    const int nn = w < MSKP_PREP_LDS_TAGS ? w : MSKP_PREP_LDS_TAGS;
+    const int lim = p.n - p.tail; // units stop there
+    const float d_sps = p.d_sps;
+    // symbols a unit can emit: every pair moves iidx by at least m items, a tag adds at most two
+    const float m = 2.0f * (d_sps - fabsf(p.limit)) - 3.0f * fabsf(p.gain);
+    auto pair_ok = [&](int k) -> bool {
+        const msk_ctag A = lt[k], B = lt[k + 1];
+        if (!mskp_tame(A.val) || !mskp_tame(B.val))
+            return false;
+        if (A.rel < 8 || B.rel >= lim - 16 || B.rel <= A.rel)
+            return false;
+        int iA = A.rel;
+        float mA = A.val;
+        if (mA < 0) { // :150-153
+            mA++;
+            iA--;
+        }
+        const float m1 = mA + d_sps; // :199-201 after iteration A (d_omega = d_sps, :155)
+        const int iB = iA + (int)floorf(m1);
+        const float muB = m1 - floorf(m1);
+        if ((B.rel >= iB) && ((float)B.rel < (float)iB + d_sps)) // tag B would fire one iteration early
+            return false;
+        const int iC = iB + (int)floorf(muB + d_sps); // where iteration C starts if the loop filter does not move it
+        return B.rel >= iC - 1 && (float)B.rel < (float)(iC + 1) + d_sps;
+    };
+    if (p.smax > 0 && m > 0.5f && lim > 64) {
+        int last = -0x40000000;
+        int klast = -1; // the last pair of all: the stretch from there to the end of the row is serial
+        for (int k = nn - 2; k >= 0 && klast < 0; k--)
+            if (pair_ok(k))
+                klast = k;
+        for (int k = 0; k + 1 < nn && K < p.smax && K < MSKP_SMAX; k++) {
+            const int relB = lt[k + 1].rel;
+            const bool is_last = k == klast;
+            // (the first pair is taken as it comes: the serial stretch in front of it is short)
+            if (K > 0 && relB < last + (is_last ? 64 : p.min_gap))
+                continue;
+            if (!is_last && K + 1 >= p.smax && klast > k)
+                continue; // keep the last slot for the last pair
+            if (!pair_ok(k))
+                continue;
+            rs[K].jA = k;
+            rs[K].relA = lt[k].rel;
+            rs[K].relB = relB;
+            last = relB;
+            K++;
+            k++; // (tag B is not some other pair's tag A)
+        }
+        // staging slots: unit k emits at most span / m + 2 per tag + a few symbols
+        long q = 0;
+        int Kfit = 0;
+        for (int k = 0; k < K; k++) {
+            const int end = k + 1 < K ? rs[k + 1].relB : lim;
+            const int jend = k + 1 < K ? rs[k + 1].jA + 1 : nn;
+            const int cap = (int)((float)(end - rs[k].relB + 16) / m) + 2 * (jend - rs[k].jA) + 16;
+            if (q + cap > p.stage_stride)
+                break;
+            rs[k].q0 = (int)q;
+            rs[k].cap = cap;
+            q += cap;
+            Kfit = k + 1;
+        }
+        K = Kfit;
+    }
+    p.nrst[c] = K;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The engine.
+// ---------------------------------------------------------------------------------------------
+template <class Ctx, bool JOIN>
+AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
+{
+    typedef unsigned long long u64;
+    const int lane = cx.tid() & 63;
+    const int wv = cx.bx() * (cx.nthreads() >> 6) + (cx.tid() >> 6);
+    char* const lds = cx.lds() + (cx.tid() >> 6) * MSKP_LDS_BYTES; // (one wave per workgroup in the product)
+    cf* const ring = (cf*)lds + lane;                                      // slot s: ring[s * 64]
+    msk_ctag* const tq = (msk_ctag*)(lds + MSKP_LDS_RING) + lane;          // entry e: tq[e * 64]
+    float* const mm = (float*)(lds + MSKP_LDS_RING + MSKP_LDS_TQ);         // [130][MSK_TAPS_PITCH]
+    for (int i = lane; i < 129 * 8; i += 64)
+        mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
+    if (lane < MSK_TAPS_PITCH)
+        mm[MSK_ZERO_ROW * MSK_TAPS_PITCH + lane] = 0.f;
+    cx.wave_lds_sync();
+
+    // ---- which unit this lane is
+    int c, k = 0;
+    if (JOIN) {
+        c = wv * 64 + lane;
+    } else {
+        const int u = wv * 64 + lane;
+        c = u / p.smax;
+        k = u - c * p.smax;
+    }
+    bool valid = c < p.nchan;
+    const int cc = valid ? c : 0;
+    const int K = p.nrst[cc];
+    if (!JOIN && k >= K)
+        valid = false;
+    if (cx.ballot(valid) == 0ull)
+        return;
+
+    const float d_sps = p.d_sps;
+    const int n = p.n;
+    const cf* const myin = p.in + (long)cc * p.in_stride;
+    const cf* const cin = p.carry_in + (long)cc * p.carry_cap;
+    int pending = 0;
+    if (JOIN) {
+        pending = p.carry_len_in[cc];
+        if (pending > MSK_CARRY_MAX)
+            pending = MSK_CARRY_MAX;
+    }
+    const mskp_rst* const rs = p.rst + (long)cc * MSKP_SMAX;
+    mskp_res* const rr = p.res + (long)cc * MSKP_SMAX;
+    int status = 0;
+
+    // ---- the tag list of this lane: (JOIN: the carried tags in front of) the new ones
+    int nc = 0;
+    int nn = p.ctl_n[cc];
+    if (nn & MSK_CTN_TRUNC)
+        status |= JOIN ? MSK_ST_TAGS_TRUNCATED : 0;
+    nn &= MSK_CTN_WILD - 1;
+    msk_ctag* ctl = p.ctl + (long)cc * p.ctl_cap + MSKP_TPRE;
+    const u64 R = p.nread[cc];
+    if (JOIN && valid) {
+        // tags the scheduler still held (offset >= nitems_read), in front of the new ones
+        int ncin = p.ctag_n_in[cc];
+        if (ncin > p.ctag_cap)
+            ncin = p.ctag_cap;
+        if (ncin > MSKP_TPRE)
+            ncin = MSKP_TPRE;
+        const tag_rec* ci = p.ctag_in + (long)cc * p.ctag_cap;
+        for (int j = ncin - 1; j >= 0; j--) {
+            const tag_rec t = ci[j];
+            if (t.key != KEY_TIME_EST || t.offset < R)
+                continue;
+            const long long d = (long long)(t.offset - p.W);
+            msk_ctag e;
+            e.rel = d > 0x3ffffff0ll ? 0x3ffffff0 : (d < -0x3ffffff0ll ? -0x3ffffff0 : (int)d);
+            e.val = (float)t.value;
+            nc++;
+            ctl[-nc] = e;
+        }
+        ctl -= nc;
+    }
+    const int ntot = nc + nn;
+
+    // ---- loop state
+    int a = 0;          // iidx as a row offset
+    float mu = 0.f, om = d_sps;
+    int dv = 0;
+    cf y = mk(0.f, 0.f), nl = mk(0.f, 0.f);
+    int cur = 0, cnt = 0;
+    bool running = valid;
+    unsigned worst_row = 0;
+    // JOIN: the general_work call in progress
+    int base_row = 0, ninp_row = 0x3fffffff, nout_tot = 0x3fffffff;
+    bool fin = false;       // the stream contract's step is over for this channel
+    bool atj = false;       // stopped where restart point `cand`'s tag B is about to fire
+    int cand = 0, cand_j = 0x7fffffff;
+    int np = 0;             // pieces written
+    // SPEC: where the unit ends
+    bool warm = !JOIN;
+    int stop_j = 0x7fffffff, lim_a = 0, q0 = 0, cap = 0x3fffffff, kind = MSKP_KIND_NONE;
+    cf ay = mk(0.f, 0.f), anl = mk(0.f, 0.f);
+    int relB = 0;
+
+    // ---- tag queue
+    int qhi = 0;                 // entries [.., qhi) of the list are staged (slot = index & (MSKP_TQ - 1))
+    bool hasq = false, needq = false;
+    int t_rel = 0;
+    float t_val = 0.f;
+    auto tq_front = [&]() {
+        hasq = cur < qhi;
+        needq = !hasq && cur < ntot;
+        if (hasq) {
+            const msk_ctag e = tq[(cur & (MSKP_TQ - 1)) * 64];
+            t_rel = e.rel;
+            t_val = e.val;
+        }
+    };
+    auto tq_load = [&]() { // (rare) stage entries [cur, cur + MSKP_TQ) of the list
+        qhi = cur + MSKP_TQ < ntot ? cur + MSKP_TQ : ntot;
+        for (int j = cur; j < qhi; j++)
+            tq[(j & (MSKP_TQ - 1)) * 64] = ctl[j];
+        tq_front();
+    };
+
+    // ---- the rings: progress = row offset - org; block B = progress [8B, 8B + 8)
+    int org = 0;
+    int L = 0; // blocks readable so far (wave-uniform): progress [8 (L + MSKP_D - MSKP_NB), 8 L); MSKP_D more are in flight
+    auto fetch = [&](int r) -> cf {
+        cf v = mk(0.f, 0.f);
+        if (r >= 0) {
+            if (r < n)
+                v = myin[r];
+        } else if (r >= -(pending + 1)) {
+            v = cin[r + pending + 1];
+        }
+        return v;
+    };
+    // block B of every lane -> ring rows (4 B .. 4 B + 3) & (MSKP_ROWS - 1).  Lanes whose eight items lie
+    // inside the row take them by LDS-DMA; at the ends of the row (JOIN: the carried items in front
+    // of it, zeros behind it) they go through registers.
+    const int c_lo = JOIN ? wv * 64 : (wv * 64) / p.smax; // first channel of this wave
+    const typename Ctx::Buf inbuf = cx.make_buf(p.in + (long)(c_lo < p.nchan ? c_lo : 0) * p.in_stride,
+                                                (unsigned)(((long)(JOIN ? 63 : 63 / p.smax + 1) * p.in_stride + n) * 8));
+    const unsigned lane_off = (unsigned)((long)(cc - (c_lo < p.nchan ? c_lo : 0)) * p.in_stride * 8);
+    char* const ring_b = lds;
+    auto issue_block = [&](int B) {
+        const int r0 = org + 8 * B;
+        const bool fast = valid && r0 >= 0 && r0 + 8 <= n;
+        const int row0 = (4 * B) & (MSKP_ROWS - 1);
+        if (cx.ballot(fast) != 0ull) {
+            if (fast) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    cx.dma16(inbuf, lane_off + (unsigned)(r0 + 2 * j) * 8u, cx.lds_addr(ring_b + (row0 + j) * 1024));
+                if (row0 == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        cx.dma16(inbuf, lane_off + (unsigned)(r0 + 2 * j) * 8u, cx.lds_addr(ring_b + (MSKP_ROWS + j) * 1024));
+                }
+            }
+        }
+        if (cx.ballot(valid && !fast) != 0ull) {
+            if (valid && !fast) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const cf v = fetch(r0 + j);
+                    st8((cf*)(ring_b + (row0 + (j >> 1)) * 1024 + lane * 16 + (j & 1) * 8), v);
+                    if (row0 == 0)
+                        st8((cf*)(ring_b + (MSKP_ROWS + (j >> 1)) * 1024 + lane * 16 + (j & 1) * 8), v);
+                }
+            }
+        }
+    };
+    // a lane moves to another place of its row: what it needs arrives with the blocks issued from now on
+    // (blocks up to L + MSKP_D - 1 have been issued)
+    auto jump_to = [&](int new_a) { org = ((new_a - 1) & ~7) - 8 * (L + MSKP_D); };
+
+    // mmse_fir_interpolator_cc::interpolate(&in[iidx], mu) (:170); an imu outside [0, 128] (upstream
+    // throws std::runtime_error) reads the all-zero row
+    auto tap_row = [&](float m) -> unsigned {
+        const unsigned imu = (unsigned)(int)rintf(m * 128.0f);
+        return imu < (unsigned)MSK_ZERO_ROW ? imu : (unsigned)MSK_ZERO_ROW;
+    };
+    auto fir = [&](int pa, unsigned row) -> cf {
+        typedef float tap4 __attribute__((vector_size(16)));
+        const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
+        const tap4 tlo = tp4[0], thi = tp4[1];
+        const float tp[8] = { tlo[0], tlo[1], tlo[2], tlo[3], thi[0], thi[1], thi[2], thi[3] };
+        // five rows = ten samples from the row in[iidx] lies in; the eight wanted start at its even or odd half
+        const cf* sp = (const cf*)(ring_b + ((pa >> 1) & (MSKP_ROWS - 1)) * 1024 + lane * 16);
+        cf w[10];
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            ld16(sp + j * 128, w[2 * j], w[2 * j + 1]);
+        // (an opaque register select: written as `odd ? w[j + 1] : w[j]` the compiler turns the
+        // window into an indexed array in scratch memory)
+        const unsigned long long oddm = cx.ballot((pa & 1) != 0);
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float sre = cx.sel_f32(oddm, w[j + 1].re, w[j].re);
+            const float sim = cx.sel_f32(oddm, w[j + 1].im, w[j].im);
+            acc.re += sre * tp[7 - j];
+            acc.im += sim * tp[7 - j];
+        }
+        return acc;
+    };
+    // (int)floor(d_mu) of :200; non-finite or absurd values (upstream has thrown long before) move nothing
+    auto adv_of = [&](float f) -> int {
+        if (!(f >= -64.f && f <= 64.f)) {
+            status |= MSK_ST_INTERP_RANGE;
+            return 0;
+        }
+        return (int)f;
+    };
+
+    // ---- JOIN: the scheduler (stream contract)
+    auto seek_tags = [&]() { // get_tags_in_range(nitems_read, ...) (:125-130): from the first tag at or behind nitems_read
+        while (cur > 0 && ctl[cur - 1].rel >= base_row)
+            cur--;
+        while (cur < ntot && ctl[cur].rel < base_row)
+            cur++;
+        while (cand < K && rs[cand].jA + 1 + nc < cur)
+            cand++;
+        cand_j = cand < K ? rs[cand].jA + 1 + nc : 0x7fffffff;
+        tq_load();
+    };
+    int ototal = 0;
+    auto setup_round = [&]() {
+        const int ninput = (n - base_row) - 1; // one look-ahead item is kept out of sight
+        int noutput = 0;
+        if (ninput > 0) {
+            noutput = (int)((ninput - 3.0 * d_sps - 8) / (2.0 * d_sps)) + 2;
+            while (noutput > 0 && msk_forecast(d_sps, noutput) > ninput)
+                noutput--;
+        }
+        if (p.max_noutput > 0 && noutput > p.max_noutput)
+            noutput = p.max_noutput;
+        if (noutput > p.out_cap - ototal) {
+            noutput = p.out_cap - ototal;
+            status |= MSK_ST_OUT_FULL;
+        }
+        const int ninp = (int)(ninput - 3.0 * d_sps); // :119
+        if (ninp <= 0 || noutput <= 0) {
+            fin = true;
+            running = false;
+            return;
+        }
+        ninp_row = base_row + ninp;
+        nout_tot = ototal + noutput;
+        seek_tags();
+    };
+    auto end_call = [&]() { // this general_work() call is over (:138, :204)
+        const bool progress = a > base_row;
+        base_row = a; // consume_each(iidx)
+        ototal = cnt;
+        if (!progress) { // (a call that consumed nothing ends the step, see k_msk.h)
+            fin = true;
+            running = false;
+            return;
+        }
+        setup_round();
+    };
+
+    // ---- start
+    if (JOIN) {
+        mu = p.mu[cc];
+        om = p.omega[cc];
+        dv = p.div[cc];
+        y = p.dly2[cc];
+        nl = p.diff1[cc];
+        base_row = -pending;
+        a = base_row;
+        if (valid)
+            setup_round();
+    } else if (valid) {
+        const mskp_rst me = rs[k];
+        a = me.relA;
+        cur = me.jA;
+        relB = me.relB;
+        q0 = me.q0;
+        cap = me.cap;
+        lim_a = n - p.tail;
+        if (k + 1 < K)
+            stop_j = rs[k + 1].jA + 1;
+        tq_load();
+    }
+    org = (a - 1) & ~7;
+    for (int d = 0; d < MSKP_D; d++)
+        issue_block(d);
+
+    const int look = p.look;
+    const int cd = (int)ceilf(d_sps);
+
+    // one trip: an even and an odd iteration for every lane that is ready for them
+    auto trip = [&]() {
+        if (cx.ballot(running && needq) != 0ull) {
+            if (running && needq)
+                tq_load();
+        }
+        if (!JOIN) {
+            // behind the two warm-up iterations A and B: the state at tag B, from the tags and the samples alone
+            const bool patch = running && warm && dv == 2;
+            if (cx.ballot(patch) != 0ull) {
+                if (patch) {
+                    warm = false;
+                    if (cur == rs[k].jA + 1) {
+                        ay = y;
+                        anl = nl;
+                        a = relB;
+                        mu = 0.f;
+                        om = d_sps;
+                    } else {
+                        running = false; // (the pair did not behave as a pair: nobody will ask for this unit)
+                    }
+                }
+            }
+        }
+        {
+            // (a lane whose samples have left the ring -- an absurd tag or mu moved it backwards --
+            // has them fetched again)
+            const bool lost = running && ((a - org) - 1 < 8 * (L + MSKP_D - MSKP_NB));
+            if (cx.ballot(lost) != 0ull) {
+                if (lost)
+                    jump_to(a);
+            }
+        }
+        const int pa = a - org;
+        bool go = running && (pa + look <= 8 * L) && (pa - 1 >= 8 * (L + MSKP_D - MSKP_NB));
+        // ---- top of the first iteration (:138)
+        if (JOIN) {
+            const bool over = go && !(cnt < nout_tot && a < ninp_row);
+            if (cx.ballot(over) != 0ull) {
+                if (over)
+                    end_call();
+            }
+            go = go && !over;
+        }
+        const bool vis = !JOIN || t_rel < ninp_row; // (a tag at or behind nitems_read + ninp is not in this call's range)
+        const bool has = hasq && vis;
+        // a time_est tag lands in [iidx, iidx + d_sps) (:140-142)
+        bool fire = go && has && (t_rel >= a) && ((float)(t_rel - base_row) < (float)(a - base_row) + d_sps);
+        if (JOIN) {
+            const bool stopj = fire && cur == cand_j;
+            if (cx.ballot(stopj) != 0ull) {
+                if (stopj) {
+                    atj = true;
+                    running = false;
+                }
+            }
+            go = go && !stopj;
+            fire = fire && !stopj;
+        } else {
+            // the unit ends: at the next restart point, or where speculation has to stop (a stale tag
+            // blocks every later one, :142; a tag value the table cannot take; the end of the row)
+            const bool s1 = fire && !warm && cur == stop_j;
+            const bool s2 = go && !warm && !s1 &&
+                            ((has && t_rel < a) || (fire && !mskp_tame(t_val)) || a >= lim_a || cnt >= cap - 1);
+            if (cx.ballot(s1 || s2) != 0ull) {
+                if (s1 || s2) {
+                    kind = s1 ? MSKP_KIND_NEXT : MSKP_KIND_HANDOFF;
+                    running = false;
+                }
+            }
+            go = go && !(s1 || s2);
+            fire = fire && !(s1 || s2);
+        }
+        const bool nan1 = t_val != t_val;
+        const bool f1 = fire && !nan1;
+        const bool runE = go && (((dv & 1) == 0) || f1);
+        if (f1) { // :148-156
+            mu = t_val;
+            a = t_rel;
+            if (mu < 0) {
+                mu++;
+                a--;
+            }
+            dv = 0;
+            om = d_sps;
+        }
+        if (cx.ballot(fire) != 0ull) {
+            if (fire) { // tags.erase(tags.begin()) (:145, :162)
+                cur++;
+                tq_front();
+            }
+        }
+        // ---- even iteration (:166-201 with d_div even)
+        {
+            const unsigned row = tap_row(mu);
+            const cf yi = fir(a - org, row);
+            if (runE) {
+                worst_row = worst_row > row ? worst_row : row;
+                const cf sq = cmul_exact(yi, yi);                                // :171
+                const cf nlin = cmul_exact(sq, cconj(cmul_exact(y, y)));         // :173-174
+                if (JOIN) {
+                    st8(p.syms + (long)cc * p.out_stride + cnt, yi);             // :187
+                    cnt++;
+                } else if (!warm) {
+                    st8(p.stage + (long)cc * p.stage_stride + q0 + cnt, yi);
+                    cnt++;
+                }
+                dv++;
+                y = yi; // :194-196
+                nl = nlin;
+                mu += om; // :199-201
+                const float fl = floorf(mu);
+                a += adv_of(fl);
+                mu = mu - fl;
+            }
+        }
+        // ---- top of the second iteration (a lane whose next tag is not staged yet waits for the next trip)
+        bool go2 = go && ((dv & 1) != 0) && !needq;
+        {
+            const int pa2 = a - org;
+            go2 = go2 && (pa2 + 9 <= 8 * L) && (pa2 >= 8 * (L + MSKP_D - MSKP_NB));
+        }
+        if (JOIN)
+            go2 = go2 && !(runE && !(cnt < nout_tot && a < ninp_row)); // (the call ends here: next trip)
+        {
+            const bool vis2 = !JOIN || t_rel < ninp_row;
+            const bool fire2 = go2 && runE && hasq && vis2 && (t_rel >= a) &&
+                               ((float)(t_rel - base_row) < (float)(a - base_row) + d_sps);
+            const bool nan2 = t_val != t_val;
+            if (cx.ballot(fire2 && nan2) != 0ull) {
+                if (fire2 && nan2) { // :144-147: dropped, the iteration runs as it is
+                    cur++;
+                    tq_front();
+                }
+            }
+            if (!JOIN && warm && fire2 && !nan2)
+                running = false; // (tag B fires one iteration early: not a restart point)
+            go2 = go2 && !(fire2 && !nan2); // a reset: that iteration is an even one, next trip
+        }
+        // ---- odd iteration (:166-201 with d_div odd: the loop filter, :179-184)
+        {
+            const unsigned row = tap_row(mu);
+            const cf yi = fir(a - org, row);
+            if (go2) {
+                worst_row = worst_row > row ? worst_row : row;
+                const cf sq = cmul_exact(yi, yi);
+                const cf nlin = cmul_exact(sq, cconj(cmul_exact(y, y)));
+                float err = (nlin - nl).re;                                      // :178
+                err = branchless_clip(err, 3.0f);
+                om += p.gain_omega * err;
+                om = d_sps + branchless_clip(om - d_sps, p.limit);
+                mu += p.gain * err;
+                dv++;
+                y = yi;
+                nl = nlin;
+                mu += om;
+                const float fl = floorf(mu);
+                a += adv_of(fl);
+                mu = mu - fl;
+            }
+        }
+    };
+
+    // ---- JOIN: a lane stands where restart point `cand`'s tag B is about to fire
+    auto walk = [&]() {
+        if (!atj)
+            return;
+        atj = false;
+        bool moved = false;
+        for (;;) {
+            const mskp_res r = rr[cand];
+            const bool same = r.kind != MSKP_KIND_NONE && mskp_same_bits(r.ay, y) && mskp_same_bits(r.anl, nl);
+            // The unit ran blind to the general_work calls.  Its run is the serial loop's if no tag it
+            // used lies outside the call's range (:125-130, the same limit in every call of a step) and
+            //  * without max_noutput_items: every iteration top in it passes :138 in the call in progress;
+            //  * with max_noutput_items = Q: every call that starts inside it is offered Q outputs
+            //    (forecast(Q) fits what is left of the row).  Such a call ends at the top behind its
+            //    Q-th symbol and the next one starts there: the loop state is untouched, the tags are
+            //    fetched again from nitems_read on -- the front tag is still the front tag (a tag that
+            //    reset the loop lies behind iidx one iteration later when d_sps >= 2; a stale tag would
+            //    be dropped, but a unit stops at a stale tag).
+            bool clean = same && (r.end.a + 1 + cd <= ninp_row) && np < MSKP_SMAX;
+            if (p.max_noutput > 0)
+                clean = clean && msk_forecast(d_sps, p.max_noutput) <= (n - r.end.a) - 1 &&
+                        (cnt + r.end.cnt + p.max_noutput <= p.out_cap);
+            else
+                clean = clean && (cnt + r.end.cnt < nout_tot);
+            if (!clean) {
+                cand++;
+                cand_j = cand < K ? rs[cand].jA + 1 + nc : 0x7fffffff;
+                break; // through the junction, serially
+            }
+            moved = true;
+            mskp_piece pc;
+            pc.out0 = cnt;
+            pc.src0 = rs[cand].q0;
+            pc.cnt = r.end.cnt;
+            p.pieces[(long)cc * MSKP_SMAX + np] = pc;
+            np++;
+            cnt += r.end.cnt;
+            while (cnt >= nout_tot) { // (calls that began and ended inside the unit; only with max_noutput_items)
+                ototal = nout_tot;
+                nout_tot += p.max_noutput;
+                base_row = r.end.a; // (somewhere at or before: nothing reads it before the next call starts)
+            }
+            a = r.end.a;
+            mu = r.end.mu;
+            om = r.end.omega;
+            dv = r.end.div;
+            y = r.end.y;
+            nl = r.end.nl;
+            cur = r.end.cur + nc;
+            status |= r.status;
+            cand++;
+            cand_j = cand < K ? rs[cand].jA + 1 + nc : 0x7fffffff;
+            if (r.kind == MSKP_KIND_NEXT && cand < K)
+                continue; // that unit ended where the next one's tag B is about to fire
+            break;
+        }
+        running = true;
+        if (moved) {
+            jump_to(a);
+            tq_load();
+        }
+    };
+
+    // ---- the recurrence
+    bool all_done = false;
+    int since_walk = 0;
+#ifdef MSKP_PROF
+    long long pf_t0 = __builtin_readcyclecounter(), pf_wait = 0, pf_issue = 0, pf_trip = 0, pf_walk = 0;
+    long pf_epochs = 0, pf_trips = 0, pf_lanes = 0;
+#define PFB long long pf_a = __builtin_readcyclecounter();
+#define PFE(acc) acc += __builtin_readcyclecounter() - pf_a;
+#else
+#define PFB
+#define PFE(acc)
+#endif
+    while (!all_done) {
+        // block L has arrived when at most the MSKP_D - 1 younger blocks (four transfers each; whatever
+        // else is in flight is younger still) are outstanding; then the next one goes out, into the
+        // rows of block L + MSKP_D - MSKP_NB, which every lane has left
+        { PFB
+        cx.template wait_vm<4 * (MSKP_D - 1)>();
+        PFE(pf_wait) }
+        L++;
+        { PFB
+        issue_block(L + MSKP_D - 1);
+        PFE(pf_issue) }
+#ifdef MSKP_PROF
+        pf_epochs++;
+#endif
+        for (;;) {
+            // lanes waiting at a junction are served when nobody runs any more, or every
+            // MSKP_WALK_EVERY trips (the walk reads records from memory: the whole wave waits)
+            const bool idle = cx.ballot(running) == 0ull;
+            if (JOIN && (idle || since_walk >= MSKP_WALK_EVERY)) {
+                since_walk = 0;
+                PFB
+                if (cx.ballot(atj) != 0ull)
+                    walk();
+                PFE(pf_walk)
+            }
+            if (idle && cx.ballot(running) == 0ull) {
+                all_done = true;
+                break;
+            }
+            since_walk++;
+            if (cx.ballot(running && ((a - org) - 1 < 8 * (L + MSKP_D - MSKP_NB + 1))) == 0ull)
+                break;
+            { PFB
+            trip();
+            PFE(pf_trip) }
+#ifdef MSKP_PROF
+            pf_trips++;
+            pf_lanes += aisx_popc64(cx.ballot(running));
+#endif
+        }
+    }
+#ifdef MSKP_PROF
+    if (wv == 0 && lane == 0)
+        printf("mskp prof %s: cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld\n",
+               JOIN ? "join" : "units", (long long)(__builtin_readcyclecounter() - pf_t0), pf_wait, pf_issue, pf_trip, pf_walk,
+               pf_epochs, pf_trips, pf_lanes);
+#endif
+    cx.template wait_vm<0>();
+
+    if (!valid)
+        return;
+    if (worst_row >= (unsigned)MSK_ZERO_ROW)
+        status |= MSK_ST_INTERP_RANGE;
+    if (!JOIN) {
+        mskp_res r;
+        r.end.a = a;
+        r.end.mu = mu;
+        r.end.omega = om;
+        r.end.div = dv;
+        r.end.y = y;
+        r.end.nl = nl;
+        r.end.cur = cur;
+        r.end.cnt = cnt;
+        r.ay = ay;
+        r.anl = anl;
+        r.kind = kind;
+        r.status = status;
+        rr[k] = r;
+        return;
+    }
+    // ---- JOIN: the state and the carry of the next call, as k_msk.h leaves them
+    p.mu[c] = mu;
+    p.omega[c] = om;
+    p.div[c] = dv;
+    p.dly1[c] = y;
+    p.dly2[c] = y;
+    p.diff1[c] = nl;
+    const int base = base_row + pending; // items consumed
+    p.nread[c] = R + (u64)base;
+    p.produced[c] = ototal;
+    p.consumed[c] = base;
+    p.npieces[c] = np;
+    cf* cout = p.carry_out + (long)c * p.carry_cap;
+    int left = n - base_row; // pending items for the next call
+    const int ccap = p.carry_cap < MSK_CARRY_MAX ? p.carry_cap : MSK_CARRY_MAX;
+    if (left + 1 > ccap) {
+        status |= MSK_ST_CARRY_OVERFLOW;
+        left = ccap - 1;
+    }
+    for (int j = 0; j <= left; j++)
+        cout[j] = fetch(base_row - 1 + j);
+    p.carry_len_out[c] = left;
+    // tags the scheduler still holds: offset >= nitems_read
+    {
+        int j = cur;
+        while (j > 0 && ctl[j - 1].rel >= base_row)
+            j--;
+        while (j < ntot && ctl[j].rel < base_row)
+            j++;
+        tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
+        int w = 0;
+        for (; j < ntot; j++) {
+            const msk_ctag e = ctl[j];
+            if (w < p.ctag_cap) {
+                tag_rec tg;
+                tg.offset = p.W + (u64)(long long)e.rel;
+                tg.value = (double)e.val;
+                tg.key = KEY_TIME_EST;
+                tg.chan = c;
+                cto[w] = tg;
+            } else {
+                status |= MSK_ST_TAGCARRY_OVERFLOW;
+            }
+            w++;
+        }
+        p.ctag_n_out[c] = w < p.ctag_cap ? w : p.ctag_cap;
+    }
+    p.status[c] = status;
+}
+
+// symbols of the accepted units: staging row -> output row.  Workgroup (x, channel) copies its
+// share of every piece.
+template <class Ctx>
+AISX_DI void mskp_gather_body(Ctx& cx, const MskpGatherParams& p)
+{
+    const int c = cx.by();
+    const int np = p.npieces[c];
+    const mskp_piece* pc = p.pieces + (long)c * MSKP_SMAX;
+    const cf* src = p.stage + (long)c * p.stage_stride;
+    cf* dst = p.syms + (long)c * p.out_stride;
+    for (int i = cx.bx(); i < np; i += MSKP_GATHER_X) {
+        const mskp_piece e = pc[i];
+        for (int j = cx.tid(); j < e.cnt; j += cx.nthreads())
+            dst[e.out0 + j] = src[e.src0 + j];
+    }
+}
+
+} // namespace aisx

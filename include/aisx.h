@@ -185,7 +185,20 @@ enum {
     AISX_MSK_ST_OUT_FULL = 8,
     AISX_MSK_ST_TAGS_TRUNCATED = 16
 };
+/* gr::block::set_max_noutput_items(): under the stream contract every general_work call is offered
+ * at most that many output items (0, the default: as many as the pending input allows).  With
+ * GNU Radio's default buffers the scheduler never offers msk_timing_recovery_cc more than ~2000-4000;
+ * a stale time_est tag blocks the later ones until the call ends (reference :140-142), so the value
+ * bounds how long.  Takes effect with the next aisx_msk_process_stream. */
+int aisx_msk_set_max_noutput_items(aisx_msk* h, int max_noutput_items);
+int aisx_msk_get_max_noutput_items(const aisx_msk* h);
 int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
+/* Diagnostics of the time-parallel recovery (k_mskp.h) for the last aisx_msk_process_stream call,
+ * summed over the channels: out6 = { restart points chosen, units whose run was taken over,
+ * symbols that came from units, units that ended at the next restart point, units that ended
+ * elsewhere (stale tag, end of the row), calls that took the time-parallel path }.  Waits for
+ * `stream`. */
+int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream);
 /* The NRZI bit tail (quadrature demod .. invert, python/ais_demod.py:48-52) has no part in
  * the timing recurrence.  With a tail stream set (enable != 0) aisx_msk_process_stream
  * launches it there, ordered after the call's recovery kernel, so that the next call need

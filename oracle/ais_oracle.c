@@ -793,6 +793,27 @@ void orc_msk_get_state(const orc_msk *h, float *s, int *div)
     *div = h->d_div;
 }
 
+/* Diagnostic for tools/msk_tag_stats.py (not part of the restatement): while a buffer is set,
+ * every general_work call appends 4-int records -- {1, stream offset of a tag that reset the loop,
+ * iterations since the previous reset, iidx before the reset - tag offset} and, at the end of the
+ * call, {2, tags in range, tags used, iterations}.  Single-threaded use only. */
+static int *g_msk_trace = NULL;
+static int g_msk_trace_cap = 0, g_msk_trace_n = 0;
+void orc_msk_set_trace(int *buf, int cap_records)
+{
+    g_msk_trace = buf;
+    g_msk_trace_cap = cap_records;
+    g_msk_trace_n = 0;
+}
+int orc_msk_trace_count(void) { return g_msk_trace_n; }
+static void msk_trace(int a, int b, int c, int d)
+{
+    if (g_msk_trace && g_msk_trace_n < g_msk_trace_cap) {
+        int *r = g_msk_trace + 4 * g_msk_trace_n++;
+        r[0] = a, r[1] = b, r[2] = c, r[3] = d;
+    }
+}
+
 /* general_work :107-206 */
 int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const orc_cf *in, orc_cf *out,
                          float *out2, float *out3, const orc_tag *alltags, int nalltags, uint64_t nitems_read,
@@ -816,7 +837,9 @@ int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const 
 
     orc_cf sq, dly_conj, nlin_out, in_interp;
     float err_out = 0;
+    int iters = 0, last_reset = 0;
     while (oidx < noutput_items && iidx < ninp) { /* :138 */
+        iters++;
         if (tpos < nt) {                            /* tags.size() > 0 */
             int offset = (int)(alltags[tq[tpos]].offset - nitems_read);
             if ((offset >= iidx) && (offset < (iidx + h->d_sps))) { /* :142 */
@@ -824,6 +847,10 @@ int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const 
                 if (center != center) { /* NaN :144-147 */
                     tpos++;
                     goto out;
+                }
+                if (g_msk_trace) {
+                    msk_trace(1, (int)(alltags[tq[tpos]].offset), iters - last_reset, iidx - offset);
+                    last_reset = iters;
                 }
                 h->d_mu = center;
                 iidx = offset;
@@ -869,6 +896,8 @@ int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const 
         iidx += (int)floor(h->d_mu);
         h->d_mu = (float)(h->d_mu - floor(h->d_mu));
     }
+    if (g_msk_trace)
+        msk_trace(2, nt, tpos, iters);
     orc_big_free(tq);
     *consumed = iidx; /* consume_each(iidx) */
     return oidx;
@@ -989,6 +1018,8 @@ struct orc_demod {
     orc_msk *msk;
     orc_cf *msk_buf; /* [0] = item before nitems_read, then pending items */
     int msk_pending, msk_cap;
+    int msk_max_noutput; /* noutput_items the scheduler offers the timing recovery at most (0: whatever fits);
+                          * gr::block::set_max_noutput_items() */
     uint64_t msk_read;
     orc_tag *store;
     int nstore, cap_store;
@@ -1037,6 +1068,8 @@ void orc_demod_destroy(orc_demod *h)
     free(h->store);
     free(h);
 }
+
+void orc_demod_set_max_noutput(orc_demod *h, int max_noutput_items) { h->msk_max_noutput = max_noutput_items; }
 
 int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, int max_bits, orc_cf *syms_out,
                    orc_tag *tags_out, int max_tags, int *ntags_out)
@@ -1112,7 +1145,13 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
     }
     memcpy(h->msk_buf + 1 + h->msk_pending, y3, sizeof(orc_cf) * n1);
     h->msk_pending += n1;
-    /* the scheduler calls general_work again and again until forecast(1) no longer fits */
+    /* the scheduler calls general_work again and again until forecast(1) no longer fits.
+     * (The consumed items are dropped from the front of msk_buf once, behind the loop: with a
+     * max_noutput_items there are many calls per step.) */
+    /* items past the ones on offer read as zero (the reference may look a few items past
+     * ninput_items when sps < 4) */
+    memset(h->msk_buf + 1 + h->msk_pending, 0, sizeof(orc_cf) * 8);
+    int off = 0; /* items of msk_buf consumed by the calls of this step */
     for (;;) {
         int ninput = h->msk_pending - 1; /* keep one look-ahead item out of sight */
         int nout = 0;
@@ -1121,28 +1160,31 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
             while (nout > 0 && orc_msk_forecast(h->msk, nout) > ninput)
                 nout--;
         }
+        if (h->msk_max_noutput > 0 && nout > h->msk_max_noutput)
+            nout = h->msk_max_noutput;
         if (nout > max_bits - nbits)
             nout = max_bits - nbits;
         if (nout <= 0 || (int)(ninput - 3.0 * orc_msk_get_sps(h->msk)) <= 0)
             break;
         orc_cf *syms = (orc_cf *)orc_big_alloc(sizeof(orc_cf) * (size_t)nout);
         int consumed = 0, status = 0;
-        /* items past the ones on offer read as zero (the reference may look a few
-         * items past ninput_items when sps < 4) */
-        memset(h->msk_buf + 1 + h->msk_pending, 0, sizeof(orc_cf) * 8);
-        int prod = orc_msk_general_work(h->msk, nout, ninput, h->msk_buf + 1, syms, NULL, NULL, h->store, h->nstore,
+        int prod = orc_msk_general_work(h->msk, nout, ninput, h->msk_buf + off + 1, syms, NULL, NULL, h->store, h->nstore,
                                         h->msk_read, &consumed, &status);
         if (consumed > 0) {
-            memmove(h->msk_buf, h->msk_buf + consumed, sizeof(orc_cf) * (size_t)(h->msk_pending - consumed + 1));
+            off += consumed;
             h->msk_pending -= consumed;
             h->msk_read += (uint64_t)consumed;
         }
-        /* prune tags the scheduler would have dropped (offset < nitems_read) */
-        int w = 0;
-        for (int k = 0; k < h->nstore; k++)
-            if (h->store[k].offset >= h->msk_read)
-                h->store[w++] = h->store[k];
-        h->nstore = w;
+        /* prune tags the scheduler would have dropped (offset < nitems_read); the store is sorted by offset */
+        {
+            int d = 0;
+            while (d < h->nstore && h->store[d].offset < h->msk_read)
+                d++;
+            if (d > 0) {
+                memmove(h->store, h->store + d, sizeof(orc_tag) * (size_t)(h->nstore - d));
+                h->nstore -= d;
+            }
+        }
         /* 5. bit tail */
         orc_bittail_process(&h->tail, syms, prod, bits + nbits);
         if (syms_out)
@@ -1156,6 +1198,8 @@ int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, i
         if (consumed <= 0)
             break;
     }
+    if (off > 0)
+        memmove(h->msk_buf, h->msk_buf + off, sizeof(orc_cf) * (size_t)(h->msk_pending + 1));
     orc_big_free(newtags);
     orc_big_free(cbuf);
     orc_big_free(y3);

@@ -100,6 +100,9 @@ int orc_msk_general_work(orc_msk *h, int noutput_items, int ninput_items, const 
                          float *out_err /* or NULL */, float *out_mu /* or NULL */, const orc_tag *tags,
                          int ntags, uint64_t nitems_read, int *consumed, int *status);
 void orc_msk_get_state(const orc_msk *h, float *state8, int *div);
+/* diagnostic (tools/msk_tag_stats.py): trace of tag resets, see ais_oracle.c */
+void orc_msk_set_trace(int *buf, int cap_records);
+int orc_msk_trace_count(void);
 
 /* ---- NRZI bit tail (python/ais_demod.py:48-52 + lib/invert_impl.cc) ---- */
 typedef struct { orc_cf prev_sym; unsigned char prev_bit; } orc_bittail;
@@ -118,6 +121,9 @@ orc_demod *orc_demod_create(float sps, float bits_per_sec, float gain, float lim
                             int nsym, int stages);
 void orc_demod_destroy(orc_demod *h);
 /* one chain step of n new input samples; returns number of bits produced */
+/* gr::block::set_max_noutput_items() of the timing-recovery block: every general_work call is
+ * offered at most that many output items (0: as many as the pending input allows) */
+void orc_demod_set_max_noutput(orc_demod *h, int max_noutput_items);
 int orc_demod_step(orc_demod *h, const orc_cf *in, int n, unsigned char *bits, int max_bits, orc_cf *syms_or_null,
                    orc_tag *tags_out, int max_tags, int *ntags);
 

@@ -16,6 +16,7 @@
 #include "../../gr-ais_amd/csrc/aisx_tables.h"
 #include "../../gr-ais_amd/csrc/k_corr.h"
 #include "../../gr-ais_amd/csrc/k_msk.h"
+#include "../../gr-ais_amd/csrc/k_mskp.h"
 #ifdef MSK_EMU_STATS
 namespace aisx { long msk_stats[8]; }
 #endif
@@ -92,6 +93,7 @@ struct EmuCtx {
         const float c = CNEG ? -K[KSEL][CS] : K[KSEL][CS], s = SNEG ? -K[KSEL][SS] : K[KSEL][SS];
         return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
     }
+    float sel_f32(unsigned long long m, float if_set, float if_clear) const { return ((m >> (tid_ & 63)) & 1ull) ? if_set : if_clear; }
     void pin(float&) const {}
     void pin(int&) const {}
     void pin_mask(unsigned long long&) const {}
@@ -161,6 +163,8 @@ struct EmuCtx {
         }
     }
     void wait_dma() const {}
+    template <int N>
+    void wait_vm() const {}
     void lds_barrier() const { sync(); }
     void buf_store64(const Buf& b, unsigned voff, unsigned soff, cf v) const
     {
@@ -376,6 +380,10 @@ struct EmuMsk {
     std::vector<int> ct_n;
     int ct_cap = 0;
     int cur = 0;
+    // time-parallel path (k_mskp.h): restart points per channel at most (-1: the serial kernel)
+    int tp_smax = -1, tp_min_gap = 256, max_noutput = 0;
+    unsigned long long total_in = 0;
+    long tp_stat[4] = { 0, 0, 0, 0 }; // restart points, units accepted, symbols taken from units, symbols in all
 };
 
 void* emu_msk_create(float sps, float gain, float limit, int osps, int nchan)
@@ -398,6 +406,74 @@ void* emu_msk_create(float sps, float gain, float limit, int osps, int nchan)
 }
 void emu_msk_destroy(void* hv) { delete (EmuMsk*)hv; }
 void emu_msk_set_lpw(void* hv, int lpw) { ((EmuMsk*)hv)->lpw = lpw; }
+void emu_msk_set_time_parallel(void* hv, int smax, int min_gap, int max_noutput)
+{
+    EmuMsk* h = (EmuMsk*)hv;
+    h->tp_smax = smax;
+    h->tp_min_gap = min_gap;
+    h->max_noutput = max_noutput;
+}
+void emu_msk_tp_stats(void* hv, long* out)
+{
+    for (int i = 0; i < 4; i++)
+        out[i] = ((EmuMsk*)hv)->tp_stat[i];
+}
+
+// the time-parallel kernels on the lane model: prepass, units, join, gather
+static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const tag_rec* tags, const int* tag_counts,
+                         int tag_cap, cf* syms, long out_stride, int* produced)
+{
+    const int nc = h->nchan;
+    const bool ok = mskp_geometry_ok(h->d_sps, h->gain, h->limit, n + MSK_CARRY_MAX);
+    const int smax = (ok && !(h->max_noutput > 0 && h->d_sps < 2.0f)) ? std::min(h->tp_smax, MSKP_SMAX) : 0;
+    const int ctl_cap = MSKP_TPRE + (tags ? tag_cap : 0) + 1;
+    std::vector<msk_ctag> ctl((size_t)nc * ctl_cap, msk_ctag{ 0, 0.f });
+    std::vector<int> ctl_n(nc, 0), nrst(nc, 0), npieces(nc, 0);
+    std::vector<mskp_rst> rst((size_t)nc * MSKP_SMAX);
+    std::vector<mskp_res> res((size_t)nc * MSKP_SMAX);
+    memset(res.data(), 0, res.size() * sizeof(mskp_res));
+    std::vector<mskp_piece> pieces((size_t)nc * MSKP_SMAX);
+    const long stage_stride = mskp_stage_stride(n, h->d_sps, h->gain, h->limit);
+    std::vector<cf> stage((size_t)nc * stage_stride, mk(0, 0));
+    MskpPrepParams pp;
+    pp.nchan = nc; pp.tags = tags; pp.tag_count = tag_counts; pp.tag_cap = tag_cap; pp.W = h->total_in; pp.n = n;
+    pp.d_sps = h->d_sps; pp.gain = h->gain; pp.limit = h->limit;
+    pp.ctl = ctl.data(); pp.ctl_n = ctl_n.data(); pp.ctl_cap = ctl_cap;
+    pp.smax = smax; pp.nrst = nrst.data(); pp.rst = rst.data(); pp.stage_stride = stage_stride;
+    pp.tail = mskp_tail(h->d_sps); pp.min_gap = h->tp_min_gap;
+    run_grid(nc, 1, 64, MSKP_PREP_LDS_TAGS * 8, [&](EmuCtx& cx) { mskp_prep_body(cx, pp); });
+    MskpParams p;
+    p.nchan = nc; p.d_sps = h->d_sps; p.gain = h->gain; p.gain_omega = h->gain_omega; p.limit = h->limit;
+    p.mu = h->mu.data(); p.omega = h->omega.data(); p.div = h->div.data();
+    p.dly1 = h->dly1.data(); p.dly2 = h->dly2.data(); p.diff1 = h->diff1.data(); p.nread = h->nread.data();
+    p.in = in; p.in_stride = in_stride; p.n = n;
+    p.carry_in = h->carry[h->cur].data(); p.carry_out = h->carry[h->cur ^ 1].data();
+    p.carry_len_in = h->carry_len[h->cur].data(); p.carry_len_out = h->carry_len[h->cur ^ 1].data(); p.carry_cap = EmuMsk::carry_cap;
+    p.ctag_in = h->ctag[h->cur].data(); p.ctag_n_in = h->ctag_n[h->cur].data();
+    p.ctag_out = h->ctag[h->cur ^ 1].data(); p.ctag_n_out = h->ctag_n[h->cur ^ 1].data(); p.ctag_cap = EmuMsk::ctag_cap;
+    p.ctl = ctl.data(); p.ctl_n = ctl_n.data(); p.ctl_cap = ctl_cap;
+    p.smax = std::max(smax, 1); p.nrst = nrst.data(); p.rst = rst.data(); p.res = res.data();
+    p.stage = stage.data(); p.stage_stride = stage_stride;
+    p.syms = syms; p.out_stride = out_stride; p.out_cap = (int)out_stride;
+    p.pieces = pieces.data(); p.npieces = npieces.data();
+    p.produced = produced; p.consumed = h->consumed.data(); p.status = h->status.data();
+    p.mmse = &aisx_mmse_taps[0][0];
+    p.W = h->total_in; p.look = mskp_look(h->d_sps, h->limit); p.tail = pp.tail; p.max_noutput = h->max_noutput;
+    if (smax > 0)
+        run_grid((nc * smax + 63) / 64, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, false>(cx, p); });
+    run_grid((nc + 63) / 64, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
+    MskpGatherParams g;
+    g.nchan = nc; g.pieces = pieces.data(); g.npieces = npieces.data(); g.stage = stage.data(); g.stage_stride = stage_stride;
+    g.syms = syms; g.out_stride = out_stride;
+    run_grid(MSKP_GATHER_X, nc, 64, 64, [&](EmuCtx& cx) { mskp_gather_body(cx, g); });
+    for (int c = 0; c < nc; c++) {
+        h->tp_stat[0] += nrst[c];
+        h->tp_stat[1] += npieces[c];
+        for (int i = 0; i < npieces[c]; i++)
+            h->tp_stat[2] += pieces[(size_t)c * MSKP_SMAX + i].cnt;
+        h->tp_stat[3] += produced[c];
+    }
+}
 
 static void emu_msk_fill(EmuMsk* h, MskParams& p)
 {
@@ -419,6 +495,7 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.tq_stride = 64;
     p.tq_private = 1;
     p.inline_tags = getenv("AISX_MSK_INLINE_TAGS") ? atoi(getenv("AISX_MSK_INLINE_TAGS")) : 1;
+    p.max_noutput = h->max_noutput;
     p.lds_tab_off = p.lds_ring_off + msk_waves(h->lpw) * p.lds_wave_stride;
 }
 
@@ -454,18 +531,23 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
                            int* produced, int* consumed_out)
 {
     EmuMsk* h = (EmuMsk*)hv;
-    emu_msk_tagprep(h, tags, tag_counts, tag_cap);
-    MskParams p;
-    emu_msk_fill(h, p);
-    p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
     if (!syms) {
         h->symscratch.resize((size_t)h->nchan * out_stride);
         syms = h->symscratch.data();
     }
-    p.syms = syms; p.err = err; p.mu_out = mu; p.out_stride = out_stride; p.out_cap = (int)out_stride;
-    p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
-    p.produced = produced;
-    emu_msk(&p);
+    if (h->tp_smax >= 0 && h->osps == 1 && !err && !mu) {
+        emu_mskp_run(h, in, in_stride, n, tags, tag_counts, tag_cap, syms, out_stride, produced);
+    } else {
+        emu_msk_tagprep(h, tags, tag_counts, tag_cap);
+        MskParams p;
+        emu_msk_fill(h, p);
+        p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
+        p.syms = syms; p.err = err; p.mu_out = mu; p.out_stride = out_stride; p.out_cap = (int)out_stride;
+        p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
+        p.produced = produced;
+        emu_msk(&p);
+    }
+    h->total_in += (unsigned long long)n;
     h->cur ^= 1;
     if (bits)
         emu_msk_bittail(h, syms, out_stride, produced, bits, out_stride, (int)out_stride);

@@ -40,6 +40,8 @@ def lib():
         L.emu_msk_create.argtypes = [f32, f32, f32, i32, i32]
         L.emu_msk_destroy.argtypes = [vp]
         L.emu_msk_set_lpw.argtypes = [vp, i32]
+        L.emu_msk_set_time_parallel.argtypes = [vp, i32, i32, i32]
+        L.emu_msk_tp_stats.argtypes = [vp, vp]
         L.emu_msk_process_stream.restype = i32
         L.emu_msk_process_stream.argtypes = [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp]
         L.emu_msk_general_work.restype = i32
@@ -102,10 +104,17 @@ class CorrEst:
 
 
 class MskStream:
-    def __init__(self, sps, gain, limit, osps=1, nchan=1, lpw=64):
+    def __init__(self, sps, gain, limit, osps=1, nchan=1, lpw=64, tp_smax=-1, tp_min_gap=256, max_noutput=0):
         self.h = lib().emu_msk_create(sps, gain, limit, osps, nchan)
         self.nchan = nchan
         lib().emu_msk_set_lpw(self.h, lpw)  # channels per wave: 16, 32 or 64
+        # tp_smax >= 0: the time-parallel kernels (k_mskp.h) with that many restart points per channel at most
+        lib().emu_msk_set_time_parallel(self.h, tp_smax, tp_min_gap, max_noutput)
+
+    def tp_stats(self):
+        a = np.zeros(4, np.int64)
+        lib().emu_msk_tp_stats(self.h, _p(a))
+        return dict(restart_points=int(a[0]), units_accepted=int(a[1]), symbols_from_units=int(a[2]), symbols=int(a[3]))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -92,6 +92,7 @@ def lib():
         L.orc_demod_destroy.argtypes = [vp]
         L.orc_demod_step.restype = i32
         L.orc_demod_step.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, pi32]
+        L.orc_demod_set_max_noutput.argtypes = [vp, i32]
         L.orc_demod_bench_mt.restype = C.c_long
         L.orc_demod_bench_mt.argtypes = [i32, f32, vp, i32, i32, vp, i32, i32, f64, C.POINTER(C.c_double)]
         L.orc_demod_hash.restype = u64
@@ -292,8 +293,9 @@ class MskStream:
     aisx chain: all pending input minus one look-ahead item is offered, and
     noutput_items is the largest count whose forecast() fits."""
 
-    def __init__(self, sps, gain, limit, osps=1):
+    def __init__(self, sps, gain, limit, osps=1, max_noutput=0):
         self.m = Msk(sps, gain, limit, osps)
+        self.max_noutput = max_noutput  # gr::block::set_max_noutput_items() (0: whatever fits)
         self.buf = np.zeros(1, dtype=np.complex64)  # [0] = item before nitems_read
         self.read = 0
         self.store = np.zeros(0, dtype=TAG_DTYPE)
@@ -314,6 +316,8 @@ class MskStream:
                 nout = int((ninput - 3.0 * dsps - 8) / (2.0 * dsps)) + 2
                 while nout > 0 and self.m.forecast(nout) > ninput:
                     nout -= 1
+            if self.max_noutput > 0:
+                nout = min(nout, self.max_noutput)
             if nout <= 0 or int(ninput - 3.0 * dsps) <= 0:
                 break
             # items past the ones on offer read as zero (the reference may look a few items
@@ -352,9 +356,11 @@ class BitTail(C.Structure):
 class Demod:
     """python/ais_demod.py chain for one channel (orc_demod_*)."""
 
-    def __init__(self, sps, symbols, gain=0.04, limit=0.01, fftlen=1024, bits_per_sec=9600.0, stages=3):
+    def __init__(self, sps, symbols, gain=0.04, limit=0.01, fftlen=1024, bits_per_sec=9600.0, stages=3, max_noutput=0):
         s = _c64(symbols)
         self.h = lib().orc_demod_create(sps, bits_per_sec, gain, limit, fftlen, _ptr(s), s.size, stages)
+        if max_noutput:
+            lib().orc_demod_set_max_noutput(self.h, max_noutput)
 
     def __del__(self):
         if getattr(self, "h", None):
