@@ -276,10 +276,11 @@ class msk_timing_recovery_cc:
 
     def restart_stats(self, stream=None):
         """What the time-parallel recovery made of the last call (sums over the channels)."""
-        a = (C.c_longlong * 6)()
+        a = (C.c_longlong * 10)()
         check(_lib.lib().aisx_msk_restart_stats(self._h, a, _stream_ptr(stream)), "restart_stats")
         return dict(restart_points=a[0], units_taken=a[1], symbols_from_units=a[2], units_ended_at_next=a[3],
-                    units_ended_elsewhere=a[4], calls=a[5])
+                    units_ended_elsewhere=a[4], calls=a[5], links_equal=a[6], links=a[7], longest_unit_items=a[8],
+                    unit_items=a[9])
 
     def general_work_host(self, noutput_items, ninput_items, buf, in_off, tags, nitems_read, in_has_lookahead=True):
         """GNU Radio path: in = &buf[in_off]; tags: structured array (TAG_DTYPE)."""

@@ -110,6 +110,17 @@ struct DevCtx {
     __device__ __forceinline__ unsigned lane_next_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
+    // two complex items to byte offset `off` (< 4 GiB) of `base`: one 16-byte store
+    __device__ __forceinline__ void store16(cf* base, unsigned off, cf a, cf b) const
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v;
+        v.x = a.re;
+        v.y = a.im;
+        v.z = b.re;
+        v.w = b.im;
+        *(f4*)((char*)base + off) = v;
+    }
     // lane-wise select by a wave mask, as one v_cndmask_b32 the optimiser cannot look into
     __device__ __forceinline__ float sel_f32(unsigned long long m, float if_set, float if_clear) const
     {
@@ -137,6 +148,7 @@ struct DevCtx {
     __device__ __forceinline__ int readlane_i32(int v, int lane) const { return __builtin_amdgcn_readlane(v, lane); }
     __device__ __forceinline__ int ctz64(unsigned long long v) const { return __ffsll((long long)v) - 1; }
     __device__ __forceinline__ void atomic_or64(unsigned long long* p, unsigned long long v) const { atomicOr(p, v); }
+    __device__ __forceinline__ int atomic_add_i32(int* p, int v) const { return atomicAdd(p, v); }
 
     // ---- raw buffers and LDS-DMA (k_corr4d.h) ------------------------------------------------
     // A raw buffer: wave-uniform base + byte count; an access whose byte offset (the VGPR part)
@@ -173,11 +185,33 @@ struct DevCtx {
         w.z = (int)b.nbytes;
         w.w = 0x00020000;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+#ifdef AISX_DMA_NOSAVE
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(byte_off), "s"(w), "s"(dst) : "memory", "m0");
+#else
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(byte_off), "s"(w), "s"(dst)
                      : "memory");
+#endif
+    }
+    // four such transfers into four consecutive KiB of LDS with ONE setting of M0 (experiment)
+    __device__ __forceinline__ void dma16x4(const Buf& b, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) const
+    {
+        v4i w;
+        w.x = (int)(unsigned)(size_t)b.base;
+        w.y = (int)(unsigned)(((size_t)b.base >> 32) & 0xffffu);
+        w.z = (int)b.nbytes;
+        w.w = 0x00020000;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %4, 0 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %2, %4, 0 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %3, %4, 0 offen offset:3072 lds"
+                     :
+                     : "v"(o0), "v"(o1 - 1024u), "v"(o2 - 2048u), "v"(o3 - 3072u), "s"(w), "s"(dst)
+                     : "memory", "m0");
     }
     // all of this wave's vector-memory operations (DMA included) have completed
     __device__ __forceinline__ void wait_dma() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

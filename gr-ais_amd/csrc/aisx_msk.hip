@@ -152,8 +152,9 @@ struct aisx_msk {
     int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
     float *d_mmse = nullptr, *d_atan = nullptr;
     // time-parallel path (k_mskp.h)
-    int tp_smax = 16;      // restart points per channel at most (0: the serial kernel)
-    int tp_min_gap = 0;    // items between restart points at least (0: max_items / tp_smax)
+    int tp_smax = MSKP_SMAX; // restart points per channel at most (0: the serial kernel)
+    int tp_min_gap = 64;   // items between restart points at least
+    int tp_jw = 16;        // channels per wave of the join kernel
     int max_noutput = 0;   // set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)
     unsigned long long total_in = 0; // items handed to the block so far = absolute offset of the next row's item 0
     msk_ctag* d_ctl = nullptr;
@@ -164,6 +165,8 @@ struct aisx_msk {
     mskp_res* d_res = nullptr;
     cf* d_stage[2] = { nullptr, nullptr };
     long stage_stride = 0;
+    int* d_ucount = nullptr; // units per length class
+    int* d_ulist = nullptr;  // ... and which
     mskp_piece* d_pieces[2] = { nullptr, nullptr };
     int* d_npieces[2] = { nullptr, nullptr };
     long tp_calls = 0;
@@ -275,6 +278,10 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
             h->tp_smax = std::max(0, std::min(atoi(e), (int)MSKP_SMAX));
         if (const char* e = getenv("AISX_MSK_TP_GAP"))
             h->tp_min_gap = std::max(0, atoi(e));
+        if (const char* e = getenv("AISX_MSK_JW"))
+            h->tp_jw = std::max(1, std::min(64, atoi(e)));
+        if (const char* e = getenv("AISX_MSK_MAX_NOUTPUT")) // (experiments; the API is aisx_msk_set_max_noutput_items)
+            h->max_noutput = std::max(0, atoi(e));
         if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
@@ -363,6 +370,8 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     dev_free(h->d_nrst);
     dev_free(h->d_rst);
     dev_free(h->d_res);
+    dev_free(h->d_ucount);
+    dev_free(h->d_ulist);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_stage[k]);
         dev_free(h->d_pieces[k]);
@@ -585,7 +594,8 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
         const size_t nc = (size_t)h->nchan;
         h->stage_stride = mskp_stage_stride(h->max_items + aisx_msk::carry_cap, h->d_sps, h->gain, h->limit);
         if ((rc = dev_alloc(&h->d_ctl_n, nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, nc)) != AISX_OK ||
-            (rc = dev_alloc(&h->d_rst, nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, nc * MSKP_SMAX)) != AISX_OK)
+            (rc = dev_alloc(&h->d_rst, nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, nc * MSKP_SMAX)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_ucount, 8)) != AISX_OK || (rc = dev_alloc(&h->d_ulist, nc * MSKP_SMAX * MSKP_NCLS)) != AISX_OK)
             return rc;
         for (int k = 0; k < 2; k++)
             if ((rc = dev_alloc(&h->d_stage[k], nc * (size_t)h->stage_stride)) != AISX_OK ||
@@ -618,6 +628,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     hipStream_t st = (hipStream_t)stream;
     const bool tp = msk_tp_applies(h, d_err, d_mu);
     int rc, t_smax = 0;
+    bool tp_sorted = false;
     if (tp) {
         if ((rc = msk_tp_buffers(h, d_tags ? tag_cap : 0, st)) != AISX_OK)
             return rc;
@@ -642,7 +653,15 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         t.rst = h->d_rst;
         t.stage_stride = h->stage_stride;
         t.tail = mskp_tail(h->d_sps);
-        t.min_gap = h->tp_min_gap > 0 ? h->tp_min_gap : std::max(64, n / std::max(1, h->tp_smax));
+        t.min_gap = h->tp_min_gap;
+        // units sorted by length need every row within 4 GiB of the first (32-bit buffer offsets)
+        const bool sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !getenv("AISX_MSK_TP_UNSORTED");
+        t.ucount = sorted ? h->d_ucount : nullptr;
+        t.ulist = h->d_ulist;
+        t.ucap = (long)h->nchan * MSKP_SMAX;
+        if (sorted)
+            AISX_HIPCHK(hipMemsetAsync(h->d_ucount, 0, sizeof(int) * 8, st));
+        tp_sorted = sorted;
         hipLaunchKernelGGL(k_mskp_prep, dim3(h->nchan), dim3(64), 0, st, t);
         AISX_HIPCHK(hipGetLastError());
     } else if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st)) != AISX_OK) {
@@ -720,6 +739,11 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         p.mmse = h->d_mmse;
         p.W = h->total_in;
         p.look = mskp_look(h->d_sps, h->limit);
+        p.padv = mskp_padv(h->d_sps, h->gain, h->limit);
+        p.jw = h->tp_jw;
+        p.ucount = tp_sorted ? h->d_ucount : nullptr;
+        p.ulist = h->d_ulist;
+        p.ucap = (long)h->nchan * MSKP_SMAX;
         p.tail = mskp_tail(h->d_sps);
         p.max_noutput = h->max_noutput;
         static bool attr_set = false;
@@ -730,10 +754,10 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         }
         if (t_smax > 0) {
             const long units = (long)h->nchan * h->tp_smax;
-            hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64)), dim3(64), MSKP_LDS_BYTES, st, p);
+            hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64 + (tp_sorted ? MSKP_NCLS : 0))), dim3(64), MSKP_LDS_BYTES, st, p);
             AISX_HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + 63) / 64), dim3(64), MSKP_LDS_BYTES, st, p);
+        hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + h->tp_jw - 1) / h->tp_jw), dim3(64), MSKP_LDS_BYTES, st, p);
         AISX_HIPCHK(hipGetLastError());
         h->tp_calls++;
     } else {
@@ -856,7 +880,7 @@ extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream
 {
     if (!h || !out6)
         return AISX_ERR_INVALID;
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 10; i++)
         out6[i] = 0;
     out6[5] = h->tp_calls;
     if (!h->d_rst || h->tp_calls == 0)
@@ -866,11 +890,13 @@ extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream
     std::vector<int> nrst(nc), np(nc);
     std::vector<mskp_piece> pc(nc * MSKP_SMAX);
     std::vector<mskp_res> rs(nc * MSKP_SMAX);
+    std::vector<mskp_rst> rp(nc * MSKP_SMAX);
     AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     AISX_HIPCHK(hipMemcpy(nrst.data(), h->d_nrst, sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(np.data(), h->d_npieces[par], sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(pc.data(), h->d_pieces[par], sizeof(mskp_piece) * pc.size(), hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(rs.data(), h->d_res, sizeof(mskp_res) * rs.size(), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(rp.data(), h->d_rst, sizeof(mskp_rst) * rp.size(), hipMemcpyDeviceToHost));
     for (size_t c = 0; c < nc; c++) {
         out6[0] += nrst[c];                     // restart points chosen
         out6[1] += np[c];                       // units whose run was taken over
@@ -879,6 +905,15 @@ extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream
         for (int i = 0; i < nrst[c]; i++) {
             out6[3] += rs[c * MSKP_SMAX + i].kind == MSKP_KIND_NEXT;    // units that ended at the next restart point
             out6[4] += rs[c * MSKP_SMAX + i].kind == MSKP_KIND_HANDOFF; // ... somewhere else (stale tag, end of the row)
+            const long long span = rs[c * MSKP_SMAX + i].end.a - rp[c * MSKP_SMAX + i].relA;
+            out6[8] = std::max(out6[8], span); // longest unit, items
+            out6[9] += span;
+            // links: a unit that ended at the next restart point with exactly the delay registers that one assumed
+            if (i + 1 < nrst[c] && rs[c * MSKP_SMAX + i].kind == MSKP_KIND_NEXT) {
+                const mskp_res &a = rs[c * MSKP_SMAX + i], &b = rs[c * MSKP_SMAX + i + 1];
+                out6[6] += mskp_same_bits(a.end.y, b.ay) && mskp_same_bits(a.end.nl, b.anl);
+                out6[7] += 1;
+            }
         }
     }
     return AISX_OK;

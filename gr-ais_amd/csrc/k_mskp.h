@@ -45,24 +45,38 @@
 namespace aisx {
 
 #ifndef MSKP_R
-#define MSKP_R 64                        // ring slots per lane (power of two)
+#define MSKP_R 128                       // ring slots per lane (power of two)
+#endif
+#ifndef MSKP_BS
+#define MSKP_BS 16                       // samples of a lane per block (a multiple of 8)
 #endif
 #ifndef MSKP_D
 #define MSKP_D 3                         // blocks in flight (LDS-DMA) ahead of the last one readable
 #endif
-constexpr int MSKP_NB = MSKP_R / 8;      // blocks of eight samples in the ring
+constexpr int MSKP_NB = MSKP_R / MSKP_BS; // blocks in the ring
 constexpr int MSKP_ROWS = MSKP_R / 2;    // ring rows: row r = two consecutive samples of every lane, [row][lane] 16 bytes each
 constexpr int MSKP_SLOTS = MSKP_R + 8;   // + 4 mirror rows: five rows from any row never wrap
-static_assert(MSKP_NB - MSKP_D >= 4, "readable window of the rings");
+static_assert(MSKP_BS % 8 == 0 && (MSKP_NB - MSKP_D) * MSKP_BS >= 24, "readable window of the rings");
 constexpr int MSKP_TQ = 8;               // time_est tags staged in LDS per lane
 constexpr int MSKP_TPRE = 64;            // room in front of a channel's new-tag list for the carried tags
-constexpr int MSKP_SMAX = 32;            // restart points per channel at most
+constexpr int MSKP_SMAX = 64;            // restart points per channel at most
 constexpr int MSKP_PREP_LDS_TAGS = 2048; // tags of a channel the restart search looks at
 constexpr int MSKP_GATHER_X = 4;         // workgroups per channel of the gather kernel
+constexpr int MSKP_NCLS = 7;             // units are handed to the waves by length class: < 256 items, < 512, ... >= 8192
 constexpr int MSKP_WALK_EVERY = 32;      // trips a lane waits at a junction at most while others still run
-constexpr int MSKP_LDS_RING = MSKP_SLOTS * 64 * 8;
+// The rings: four groups of 16 lanes; a group's ring is MSKP_ROWS + 4 rows of 256 bytes, row r = the
+// sample pair (2 r, 2 r + 1) of each of its 16 lanes, 16 bytes per lane.  A block of eight samples of
+// a group = four rows = 1 KiB, which ONE LDS-DMA instruction fills: lane 16 q + u brings pair q of lane
+// u's stream (the four lanes of a stream read 64 contiguous bytes: 16 cache lines per instruction,
+// not 64).  The four rows behind the ring mirror its first four: five rows from any row never wrap.
+// A lane's 16-byte reads hit bank group (lane & 7) wherever its row is: no conflicts.
+constexpr int MSKP_GRP_B = (MSKP_ROWS + 4) * 256;
+constexpr int MSKP_LDS_RING = 4 * MSKP_GRP_B;
+static_assert(MSKP_LDS_RING == MSKP_SLOTS * 64 * 8, "ring bytes");
 constexpr int MSKP_LDS_TQ = MSKP_TQ * 64 * 8;
-constexpr int MSKP_LDS_BYTES = MSKP_LDS_RING + MSKP_LDS_TQ + MSK_LDS_MMSE;
+// units kernel: 16 symbols per lane staged for 64-byte stores, [group][slot pair][lane of the group] 16 bytes
+constexpr int MSKP_LDS_SYM = 16 * 64 * 8;
+constexpr int MSKP_LDS_BYTES = MSKP_LDS_RING + MSKP_LDS_TQ + MSK_LDS_MMSE + MSKP_LDS_SYM;
 
 enum { MSKP_KIND_NONE = 0, MSKP_KIND_NEXT = 1, MSKP_KIND_HANDOFF = 2 };
 
@@ -116,6 +130,10 @@ struct MskpParams {
     const float* mmse;          // [129][8]
     unsigned long long W;       // absolute offset of row item 0 (items handed to the block before this call)
     int look;                   // samples a trip may read beyond in[iidx]
+    int padv;                   // items a pair of iterations moves iidx at most
+    int jw;                     // channels per wave of the join kernel (1..64: fewer lanes, fewer events per trip)
+    // units by length class (null: lane u of wave w takes unit (w * 64 + u) % smax of channel (w * 64 + u) / smax)
+    const int* ucount; const int* ulist; long ucap;
     int tail;                   // units stop this many items before the end of the row
     int max_noutput;            // set_max_noutput_items(): output items a general_work call is offered at most (0: what fits)
 };
@@ -131,6 +149,7 @@ struct MskpPrepParams {
     long stage_stride;
     int tail;
     int min_gap;    // restart points at least this many items apart
+    int* ucount; int* ulist; long ucap; // units by length class (may be null)
 };
 
 struct MskpGatherParams {
@@ -153,6 +172,7 @@ AISX_HD bool mskp_geometry_ok(float d_sps, float gain, float limit, int max_item
     return coord_ok && lock_ok && m > 1.0f && d_sps <= 12.f && max_items <= (1 << 18) - 1024;
 }
 AISX_HD int mskp_look(float d_sps, float limit) { return (int)ceilf(d_sps) + (int)floorf(1.f + d_sps + fabsf(limit)) + 8; }
+AISX_HD int mskp_padv(float d_sps, float gain, float limit) { return (int)ceilf(2.f * (d_sps + fabsf(limit)) + 3.f * fabsf(gain)) + 1; }
 AISX_HD int mskp_tail(float d_sps) { return 64 + (int)ceilf(3.f * d_sps) + (int)ceilf(d_sps); }
 // staging slots per channel (the prepass drops restart points that would not fit)
 AISX_HD long mskp_stage_stride(int max_items, float d_sps, float gain, float limit)
@@ -285,7 +305,7 @@ AISX_DI void mskp_prep_body(Ctx& cx, const MskpPrepParams& p)
         for (int k = 0; k < K; k++) {
             const int end = k + 1 < K ? rs[k + 1].relB : lim;
             const int jend = k + 1 < K ? rs[k + 1].jA + 1 : nn;
-            const int cap = (int)((float)(end - rs[k].relB + 16) / m) + 2 * (jend - rs[k].jA) + 16;
+            const int cap = ((int)((float)(end - rs[k].relB + 16) / m) + 2 * (jend - rs[k].jA) + 16 + 7) & ~7; // (64-byte stores)
             if (q + cap > p.stage_stride)
                 break;
             rs[k].q0 = (int)q;
@@ -296,6 +316,17 @@ AISX_DI void mskp_prep_body(Ctx& cx, const MskpPrepParams& p)
         K = Kfit;
     }
     p.nrst[c] = K;
+    if (p.ucount) {
+        // a wave of the units kernel lives as long as its longest unit: units of a kind go together
+        for (int k = 0; k < K; k++) {
+            const int span = (k + 1 < K ? rs[k + 1].relB : lim) - rs[k].relB;
+            int cls = 0;
+            while (cls < MSKP_NCLS - 1 && span >= (256 << cls))
+                cls++;
+            const int idx = cx.atomic_add_i32(p.ucount + cls, 1);
+            p.ulist[(long)cls * p.ucap + idx] = (c << 6) | k;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,9 +339,9 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     const int lane = cx.tid() & 63;
     const int wv = cx.bx() * (cx.nthreads() >> 6) + (cx.tid() >> 6);
     char* const lds = cx.lds() + (cx.tid() >> 6) * MSKP_LDS_BYTES; // (one wave per workgroup in the product)
-    cf* const ring = (cf*)lds + lane;                                      // slot s: ring[s * 64]
     msk_ctag* const tq = (msk_ctag*)(lds + MSKP_LDS_RING) + lane;          // entry e: tq[e * 64]
     float* const mm = (float*)(lds + MSKP_LDS_RING + MSKP_LDS_TQ);         // [130][MSK_TAPS_PITCH]
+    char* const sbuf = lds + MSKP_LDS_RING + MSKP_LDS_TQ + MSK_LDS_MMSE;   // units: the symbol stage
     for (int i = lane; i < 129 * 8; i += 64)
         mm[(i >> 3) * MSK_TAPS_PITCH + (i & 7)] = p.mmse[i];
     if (lane < MSK_TAPS_PITCH)
@@ -320,7 +351,24 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     // ---- which unit this lane is
     int c, k = 0;
     if (JOIN) {
-        c = wv * 64 + lane;
+        c = lane < p.jw ? wv * p.jw + lane : p.nchan;
+    } else if (p.ucount) {
+        // classes of long units first: wave wv is one of the ceil(count / 64) waves of its class
+        int wb = 0;
+        c = p.nchan;
+        for (int cls = MSKP_NCLS - 1; cls >= 0; cls--) {
+            const int cn = p.ucount[cls];
+            const int nw = (cn + 63) >> 6;
+            if (wv >= wb && wv < wb + nw) {
+                const int idx = (wv - wb) * 64 + lane;
+                if (idx < cn) {
+                    const int id = p.ulist[(long)cls * p.ucap + idx];
+                    c = id >> 6;
+                    k = id & 63;
+                }
+            }
+            wb += nw;
+        }
     } else {
         const int u = wv * 64 + lane;
         c = u / p.smax;
@@ -421,6 +469,10 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     };
 
     // ---- the rings: progress = row offset - org; block B = progress [8B, 8B + 8)
+#ifdef MSKP_PROF
+    long long pf_dma = 0;
+    long pf_ndma = 0;
+#endif
     int org = 0;
     int L = 0; // blocks readable so far (wave-uniform): progress [8 (L + MSKP_D - MSKP_NB), 8 L); MSKP_D more are in flight
     auto fetch = [&](int r) -> cf {
@@ -433,45 +485,103 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         }
         return v;
     };
-    // block B of every lane -> ring rows (4 B .. 4 B + 3) & (MSKP_ROWS - 1).  Lanes whose eight items lie
-    // inside the row take them by LDS-DMA; at the ends of the row (JOIN: the carried items in front
-    // of it, zeros behind it) they go through registers.
-    const int c_lo = JOIN ? wv * 64 : (wv * 64) / p.smax; // first channel of this wave
-    const typename Ctx::Buf inbuf = cx.make_buf(p.in + (long)(c_lo < p.nchan ? c_lo : 0) * p.in_stride,
-                                                (unsigned)(((long)(JOIN ? 63 : 63 / p.smax + 1) * p.in_stride + n) * 8));
+    // block B of every lane -> rows (4 B .. 4 B + 3) & (MSKP_ROWS - 1) of its group's ring.  Lanes whose
+    // eight items lie inside the row get them by LDS-DMA (from the four lanes that serve their stream);
+    // at the ends of the row (JOIN: the carried items in front of it, zeros behind it) a lane fetches
+    // its own through registers.
+    // (units by class: the lanes of a wave come from anywhere; the host has made sure that all rows lie within 4 GiB)
+    const bool anyrow = !JOIN && p.ucount != nullptr;
+    const int c_lo = anyrow ? 0 : (JOIN ? wv * p.jw : (wv * 64) / p.smax); // first channel of this wave
+    const long rows = anyrow ? p.nchan - 1 : (JOIN ? p.jw - 1 : 63 / p.smax + 1);
+    const typename Ctx::Buf inbuf = cx.make_buf(p.in + (long)(c_lo < p.nchan ? c_lo : 0) * p.in_stride, (unsigned)((rows * p.in_stride + n) * 8));
     const unsigned lane_off = (unsigned)((long)(cc - (c_lo < p.nchan ? c_lo : 0)) * p.in_stride * 8);
     char* const ring_b = lds;
+    char* const my_ring = ring_b + (lane >> 4) * MSKP_GRP_B + (lane & 15) * 16; // row r of this lane: my_ring + r * 256
+    // what this lane knows of the four streams it serves (lane 16 j + (lane & 15), j = 0..3)
+    int s_org[4];
+    unsigned s_base[4];
+    bool s_valid[4];
+    bool org_dirty = true;
+    auto refresh_streams = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int src = 16 * j + (lane & 15);
+            s_org[j] = cx.shfl_i32(org, src);
+            s_base[j] = (unsigned)cx.shfl_i32((int)(lane_off + (unsigned)org * 8u), src);
+            s_valid[j] = cx.shfl_i32(valid ? 1 : 0, src) != 0;
+        }
+        org_dirty = false;
+    };
     auto issue_block = [&](int B) {
-        const int r0 = org + 8 * B;
-        const bool fast = valid && r0 >= 0 && r0 + 8 <= n;
-        const int row0 = (4 * B) & (MSKP_ROWS - 1);
-        if (cx.ballot(fast) != 0ull) {
-            if (fast) {
+        if (cx.ballot(org_dirty) != 0ull)
+            refresh_streams();
+        const int q = lane >> 4;
+        // (a lane that has stopped needs nothing more: a finished unit or channel would otherwise be
+        // served past the end of its row, item by item through the slow path, for as long as the wave lives)
+        const u64 runm = cx.ballot(running);
+#pragma unroll
+        for (int h = 0; h < MSKP_BS / 8; h++) { // eight samples of every lane at a time
+            const int p0 = MSKP_BS * B + 8 * h; // progress of the first of them
+            const int row0 = (p0 >> 1) & (MSKP_ROWS - 1);
+#ifdef MSKP_EXP_M0ONCE
+            { // (timing experiment: wrong placement)
+                unsigned o[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    cx.dma16(inbuf, lane_off + (unsigned)(r0 + 2 * j) * 8u, cx.lds_addr(ring_b + (row0 + j) * 1024));
-                if (row0 == 0) {
+                    o[j] = s_base[j] + (unsigned)(p0 + 2 * q) * 8u;
+                cx.dma16x4(inbuf, o[0], o[1], o[2], o[3], cx.lds_addr(ring_b + row0 * 256));
+            }
+#else
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        cx.dma16(inbuf, lane_off + (unsigned)(r0 + 2 * j) * 8u, cx.lds_addr(ring_b + (MSKP_ROWS + j) * 1024));
+            for (int j = 0; j < 4; j++) {
+                const int r0 = s_org[j] + p0;
+                const bool fast = s_valid[j] && ((runm >> (16 * j + (lane & 15))) & 1ull) != 0ull && r0 >= 0 && r0 + 8 <= n;
+                if (!JOIN) {
+                    // (units lie inside their rows; what a stopped or absent lane's stream would bring is
+                    // replaced by an offset the buffer rejects: zeros, read by nobody -- no test, no branch)
+                    const unsigned off = fast ? s_base[j] + (unsigned)(p0 + 2 * q) * 8u : 0xfffffff0u;
+                    cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + row0 * 256));
+                    if (row0 == 0)
+                        cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + MSKP_ROWS * 256));
+                } else if (cx.ballot(fast) != 0ull) {
+#ifdef MSKP_PROF
+                    const long long d0 = __builtin_readcyclecounter();
+#endif
+                    if (fast) {
+                        const unsigned off = s_base[j] + (unsigned)(p0 + 2 * q) * 8u;
+#ifndef MSKP_NODMA
+                        cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + row0 * 256));
+#endif
+                        if (row0 == 0)
+                            cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + MSKP_ROWS * 256));
+                    }
+#ifdef MSKP_PROF
+                    pf_dma += __builtin_readcyclecounter() - d0;
+                    pf_ndma++;
+#endif
                 }
             }
-        }
-        if (cx.ballot(valid && !fast) != 0ull) {
-            if (valid && !fast) {
+#endif
+            const int r0 = org + p0;
+            const bool slow = JOIN && valid && running && !(r0 >= 0 && r0 + 8 <= n);
+            if (JOIN && cx.ballot(slow) != 0ull) {
+                if (slow) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const cf v = fetch(r0 + j);
-                    st8((cf*)(ring_b + (row0 + (j >> 1)) * 1024 + lane * 16 + (j & 1) * 8), v);
-                    if (row0 == 0)
-                        st8((cf*)(ring_b + (MSKP_ROWS + (j >> 1)) * 1024 + lane * 16 + (j & 1) * 8), v);
+                    for (int j = 0; j < 8; j++) {
+                        const cf v = fetch(r0 + j);
+                        st8((cf*)(my_ring + (row0 + (j >> 1)) * 256 + (j & 1) * 8), v);
+                        if (row0 == 0)
+                            st8((cf*)(my_ring + (MSKP_ROWS + (j >> 1)) * 256 + (j & 1) * 8), v);
+                    }
                 }
             }
         }
     };
-    // a lane moves to another place of its row: what it needs arrives with the blocks issued from now on
     // (blocks up to L + MSKP_D - 1 have been issued)
-    auto jump_to = [&](int new_a) { org = ((new_a - 1) & ~7) - 8 * (L + MSKP_D); };
+    auto jump_to = [&](int new_a) {
+        org = ((new_a - 1) & ~7) - MSKP_BS * (L + MSKP_D);
+        org_dirty = true;
+    };
 
     // mmse_fir_interpolator_cc::interpolate(&in[iidx], mu) (:170); an imu outside [0, 128] (upstream
     // throws std::runtime_error) reads the all-zero row
@@ -484,22 +594,16 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         const tap4* tp4 = (const tap4*)((const char*)mm + row * (unsigned)(MSK_TAPS_PITCH * 4));
         const tap4 tlo = tp4[0], thi = tp4[1];
         const float tp[8] = { tlo[0], tlo[1], tlo[2], tlo[3], thi[0], thi[1], thi[2], thi[3] };
-        // five rows = ten samples from the row in[iidx] lies in; the eight wanted start at its even or odd half
-        const cf* sp = (const cf*)(ring_b + ((pa >> 1) & (MSKP_ROWS - 1)) * 1024 + lane * 16);
-        cf w[10];
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-            ld16(sp + j * 128, w[2 * j], w[2 * j + 1]);
-        // (an opaque register select: written as `odd ? w[j + 1] : w[j]` the compiler turns the
-        // window into an indexed array in scratch memory)
-        const unsigned long long oddm = cx.ballot((pa & 1) != 0);
+        // in[iidx + 2 m] sits m rows behind in[iidx], in[iidx + 2 m + 1] m rows behind in[iidx + 1]: two
+        // base addresses, eight 8-byte reads at constant offsets (the mirror rows make the fifth row safe)
+        const char* a0 = my_ring + ((pa >> 1) & (MSKP_ROWS - 1)) * 256 + (pa & 1) * 8;
+        const char* a1 = a0 + ((pa & 1) ? 248 : 8);
         cf acc = mk(0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float sre = cx.sel_f32(oddm, w[j + 1].re, w[j].re);
-            const float sim = cx.sel_f32(oddm, w[j + 1].im, w[j].im);
-            acc.re += sre * tp[7 - j];
-            acc.im += sim * tp[7 - j];
+            const cf sv = ld8((const cf*)(((j & 1) ? a1 : a0) + (j >> 1) * 256));
+            acc.re += sv.re * tp[7 - j];
+            acc.im += sv.im * tp[7 - j];
         }
         return acc;
     };
@@ -617,14 +721,14 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         {
             // (a lane whose samples have left the ring -- an absurd tag or mu moved it backwards --
             // has them fetched again)
-            const bool lost = running && ((a - org) - 1 < 8 * (L + MSKP_D - MSKP_NB));
+            const bool lost = running && ((a - org) - 1 < MSKP_BS * (L + MSKP_D - MSKP_NB));
             if (cx.ballot(lost) != 0ull) {
                 if (lost)
                     jump_to(a);
             }
         }
         const int pa = a - org;
-        bool go = running && (pa + look <= 8 * L) && (pa - 1 >= 8 * (L + MSKP_D - MSKP_NB));
+        bool go = running && (pa + look <= MSKP_BS * L) && (pa - 1 >= MSKP_BS * (L + MSKP_D - MSKP_NB));
         // ---- top of the first iteration (:138)
         if (JOIN) {
             const bool over = go && !(cnt < nout_tot && a < ninp_row);
@@ -694,7 +798,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                     st8(p.syms + (long)cc * p.out_stride + cnt, yi);             // :187
                     cnt++;
                 } else if (!warm) {
-                    st8(p.stage + (long)cc * p.stage_stride + q0 + cnt, yi);
+                    st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yi);
                     cnt++;
                 }
                 dv++;
@@ -710,7 +814,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         bool go2 = go && ((dv & 1) != 0) && !needq;
         {
             const int pa2 = a - org;
-            go2 = go2 && (pa2 + 9 <= 8 * L) && (pa2 >= 8 * (L + MSKP_D - MSKP_NB));
+            go2 = go2 && (pa2 + 9 <= MSKP_BS * L) && (pa2 >= MSKP_BS * (L + MSKP_D - MSKP_NB));
         }
         if (JOIN)
             go2 = go2 && !(runE && !(cnt < nout_tot && a < ninp_row)); // (the call ends here: next trip)
@@ -751,6 +855,187 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 mu = mu - fl;
             }
         }
+    };
+
+    // The same trip when nothing unusual is due in any running lane: every lane at an even iteration
+    // with its samples in the ring, no call or unit about to end, no junction, no stale / NaN / absurd
+    // tag, the tag behind the front one staged.  A tag reset is taken in line (:140-164), both
+    // interpolations are fetched together (where the odd iteration reads follows from the even one's
+    // state, :199-201 -- it has no feedback into mu, :179), no branch inside.  Returns false, having
+    // done nothing, when some lane needs trip().
+    auto fast_trip = [&]() -> bool {
+        const int pa = a - org;
+        const bool ready = (pa + look <= MSKP_BS * L) && (pa - 1 >= MSKP_BS * (L + MSKP_D - MSKP_NB));
+        const bool vis = !JOIN || t_rel < ninp_row;
+        const bool has = hasq && vis;
+        const bool fire = has && (t_rel >= a) && ((float)(t_rel - base_row) < (float)(a - base_row) + d_sps);
+        bool rare = !ready || ((dv & 1) != 0) || needq || (fire && (!mskp_tame(t_val) || (cur + 1 >= qhi && cur + 1 < ntot)));
+        if (JOIN)
+            rare = rare || !(cnt + 1 < nout_tot && a + look < ninp_row) || (fire && cur == cand_j);
+        else
+            rare = rare || warm || a >= lim_a || cnt >= cap - 1 || (has && t_rel < a) || (fire && cur == stop_j);
+        if (cx.ballot(running && rare) != 0ull)
+            return false;
+        if (running) {
+            if (fire) { // :148-162
+                mu = t_val;
+                a = t_rel;
+                if (mu < 0) {
+                    mu++;
+                    a--;
+                }
+                dv = 0;
+                om = d_sps;
+                cur++;
+                tq_front();
+            }
+            // where the odd iteration reads (:199-201 behind the even one)
+            const float m1 = mu + om;
+            const float fl1 = floorf(m1);
+            const int aO = a + adv_of(fl1);
+            const float muO = m1 - fl1;
+            // a tag that fires there makes that iteration an even one (:154): it is left for the next trip
+            const bool skipO = hasq && (!JOIN || t_rel < ninp_row) && (t_rel >= aO) &&
+                               ((float)(t_rel - base_row) < (float)(aO - base_row) + d_sps);
+            const unsigned rowE = tap_row(mu), rowO = tap_row(muO);
+            const cf yE = fir(a - org, rowE);
+            const cf yO = fir(aO - org, rowO);
+            worst_row = worst_row > rowE ? worst_row : rowE;
+            const cf sqE = cmul_exact(yE, yE);                               // :171
+            const cf nlE = cmul_exact(sqE, cconj(cmul_exact(y, y)));         // :173-174
+            if (JOIN)
+                st8(p.syms + (long)cc * p.out_stride + cnt, yE);             // :187
+            else
+                st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE);
+            cnt++;
+            if (!skipO) {
+                worst_row = worst_row > rowO ? worst_row : rowO;
+                const cf sqO = cmul_exact(yO, yO);
+                const cf nlO = cmul_exact(sqO, cconj(sqE));
+                float err = (nlO - nlE).re;                                  // :178
+                err = branchless_clip(err, 3.0f);                            // :179-184
+                om += p.gain_omega * err;
+                om = d_sps + branchless_clip(om - d_sps, p.limit);
+                float m2 = muO + p.gain * err;
+                dv += 2;
+                y = yO; // :194-196
+                nl = nlO;
+                m2 += om; // :199-201
+                const float fl2 = floorf(m2);
+                a = aO + adv_of(fl2);
+                mu = m2 - fl2;
+            } else {
+                dv += 1;
+                y = yE;
+                nl = nlE;
+                a = aO;
+                mu = muO;
+            }
+        }
+        return true;
+    };
+
+    int flushed = 0; // units: symbols of this lane already written to its staging row
+    // NP pairs of iterations with nothing in the way for any running lane (fast_run_pairs() has made
+    // sure): no tag can fire, no call or unit can end, the samples are in the ring, mu and omega are
+    // in their normal ranges.  No test inside; only the real part of nlin_out is formed on the way
+    // (:174, :178), the imaginary part of the last one -- state, d_dly_diff_1 -- at the end.
+    auto run_pairs = [&](const int NP) {
+        if (running) {
+            cf ysq = cmul_exact(y, y);
+            cf sqE = ysq, sqO = ysq, yO = y;
+            float nlr = nl.re;
+            for (int it = 0; it < NP; it++) {
+                const float m1 = mu + om;                                    // :199-201 behind the even iteration
+                const float fl1 = floorf(m1);
+                const int aO = a + (int)fl1;
+                const float muO = m1 - fl1;
+                const cf yE = fir(a - org, (unsigned)(int)rintf(mu * 128.0f));
+                yO = fir(aO - org, (unsigned)(int)rintf(muO * 128.0f));
+                sqE = cmul_exact(yE, yE);                                    // :171
+                const float nlEr = sqE.re * ysq.re + sqE.im * ysq.im;        // :173-174, real part
+                if (JOIN)
+                    st8(p.syms + (long)cc * p.out_stride + cnt, yE);         // :187
+                else
+                    st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE);
+                cnt++;
+                sqO = cmul_exact(yO, yO);
+                nlr = sqO.re * sqE.re + sqO.im * sqE.im;
+                const float err = branchless_clip(nlr - nlEr, 3.0f);         // :178-184
+                om += p.gain_omega * err;
+                om = d_sps + branchless_clip(om - d_sps, p.limit);
+                float m2 = muO + p.gain * err;
+                m2 += om;
+                const float fl2 = floorf(m2);
+                a = aO + (int)fl2;
+                mu = m2 - fl2;
+                ysq = sqO;
+            }
+            dv += 2 * NP;
+            y = yO;
+            nl = mk(nlr, sqO.im * sqE.re - sqO.re * sqE.im); // :174 of the last odd iteration
+        }
+    };
+    // how many such pairs every running lane is good for: 8, 4, 2 or none
+    auto fast_run_pairs = [&]() -> int {
+        const int pa = a - org;
+        const bool vis = !JOIN || t_rel < ninp_row;
+        const bool has = hasq && vis;
+        // items this lane may move before anything has to be looked at
+        int room = MSKP_BS * L - look - pa;                                  // the ring
+        if (has) {
+            const int r = (t_rel - cd - 1) - a;                        // the front tag's window (:142)
+            room = room < r ? room : r;
+        }
+        int prs = 0x3fffffff;                                          // pairs by count
+        if (JOIN) {
+            const int r = ninp_row - look - a;
+            room = room < r ? room : r;
+            prs = nout_tot - 1 - cnt;
+        } else {
+            const int r = lim_a - 1 - a;
+            room = room < r ? room : r;
+            prs = cap - 2 - cnt;
+            const int st = 16 - (cnt - flushed);
+            prs = prs < st ? prs : st;
+        }
+        const bool plain = ((dv & 1) == 0) && !needq && !(!JOIN && warm) && (pa - 1 >= MSKP_BS * (L + MSKP_D - MSKP_NB)) &&
+                           (mu >= 0.f && mu <= 1.f) && (om >= 0.5f && om <= 30.f);
+        int can = 0;
+        if (plain && room >= 0) {
+            can = room / p.padv;
+            can = can < prs ? can : prs;
+        }
+        if (cx.ballot(running && can < 2) != 0ull)
+            return 0;
+        if (cx.ballot(running && can < 4) != 0ull)
+            return 2;
+        return cx.ballot(running && can < 8) != 0ull ? 4 : 8;
+    };
+
+    // ---- units: symbols leave the stage eight at a time, 64 contiguous bytes per lane, written by the
+    // four lanes that serve it (16 cache lines per store instruction instead of 64)
+    const unsigned stage_off = (unsigned)(((long)cc * p.stage_stride + q0) * 8);
+    auto flush_syms = [&]() {
+        const bool full = valid && (cnt - flushed >= 8);
+        const u64 fm = cx.ballot(full);
+        if (fm == 0ull)
+            return;
+        const int qq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int src = 16 * j + (lane & 15);
+            const int tf = cx.shfl_i32(flushed, src);
+            const unsigned tso = (unsigned)cx.shfl_i32((int)stage_off, src);
+            const bool act = ((fm >> src) & 1ull) != 0ull;
+            if (act) {
+                cf s0, s1;
+                ld16((const cf*)(sbuf + j * 2048 + (((tf & 15) >> 1) + qq) * 256 + (lane & 15) * 16), s0, s1);
+                cx.store16(p.stage, tso + (unsigned)(tf + 2 * qq) * 8u, s0, s1);
+            }
+        }
+        if (full)
+            flushed += 8;
     };
 
     // ---- JOIN: a lane stands where restart point `cand`'s tag B is about to fire
@@ -810,18 +1095,18 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
             break;
         }
         running = true;
-        if (moved) {
-            jump_to(a);
+        jump_to(a); // (nothing was fetched for this lane while it stood at the junction)
+        if (moved)
             tq_load();
-        }
     };
 
     // ---- the recurrence
     bool all_done = false;
-    int since_walk = 0;
+    int since_walk = 0, since_flush = 0;
 #ifdef MSKP_PROF
     long long pf_t0 = __builtin_readcyclecounter(), pf_wait = 0, pf_issue = 0, pf_trip = 0, pf_walk = 0;
-    long pf_epochs = 0, pf_trips = 0, pf_lanes = 0;
+    long pf_epochs = 0, pf_trips = 0, pf_lanes = 0, pf_kind[4] = { 0, 0, 0, 0 };
+    long long pf_run8 = 0;
 #define PFB long long pf_a = __builtin_readcyclecounter();
 #define PFE(acc) acc += __builtin_readcyclecounter() - pf_a;
 #else
@@ -833,7 +1118,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         // else is in flight is younger still) are outstanding; then the next one goes out, into the
         // rows of block L + MSKP_D - MSKP_NB, which every lane has left
         { PFB
-        cx.template wait_vm<4 * (MSKP_D - 1)>();
+        cx.template wait_vm<(MSKP_BS / 2) * (MSKP_D - 1)>();
         PFE(pf_wait) }
         L++;
         { PFB
@@ -858,11 +1143,47 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 break;
             }
             since_walk++;
-            if (cx.ballot(running && ((a - org) - 1 < 8 * (L + MSKP_D - MSKP_NB + 1))) == 0ull)
+            if (cx.ballot(running && ((a - org) - 1 < MSKP_BS * (L + MSKP_D - MSKP_NB + 1))) == 0ull)
                 break;
             { PFB
-            trip();
+            const int npairs = fast_run_pairs();
+            if (npairs == 8) {
+#ifdef MSKP_PROF
+                const long long r0 = __builtin_readcyclecounter();
+#endif
+                run_pairs(8);
+#ifdef MSKP_PROF
+                pf_run8 += __builtin_readcyclecounter() - r0;
+                pf_kind[0] += 2;
+#endif
+            } else if (npairs == 4) {
+                run_pairs(4);
+#ifdef MSKP_PROF
+                pf_kind[0]++;
+#endif
+            } else if (npairs == 2) {
+                run_pairs(2);
+#ifdef MSKP_PROF
+                pf_kind[1]++;
+#endif
+            } else if (!fast_trip()) {
+                trip();
+#ifdef MSKP_PROF
+                pf_kind[3]++;
+            } else {
+                pf_kind[2]++;
+#endif
+            }
+            since_flush += npairs > 0 ? npairs : 1;
             PFE(pf_trip) }
+#ifndef MSKP_EXP_NOFLUSH
+            if (!JOIN && since_flush >= 4) { // (at most 7 symbols wait in a lane's stage behind a flush, a run adds 8)
+                since_flush = 0;
+                flush_syms();
+            }
+#else
+            flushed = cnt & ~7;
+#endif
 #ifdef MSKP_PROF
             pf_trips++;
             pf_lanes += aisx_popc64(cx.ballot(running));
@@ -870,10 +1191,10 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         }
     }
 #ifdef MSKP_PROF
-    if (wv == 0 && lane == 0)
-        printf("mskp prof %s: cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld\n",
-               JOIN ? "join" : "units", (long long)(__builtin_readcyclecounter() - pf_t0), pf_wait, pf_issue, pf_trip, pf_walk,
-               pf_epochs, pf_trips, pf_lanes);
+    if (lane == 0 && (wv == 5 || wv == 100 || wv == 177))
+        printf("mskp prof %s wave %d: dma %lld / %ld run8cycles %lld cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld | run4 %ld run2 %ld fast %ld general %ld\n",
+               JOIN ? "join" : "units", wv, pf_dma, pf_ndma, pf_run8, (long long)(__builtin_readcyclecounter() - pf_t0), pf_wait, pf_issue, pf_trip, pf_walk,
+               pf_epochs, pf_trips, pf_lanes, pf_kind[0], pf_kind[1], pf_kind[2], pf_kind[3]);
 #endif
     cx.template wait_vm<0>();
 
@@ -882,6 +1203,9 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     if (worst_row >= (unsigned)MSK_ZERO_ROW)
         status |= MSK_ST_INTERP_RANGE;
     if (!JOIN) {
+        for (int j = flushed; j < cnt; j++) // what is left in the stage
+            p.stage[(long)cc * p.stage_stride + q0 + j] =
+                ld8((const cf*)(sbuf + (lane >> 4) * 2048 + ((j & 15) >> 1) * 256 + (lane & 15) * 16 + (j & 1) * 8));
         mskp_res r;
         r.end.a = a;
         r.end.mu = mu;

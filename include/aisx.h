@@ -196,9 +196,10 @@ int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
 /* Diagnostics of the time-parallel recovery (k_mskp.h) for the last aisx_msk_process_stream call,
  * summed over the channels: out6 = { restart points chosen, units whose run was taken over,
  * symbols that came from units, units that ended at the next restart point, units that ended
- * elsewhere (stale tag, end of the row), calls that took the time-parallel path }.  Waits for
- * `stream`. */
-int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream);
+ * elsewhere (stale tag, end of the row), calls that took the time-parallel path, units whose end
+ * state equals what the next unit assumed, out of this many, items of the longest unit, items of all
+ * units }.  Waits for `stream`. */
+int aisx_msk_restart_stats(aisx_msk* h, long long* out10, void* stream);
 /* The NRZI bit tail (quadrature demod .. invert, python/ais_demod.py:48-52) has no part in
  * the timing recurrence.  With a tail stream set (enable != 0) aisx_msk_process_stream
  * launches it there, ordered after the call's recovery kernel, so that the next call need

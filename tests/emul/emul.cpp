@@ -93,6 +93,12 @@ struct EmuCtx {
         const float c = CNEG ? -K[KSEL][CS] : K[KSEL][CS], s = SNEG ? -K[KSEL][SS] : K[KSEL][SS];
         return mk(fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c));
     }
+    void store16(cf* base, unsigned off, cf a, cf b) const
+    {
+        cf* d = (cf*)((char*)base + off);
+        d[0] = a;
+        d[1] = b;
+    }
     float sel_f32(unsigned long long m, float if_set, float if_clear) const { return ((m >> (tid_ & 63)) & 1ull) ? if_set : if_clear; }
     void pin(float&) const {}
     void pin(int&) const {}
@@ -141,6 +147,7 @@ struct EmuCtx {
     int readlane_i32(int v, int lane) const { return xchg(v, lane); }
     int ctz64(unsigned long long v) const { return __builtin_ctzll(v); }
     void atomic_or64(unsigned long long* p, unsigned long long v) const { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+    int atomic_add_i32(int* p, int v) const { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
     // raw buffers and LDS-DMA (model of DevCtx's: the copy is done on the spot)
     struct Buf {
         const void* base;
@@ -441,6 +448,9 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
     pp.ctl = ctl.data(); pp.ctl_n = ctl_n.data(); pp.ctl_cap = ctl_cap;
     pp.smax = smax; pp.nrst = nrst.data(); pp.rst = rst.data(); pp.stage_stride = stage_stride;
     pp.tail = mskp_tail(h->d_sps); pp.min_gap = h->tp_min_gap;
+    const bool sorted = !getenv("AISX_MSK_TP_UNSORTED");
+    std::vector<int> ucount(8, 0), ulist((size_t)nc * MSKP_SMAX * MSKP_NCLS, 0);
+    pp.ucount = sorted ? ucount.data() : nullptr; pp.ulist = ulist.data(); pp.ucap = (long)nc * MSKP_SMAX;
     run_grid(nc, 1, 64, MSKP_PREP_LDS_TAGS * 8, [&](EmuCtx& cx) { mskp_prep_body(cx, pp); });
     MskpParams p;
     p.nchan = nc; p.d_sps = h->d_sps; p.gain = h->gain; p.gain_omega = h->gain_omega; p.limit = h->limit;
@@ -458,10 +468,11 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
     p.pieces = pieces.data(); p.npieces = npieces.data();
     p.produced = produced; p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
-    p.W = h->total_in; p.look = mskp_look(h->d_sps, h->limit); p.tail = pp.tail; p.max_noutput = h->max_noutput;
+    p.W = h->total_in; p.look = mskp_look(h->d_sps, h->limit); p.padv = mskp_padv(h->d_sps, h->gain, h->limit); p.jw = getenv("AISX_MSK_JW") ? atoi(getenv("AISX_MSK_JW")) : 16; p.tail = pp.tail; p.max_noutput = h->max_noutput;
+    p.ucount = pp.ucount; p.ulist = pp.ulist; p.ucap = pp.ucap;
     if (smax > 0)
-        run_grid((nc * smax + 63) / 64, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, false>(cx, p); });
-    run_grid((nc + 63) / 64, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
+        run_grid((nc * smax + 63) / 64 + (sorted ? MSKP_NCLS : 0), 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, false>(cx, p); });
+    run_grid((nc + p.jw - 1) / p.jw, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
     MskpGatherParams g;
     g.nchan = nc; g.pieces = pieces.data(); g.npieces = npieces.data(); g.stage = stage.data(); g.stage_stride = stage_stride;
     g.syms = syms; g.out_stride = out_stride;
