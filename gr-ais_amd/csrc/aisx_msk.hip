@@ -740,6 +740,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         p.W = h->total_in;
         p.look = mskp_look(h->d_sps, h->limit);
         p.padv = mskp_padv(h->d_sps, h->gain, h->limit);
+        p.padv_inv = mskp_padv_inv(h->d_sps, h->gain, h->limit);
         p.jw = h->tp_jw;
         p.ucount = tp_sorted ? h->d_ucount : nullptr;
         p.ulist = h->d_ulist;

@@ -131,6 +131,7 @@ struct MskpParams {
     unsigned long long W;       // absolute offset of row item 0 (items handed to the block before this call)
     int look;                   // samples a trip may read beyond in[iidx]
     int padv;                   // items a pair of iterations moves iidx at most
+    float padv_inv;             // a run of c pairs moves iidx by less than 1 + c / padv_inv
     int jw;                     // channels per wave of the join kernel (1..64: fewer lanes, fewer events per trip)
     // units by length class (null: lane u of wave w takes unit (w * 64 + u) % smax of channel (w * 64 + u) / smax)
     const int* ucount; const int* ulist; long ucap;
@@ -173,6 +174,7 @@ AISX_HD bool mskp_geometry_ok(float d_sps, float gain, float limit, int max_item
 }
 AISX_HD int mskp_look(float d_sps, float limit) { return (int)ceilf(d_sps) + (int)floorf(1.f + d_sps + fabsf(limit)) + 8; }
 AISX_HD int mskp_padv(float d_sps, float gain, float limit) { return (int)ceilf(2.f * (d_sps + fabsf(limit)) + 3.f * fabsf(gain)) + 1; }
+AISX_HD float mskp_padv_inv(float d_sps, float gain, float limit) { return 0.9999f / (2.f * (d_sps + fabsf(limit)) + 3.f * fabsf(gain)); }
 AISX_HD int mskp_tail(float d_sps) { return 64 + (int)ceilf(3.f * d_sps) + (int)ceilf(d_sps); }
 // staging slots per channel (the prepass drops restart points that would not fit)
 AISX_HD long mskp_stage_stride(int max_items, float d_sps, float gain, float limit)
@@ -496,6 +498,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     const typename Ctx::Buf inbuf = cx.make_buf(p.in + (long)(c_lo < p.nchan ? c_lo : 0) * p.in_stride, (unsigned)((rows * p.in_stride + n) * 8));
     const unsigned lane_off = (unsigned)((long)(cc - (c_lo < p.nchan ? c_lo : 0)) * p.in_stride * 8);
     char* const ring_b = lds;
+    const int ngrp = JOIN ? (p.jw + 15) >> 4 : 4; // groups of 16 lanes that carry streams
     char* const my_ring = ring_b + (lane >> 4) * MSKP_GRP_B + (lane & 15) * 16; // row r of this lane: my_ring + r * 256
     // what this lane knows of the four streams it serves (lane 16 j + (lane & 15), j = 0..3)
     int s_org[4];
@@ -534,6 +537,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
 #else
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                if (j >= ngrp)
+                    continue;
                 const int r0 = s_org[j] + p0;
                 const bool fast = s_valid[j] && ((runm >> (16 * j + (lane & 15))) & 1ull) != 0ull && r0 >= 0 && r0 + 8 <= n;
                 if (!JOIN) {
@@ -544,9 +549,6 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                     if (row0 == 0)
                         cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + MSKP_ROWS * 256));
                 } else if (cx.ballot(fast) != 0ull) {
-#ifdef MSKP_PROF
-                    const long long d0 = __builtin_readcyclecounter();
-#endif
                     if (fast) {
                         const unsigned off = s_base[j] + (unsigned)(p0 + 2 * q) * 8u;
 #ifndef MSKP_NODMA
@@ -555,10 +557,6 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                         if (row0 == 0)
                             cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + MSKP_ROWS * 256));
                     }
-#ifdef MSKP_PROF
-                    pf_dma += __builtin_readcyclecounter() - d0;
-                    pf_ndma++;
-#endif
                 }
             }
 #endif
@@ -794,10 +792,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 worst_row = worst_row > row ? worst_row : row;
                 const cf sq = cmul_exact(yi, yi);                                // :171
                 const cf nlin = cmul_exact(sq, cconj(cmul_exact(y, y)));         // :173-174
-                if (JOIN) {
-                    st8(p.syms + (long)cc * p.out_stride + cnt, yi);             // :187
-                    cnt++;
-                } else if (!warm) {
+                if (JOIN || !warm) { // :187 (into the stage: flush_syms)
                     st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yi);
                     cnt++;
                 }
@@ -869,14 +864,16 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         const bool vis = !JOIN || t_rel < ninp_row;
         const bool has = hasq && vis;
         const bool fire = has && (t_rel >= a) && ((float)(t_rel - base_row) < (float)(a - base_row) + d_sps);
-        bool rare = !ready || ((dv & 1) != 0) || needq || (fire && (!mskp_tame(t_val) || (cur + 1 >= qhi && cur + 1 < ntot)));
+        bool rare = ((dv & 1) != 0) || needq || (fire && (!mskp_tame(t_val) || (cur + 1 >= qhi && cur + 1 < ntot)));
         if (JOIN)
             rare = rare || !(cnt + 1 < nout_tot && a + look < ninp_row) || (fire && cur == cand_j);
         else
             rare = rare || warm || a >= lim_a || cnt >= cap - 1 || (has && t_rel < a) || (fire && cur == stop_j);
-        if (cx.ballot(running && rare) != 0ull)
+        // (a lane that is not ready sits the trip out; one whose samples have left the ring needs trip())
+        rare = ready ? rare : (pa - 1 < MSKP_BS * (L + MSKP_D - MSKP_NB));
+        if (cx.ballot(running && rare) != 0ull || cx.ballot(running && ready) == 0ull)
             return false;
-        if (running) {
+        if (running && ready) {
             if (fire) { // :148-162
                 mu = t_val;
                 a = t_rel;
@@ -903,10 +900,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
             worst_row = worst_row > rowE ? worst_row : rowE;
             const cf sqE = cmul_exact(yE, yE);                               // :171
             const cf nlE = cmul_exact(sqE, cconj(cmul_exact(y, y)));         // :173-174
-            if (JOIN)
-                st8(p.syms + (long)cc * p.out_stride + cnt, yE);             // :187
-            else
-                st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE);
+            st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE); // :187
             cnt++;
             if (!skipO) {
                 worst_row = worst_row > rowO ? worst_row : rowO;
@@ -940,12 +934,17 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     // sure): no tag can fire, no call or unit can end, the samples are in the ring, mu and omega are
     // in their normal ranges.  No test inside; only the real part of nlin_out is formed on the way
     // (:174, :178), the imaginary part of the last one -- state, d_dly_diff_1 -- at the end.
+    int mycan = 0;     // pairs this lane is good for (set by fast_run_pairs; 0: it is not ready, or something is due)
+    bool single = false; // some ready lane needs a trip of its own kind (a tag, an end, an odd iteration)
     auto run_pairs = [&](const int NP) {
-        if (running) {
+        if (mycan >= 1) { // (every lane does as many of the NP pairs as it is good for)
+            const int mine = mycan < NP ? mycan : NP;
             cf ysq = cmul_exact(y, y);
             cf sqE = ysq, sqO = ysq, yO = y;
             float nlr = nl.re;
             for (int it = 0; it < NP; it++) {
+                if (it >= mine)
+                    break;
                 const float m1 = mu + om;                                    // :199-201 behind the even iteration
                 const float fl1 = floorf(m1);
                 const int aO = a + (int)fl1;
@@ -954,10 +953,7 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 yO = fir(aO - org, (unsigned)(int)rintf(muO * 128.0f));
                 sqE = cmul_exact(yE, yE);                                    // :171
                 const float nlEr = sqE.re * ysq.re + sqE.im * ysq.im;        // :173-174, real part
-                if (JOIN)
-                    st8(p.syms + (long)cc * p.out_stride + cnt, yE);         // :187
-                else
-                    st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE);
+                st8((cf*)(sbuf + (lane >> 4) * 2048 + ((cnt & 15) >> 1) * 256 + (lane & 15) * 16 + (cnt & 1) * 8), yE); // :187
                 cnt++;
                 sqO = cmul_exact(yO, yO);
                 nlr = sqO.re * sqE.re + sqO.im * sqE.im;
@@ -971,18 +967,19 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 mu = m2 - fl2;
                 ysq = sqO;
             }
-            dv += 2 * NP;
+            dv += 2 * mine;
             y = yO;
             nl = mk(nlr, sqO.im * sqE.re - sqO.re * sqE.im); // :174 of the last odd iteration
         }
     };
-    // how many such pairs every running lane is good for: 8, 4, 2 or none
+    // the longest run some lane is good for: 8, 4, 2 pairs or none
     auto fast_run_pairs = [&]() -> int {
         const int pa = a - org;
         const bool vis = !JOIN || t_rel < ninp_row;
         const bool has = hasq && vis;
-        // items this lane may move before anything has to be looked at
-        int room = MSKP_BS * L - look - pa;                                  // the ring
+        // items this lane may move before the ring ends / before anything has to be looked at
+        const int ring_room = MSKP_BS * L - look - pa;
+        int room = 0x3fffffff;
         if (has) {
             const int r = (t_rel - cd - 1) - a;                        // the front tag's window (:142)
             room = room < r ? room : r;
@@ -996,27 +993,55 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
             const int r = lim_a - 1 - a;
             room = room < r ? room : r;
             prs = cap - 2 - cnt;
-            const int st = 16 - (cnt - flushed);
-            prs = prs < st ? prs : st;
         }
-        const bool plain = ((dv & 1) == 0) && !needq && !(!JOIN && warm) && (pa - 1 >= MSKP_BS * (L + MSKP_D - MSKP_NB)) &&
-                           (mu >= 0.f && mu <= 1.f) && (om >= 0.5f && om <= 30.f);
-        int can = 0;
-        if (plain && room >= 0) {
-            can = room / p.padv;
-            can = can < prs ? can : prs;
+        // (lanes that have run ahead of the others wait for the ring to move on: they sit the run out,
+        // and so does a lane that is good for fewer pairs than the run is long -- the lanes at the back,
+        // which hold the ring, have the most room)
+        const bool rdy = (pa + look <= MSKP_BS * L) && (pa - 1 >= MSKP_BS * (L + MSKP_D - MSKP_NB));
+        const bool plain = ((dv & 1) == 0) && !needq && !(!JOIN && warm) && (mu >= 0.f && mu <= 1.f) && (om >= 0.5f && om <= 30.f);
+        int can_evt = 0; // pairs before something is due in this lane
+        if (plain && room >= 1) {
+            can_evt = (int)((float)(room - 1) * p.padv_inv);
+            can_evt = can_evt < prs ? can_evt : prs;
         }
-        if (cx.ballot(running && can < 2) != 0ull)
-            return 0;
-        if (cx.ballot(running && can < 4) != 0ull)
-            return 2;
-        return cx.ballot(running && can < 8) != 0ull ? 4 : 8;
+        int can = ring_room >= 1 ? (int)((float)(ring_room - 1) * p.padv_inv) : 0;
+        can = can < can_evt ? can : can_evt;
+        { // (the symbol stage; a single trip may follow the run)
+            const int st = 15 - (cnt - flushed);
+            can = can < st ? can : st;
+        }
+        const bool in = running && rdy;
+        mycan = in ? can : 0;
+        single = cx.ballot(in && can_evt < 2) != 0ull; // (not the lanes the ring holds back: they wait)
+        if (cx.ballot(mycan >= 8) != 0ull)
+            return 8;
+        if (cx.ballot(mycan >= 4) != 0ull)
+            return 4;
+        return cx.ballot(mycan >= 2) != 0ull ? 2 : 0;
     };
 
     // ---- units: symbols leave the stage eight at a time, 64 contiguous bytes per lane, written by the
     // four lanes that serve it (16 cache lines per store instruction instead of 64)
-    const unsigned stage_off = (unsigned)(((long)cc * p.stage_stride + q0) * 8);
+    // symbol j of this lane goes to out_row[j]: the unit's slots of the staging row / the channel's output row
+    cf* const out_base = JOIN ? p.syms : p.stage;
+    const unsigned stage_off = JOIN ? (unsigned)((long)cc * p.out_stride * 8) : (unsigned)(((long)cc * p.stage_stride + q0) * 8);
+    auto drain_syms = [&]() { // (this lane's staged symbols, one by one: before its count jumps, and at the end)
+        for (int j = flushed; j < cnt; j++)
+            *(cf*)((char*)out_base + stage_off + (unsigned)j * 8u) =
+                ld8((const cf*)(sbuf + (lane >> 4) * 2048 + ((j & 15) >> 1) * 256 + (lane & 15) * 16 + (j & 1) * 8));
+        flushed = cnt;
+    };
     auto flush_syms = [&]() {
+        if (JOIN) { // (behind a jump the count may be odd: the 16-byte reads below want pairs)
+            const bool odd = valid && (flushed & 1) && cnt > flushed;
+            if (cx.ballot(odd) != 0ull) {
+                if (odd) {
+                    *(cf*)((char*)out_base + stage_off + (unsigned)flushed * 8u) =
+                        ld8((const cf*)(sbuf + (lane >> 4) * 2048 + ((flushed & 15) >> 1) * 256 + (lane & 15) * 16 + 8));
+                    flushed++;
+                }
+            }
+        }
         const bool full = valid && (cnt - flushed >= 8);
         const u64 fm = cx.ballot(full);
         if (fm == 0ull)
@@ -1024,14 +1049,16 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         const int qq = lane >> 4;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int src = 16 * j + (lane & 15);
-            const int tf = cx.shfl_i32(flushed, src);
-            const unsigned tso = (unsigned)cx.shfl_i32((int)stage_off, src);
-            const bool act = ((fm >> src) & 1ull) != 0ull;
-            if (act) {
-                cf s0, s1;
-                ld16((const cf*)(sbuf + j * 2048 + (((tf & 15) >> 1) + qq) * 256 + (lane & 15) * 16), s0, s1);
-                cx.store16(p.stage, tso + (unsigned)(tf + 2 * qq) * 8u, s0, s1);
+            if (j < ngrp) {
+                const int src = 16 * j + (lane & 15);
+                const int tf = cx.shfl_i32(flushed, src);
+                const unsigned tso = (unsigned)cx.shfl_i32((int)stage_off, src);
+                const bool act = ((fm >> src) & 1ull) != 0ull;
+                if (act) {
+                    cf s0, s1;
+                    ld16((const cf*)(sbuf + j * 2048 + ((((tf & 15) >> 1) + qq) & 7) * 256 + (lane & 15) * 16), s0, s1);
+                    cx.store16(out_base, tso + (unsigned)(tf + 2 * qq) * 8u, s0, s1);
+                }
             }
         }
         if (full)
@@ -1067,6 +1094,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 cand_j = cand < K ? rs[cand].jA + 1 + nc : 0x7fffffff;
                 break; // through the junction, serially
             }
+            if (!moved)
+                drain_syms();
             moved = true;
             mskp_piece pc;
             pc.out0 = cnt;
@@ -1096,8 +1125,10 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         }
         running = true;
         jump_to(a); // (nothing was fetched for this lane while it stood at the junction)
-        if (moved)
+        if (moved) {
+            flushed = cnt;
             tq_load();
+        }
     };
 
     // ---- the recurrence
@@ -1154,30 +1185,29 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 run_pairs(8);
 #ifdef MSKP_PROF
                 pf_run8 += __builtin_readcyclecounter() - r0;
-                pf_kind[0] += 2;
 #endif
-            } else if (npairs == 4) {
+            } else if (npairs == 4)
                 run_pairs(4);
-#ifdef MSKP_PROF
-                pf_kind[0]++;
-#endif
-            } else if (npairs == 2) {
+            else if (npairs == 2)
                 run_pairs(2);
+            if (npairs == 0 || single) {
 #ifdef MSKP_PROF
-                pf_kind[1]++;
+                const long long r0 = __builtin_readcyclecounter();
 #endif
-            } else if (!fast_trip()) {
-                trip();
+                if (!fast_trip())
+                    trip();
 #ifdef MSKP_PROF
-                pf_kind[3]++;
-            } else {
-                pf_kind[2]++;
+                pf_dma += __builtin_readcyclecounter() - r0;
+                pf_ndma++;
 #endif
             }
-            since_flush += npairs > 0 ? npairs : 1;
+#ifdef MSKP_PROF
+            pf_kind[npairs == 8 ? 0 : (npairs == 4 ? 1 : (npairs == 2 ? 2 : 3))]++;
+#endif
+            since_flush += npairs + 1;
             PFE(pf_trip) }
 #ifndef MSKP_EXP_NOFLUSH
-            if (!JOIN && since_flush >= 4) { // (at most 7 symbols wait in a lane's stage behind a flush, a run adds 8)
+            if (since_flush >= 4) { // (at most 7 symbols wait in a lane's stage behind a flush, a run adds 8)
                 since_flush = 0;
                 flush_syms();
             }
@@ -1191,8 +1221,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         }
     }
 #ifdef MSKP_PROF
-    if (lane == 0 && (wv == 5 || wv == 100 || wv == 177))
-        printf("mskp prof %s wave %d: dma %lld / %ld run8cycles %lld cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld | run4 %ld run2 %ld fast %ld general %ld\n",
+    if (lane == 0 && JOIN && pf_epochs > 1300)
+        printf("mskp prof %s wave %d: singles %lld / %ld run8 %lld cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld | run8 %ld run4 %ld run2 %ld none %ld\n",
                JOIN ? "join" : "units", wv, pf_dma, pf_ndma, pf_run8, (long long)(__builtin_readcyclecounter() - pf_t0), pf_wait, pf_issue, pf_trip, pf_walk,
                pf_epochs, pf_trips, pf_lanes, pf_kind[0], pf_kind[1], pf_kind[2], pf_kind[3]);
 #endif
@@ -1202,10 +1232,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         return;
     if (worst_row >= (unsigned)MSK_ZERO_ROW)
         status |= MSK_ST_INTERP_RANGE;
+    drain_syms(); // what is left in the stage
     if (!JOIN) {
-        for (int j = flushed; j < cnt; j++) // what is left in the stage
-            p.stage[(long)cc * p.stage_stride + q0 + j] =
-                ld8((const cf*)(sbuf + (lane >> 4) * 2048 + ((j & 15) >> 1) * 256 + (lane & 15) * 16 + (j & 1) * 8));
         mskp_res r;
         r.end.a = a;
         r.end.mu = mu;

@@ -468,7 +468,7 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
     p.pieces = pieces.data(); p.npieces = npieces.data();
     p.produced = produced; p.consumed = h->consumed.data(); p.status = h->status.data();
     p.mmse = &aisx_mmse_taps[0][0];
-    p.W = h->total_in; p.look = mskp_look(h->d_sps, h->limit); p.padv = mskp_padv(h->d_sps, h->gain, h->limit); p.jw = getenv("AISX_MSK_JW") ? atoi(getenv("AISX_MSK_JW")) : 16; p.tail = pp.tail; p.max_noutput = h->max_noutput;
+    p.W = h->total_in; p.look = mskp_look(h->d_sps, h->limit); p.padv = mskp_padv(h->d_sps, h->gain, h->limit); p.padv_inv = mskp_padv_inv(h->d_sps, h->gain, h->limit); p.jw = getenv("AISX_MSK_JW") ? atoi(getenv("AISX_MSK_JW")) : 16; p.tail = pp.tail; p.max_noutput = h->max_noutput;
     p.ucount = pp.ucount; p.ulist = pp.ulist; p.ucap = pp.ucap;
     if (smax > 0)
         run_grid((nc * smax + 63) / 64 + (sorted ? MSKP_NCLS : 0), 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, false>(cx, p); });
