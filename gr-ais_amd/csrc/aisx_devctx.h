@@ -8,6 +8,8 @@
 namespace aisx {
 
 struct DevCtx {
+    // LDS writes of one lane are seen by the other lanes of its wave at once (they run in lock step)
+    static constexpr bool wave_lds_coherent = true;
     char* lds_;
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nthreads() const { return blockDim.x; }

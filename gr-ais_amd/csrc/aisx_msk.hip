@@ -155,6 +155,9 @@ struct aisx_msk {
     int tp_smax = MSKP_SMAX; // restart points per channel at most (0: the serial kernel)
     int tp_min_gap = 64;   // items between restart points at least
     int tp_jw = 16;        // channels per wave of the join kernel
+    int tp_join = 1;       // the join: 1 = the serial kernel with fast-forward (k_msk.h, MskParams::ff), 0 = k_mskp_join
+    int tp_max_span = 4096; // no unit from a restart point further than this from the next one (tp_join = 1: the serial kernel is faster there)
+    int* d_ct_nc = nullptr;
     int max_noutput = 0;   // set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)
     unsigned long long total_in = 0; // items handed to the block so far = absolute offset of the next row's item 0
     msk_ctag* d_ctl = nullptr;
@@ -278,6 +281,10 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
             h->tp_smax = std::max(0, std::min(atoi(e), (int)MSKP_SMAX));
         if (const char* e = getenv("AISX_MSK_TP_GAP"))
             h->tp_min_gap = std::max(0, atoi(e));
+        if (const char* e = getenv("AISX_MSK_TP_JOIN"))
+            h->tp_join = atoi(e) != 0;
+        if (const char* e = getenv("AISX_MSK_TP_MAXSPAN"))
+            h->tp_max_span = std::max(64, atoi(e));
         if (const char* e = getenv("AISX_MSK_JW"))
             h->tp_jw = std::max(1, std::min(64, atoi(e)));
         if (const char* e = getenv("AISX_MSK_MAX_NOUTPUT")) // (experiments; the API is aisx_msk_set_max_noutput_items)
@@ -372,6 +379,7 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     dev_free(h->d_res);
     dev_free(h->d_ucount);
     dev_free(h->d_ulist);
+    dev_free(h->d_ct_nc);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_stage[k]);
         dev_free(h->d_pieces[k]);
@@ -506,10 +514,17 @@ static void msk_fill_common(aisx_msk* h, MskParams& p)
     p.lds_ring_off = msk_lds_ringoff(h->lpw);
     p.inline_tags = h->inline_tags;
     p.max_noutput = h->max_noutput;
+    p.ff = 0;
+    p.nrst = nullptr;
+    p.rst = nullptr;
+    p.res = nullptr;
+    p.pieces = nullptr;
+    p.npieces = nullptr;
+    p.ct_nc = nullptr;
 }
 
 // compacts (carried tags + this call's tags) into h->d_ct for the kernel launch that follows
-static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_tag_counts, int tag_cap, hipStream_t st)
+static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_tag_counts, int tag_cap, hipStream_t st, int* d_ct_nc = nullptr)
 {
     const int need = aisx_msk::ctag_cap + (d_tags ? tag_cap : 0);
     int rc;
@@ -538,6 +553,7 @@ static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_t
     t.ct = h->d_ct;
     t.ct_n = h->d_ct_n;
     t.ct_cap = h->ct_cap;
+    t.ct_nc = d_ct_nc;
     hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 3) / 4), dim3(256), 0, st, t); // a wave per channel
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
@@ -595,7 +611,7 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
         h->stage_stride = mskp_stage_stride(h->max_items + aisx_msk::carry_cap, h->d_sps, h->gain, h->limit);
         if ((rc = dev_alloc(&h->d_ctl_n, nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, nc)) != AISX_OK ||
             (rc = dev_alloc(&h->d_rst, nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, nc * MSKP_SMAX)) != AISX_OK ||
-            (rc = dev_alloc(&h->d_ucount, 8)) != AISX_OK || (rc = dev_alloc(&h->d_ulist, nc * MSKP_SMAX * MSKP_NCLS)) != AISX_OK)
+            (rc = dev_alloc(&h->d_ucount, 8)) != AISX_OK || (rc = dev_alloc(&h->d_ct_nc, nc)) != AISX_OK || (rc = dev_alloc(&h->d_ulist, nc * MSKP_SMAX * MSKP_NCLS)) != AISX_OK)
             return rc;
         for (int k = 0; k < 2; k++)
             if ((rc = dev_alloc(&h->d_stage[k], nc * (size_t)h->stage_stride)) != AISX_OK ||
@@ -654,6 +670,7 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         t.stage_stride = h->stage_stride;
         t.tail = mskp_tail(h->d_sps);
         t.min_gap = h->tp_min_gap;
+        t.max_span = h->tp_join ? h->tp_max_span : 0x3fffffff;
         // units sorted by length need every row within 4 GiB of the first (32-bit buffer offsets)
         const bool sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !getenv("AISX_MSK_TP_UNSORTED");
         t.ucount = sorted ? h->d_ucount : nullptr;
@@ -664,6 +681,8 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         tp_sorted = sorted;
         hipLaunchKernelGGL(k_mskp_prep, dim3(h->nchan), dim3(64), 0, st, t);
         AISX_HIPCHK(hipGetLastError());
+        if (h->tp_join && (rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st, h->d_ct_nc)) != AISX_OK)
+            return rc;
     } else if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st)) != AISX_OK) {
         return rc;
     }
@@ -758,8 +777,37 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
             hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64 + (tp_sorted ? MSKP_NCLS : 0))), dim3(64), MSKP_LDS_BYTES, st, p);
             AISX_HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + h->tp_jw - 1) / h->tp_jw), dim3(64), MSKP_LDS_BYTES, st, p);
-        AISX_HIPCHK(hipGetLastError());
+        if (h->tp_join) {
+            // the serial kernel as the join: the loop from the carried state, fast-forwarded through the units
+            MskParams m;
+            msk_fill_common(h, m);
+            m.in = (const cf*)d_in;
+            m.in_stride = in_stride;
+            m.n = n;
+            m.stream_mode = 1;
+            m.gr_ninput = 0;
+            m.gr_noutput = 0;
+            m.syms = syms;
+            m.err = nullptr;
+            m.mu_out = nullptr;
+            m.out_stride = out_stride;
+            m.sym_al16 = 0; // (behind a fast-forward a channel's symbol count may be odd)
+            m.out_cap = out_cap;
+            m.produced = produced;
+            m.inline_tags = 0; // (every tag reset through the general step, where the junctions are looked at)
+            m.ff = 1;
+            m.nrst = h->d_nrst;
+            m.rst = h->d_rst;
+            m.res = h->d_res;
+            m.pieces = h->d_pieces[par];
+            m.npieces = h->d_npieces[par];
+            m.ct_nc = h->d_ct_nc;
+            if ((rc = msk_launch(m, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), st)) != AISX_OK)
+                return rc;
+        } else {
+            hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + h->tp_jw - 1) / h->tp_jw), dim3(64), MSKP_LDS_BYTES, st, p);
+            AISX_HIPCHK(hipGetLastError());
+        }
         h->tp_calls++;
     } else {
         MskParams p;

@@ -93,6 +93,44 @@ static_assert(msk_lds_bytes(8) + 71680 <= 160 * 1024, "timing recovery + one cor
 constexpr int BT_T = 256;          // bit tail: threads per workgroup
 constexpr int BT_SEG = BT_T * 8;   // symbols per workgroup
 
+// ---- restart points of the time-parallel recovery (k_mskp.h), as this kernel meets them when it
+// runs as the JOIN of that scheme (MskParams::ff): see k_mskp.h for what they are
+constexpr int MSKP_SMAX = 64; // restart points per channel at most
+enum { MSKP_KIND_NONE = 0, MSKP_KIND_NEXT = 1, MSKP_KIND_HANDOFF = 2 };
+struct mskp_rst { // restart point k of a channel: tags jA and jA + 1 of the channel's list of new time_est tags
+    int jA;
+    int relA, relB; // row offsets of the two tags
+    int q0, cap;    // the unit's slots in the channel's staging row (cap 0: no unit runs from here)
+    int pad[3];
+};
+struct mskp_snap { // the loop at the top of an iteration, before the tag test (:138-140)
+    int a;          // iidx, as a row offset
+    float mu, omega;
+    int div;
+    cf y;           // d_dly_conj_1 = d_dly_conj_2 (:194-195)
+    cf nl;          // d_dly_diff_1
+    int cur;        // index of the front tag in the new-tag list
+    int cnt;        // symbols emitted
+};
+struct mskp_res { // what a unit leaves behind
+    mskp_snap end;
+    cf ay, anl;     // the delay registers it assumed at its restart point
+    int kind;       // MSKP_KIND_*: ended where the next restart point's tag B is about to fire / somewhere else
+    int status;
+};
+struct mskp_piece {
+    int out0, src0, cnt; // symbols [out0, out0 + cnt) of the output row = staging row [src0, src0 + cnt)
+};
+AISX_HD bool mskp_same_bits(cf a, cf b)
+{
+    unsigned ar, ai, br, bi;
+    __builtin_memcpy(&ar, &a.re, 4);
+    __builtin_memcpy(&ai, &a.im, 4);
+    __builtin_memcpy(&br, &b.re, 4);
+    __builtin_memcpy(&bi, &b.im, 4);
+    return ar == br && ai == bi;
+}
+
 // a time_est tag as the timing-recovery kernel wants it: offset relative to the channel's
 // nitems_read at the start of the call, value narrowed to the float the loop uses
 struct msk_ctag { int rel; float val; };
@@ -134,6 +172,14 @@ struct MskParams {
     int lpw;           // channels per wave, = the build's LPW: 4, 8, 16, 32 or 64
     int inline_tags;   // tag resets inside the lock-step runs (0: every tag through the general steps)
     int max_noutput;   // gr::block::set_max_noutput_items(): output items a general_work call is offered at most (0: what fits)
+    // ---- this kernel as the JOIN of the time-parallel recovery (ff != 0; stream mode, osps 1, no err / mu ports).
+    // Where the front tag is tag B of restart point k, about to reset the loop, and the two delay registers
+    // equal what unit k assumed, unit k's run IS this loop's: the lane takes its symbol count and end
+    // state, and the following units' too while each ended on the next one's assumption (k_mskp.h).
+    int ff;
+    const int* nrst; const mskp_rst* rst; const mskp_res* res;
+    mskp_piece* pieces; int* npieces;
+    const int* ct_nc;  // carried tags in front of the new ones in `ct` (-1: a new tag was dropped, no fast-forward)
 };
 
 // quadrature_demod_cf(pi/2) -> binary_slicer_fb -> diff_decoder_bb(2) -> invert over the
@@ -293,6 +339,24 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     };
     tq_fill();
 
+    // ---- JOIN of the time-parallel recovery: the next restart point this lane may meet
+    const bool FF = p.ff != 0;
+    // (FF: what a channel was when its step ended, see the main loop)
+    bool fin_saved = false;
+    float fin_mu = 0.f, fin_omega = 0.f;
+    int fin_div = 0, fin_status = 0;
+    cf fin_interp = mk(0.f, 0.f), fin_diff = mk(0.f, 0.f);
+    unsigned fin_worst = 0;
+    int ffK = 0, ffnck = 0, cand = 0, candj = 0x7fffffff, ffnp = 0;
+    int voff = 0; // new-sample index = ring index + voff: behind a fast-forward the ring carries on elsewhere in the row
+    const mskp_rst* const ffrs = FF ? p.rst + (long)cc * MSKP_SMAX : nullptr;
+    const mskp_res* const ffrr = FF ? p.res + (long)cc * MSKP_SMAX : nullptr;
+    if (FF) {
+        ffnck = p.ct_nc[cc];
+        ffK = ffnck >= 0 ? p.nrst[cc] : 0;
+        candj = ffK > 0 ? ffrs[0].jA + 1 + ffnck : 0x7fffffff;
+    }
+
     // output rows are addressed as (wave-uniform base) + (32-bit byte offset of this lane)
     char* const osym0 = (char*)(p.syms + (long)cbase * p.out_stride);
     char* const oerr0 = AUX && p.err ? (char*)(p.err + (long)cbase * p.out_stride) : nullptr;
@@ -333,7 +397,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             while (cx.ballot((so >> SLOT_SH) - nf >= FL) != 0ull) {
                 if ((so >> SLOT_SH) - nf >= FL) {
                     const unsigned k0 = nf + 2u * (unsigned)q;
-                    if (NQ <= 8 || (unsigned)q < FLQ) {
+                    if ((NQ <= 8 || (unsigned)q < FLQ) && !fin_saved) {
                         const cf a = stage_get(k0), b = stage_get(k0 + 1u);
                         cf* dst = (cf*)(osym0 + obrow) + k0;
                         if (p.sym_al16) {
@@ -406,8 +470,10 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     cf r[QS]; // this lane's share of the chunk in flight
     const cf* myin = p.in + (long)cc * p.in_stride;
     auto issue_chunk = [&](int t) {
-        const int s0 = t * MSK_CHUNK + q * QS;
-        if (t * MSK_CHUNK + MSK_CHUNK <= n) { // whole chunk inside the input: 16-byte loads, no predicates
+        const int s0 = t * MSK_CHUNK + q * QS + voff;
+        // (FF: every lane's chunk lies somewhere else in its row)
+        const bool inside = FF ? cx.ballot(!(s0 >= 0 && t * MSK_CHUNK + MSK_CHUNK + voff <= n)) == 0ull : (t * MSK_CHUNK + MSK_CHUNK <= n);
+        if (inside) { // whole chunk inside the input: 16-byte loads, no predicates
             const cf_pair* src = (const cf_pair*)(myin + s0); // (dead lanes re-read the last channel's row)
 #pragma unroll
             for (int k = 0; k < QS / 2; k++) {
@@ -419,7 +485,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #pragma unroll
             for (int k = 0; k < QS; k++) {
                 r[k] = mk(0.f, 0.f);
-                if (s0 + k < n)
+                if (s0 + k < n && s0 + k >= 0)
                     r[k] = myin[s0 + k];
             }
         }
@@ -468,6 +534,140 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         fast_lim = ninp < tag_trig ? ninp : tag_trig;
         fast_lim = fast_lim < chunk_lim ? fast_lim : chunk_lim;
     };
+    // FF: the lane stands where restart point `cand`'s tag B is about to reset the loop
+    auto ff_walk = [&]() -> bool {
+        bool moved = false;
+        int dcnt = 0, a_new = 0, cur_new = 0;
+        cf yv = last_interp, nlv = d_dly_diff_1;
+        float mu_new = 0.f, om_new = 0.f;
+        int div_new = 0;
+        const int cd = jump_margin - 1;
+        for (;;) {
+            const mskp_res r = ffrr[cand];
+            const bool same = r.kind != MSKP_KIND_NONE && mskp_same_bits(r.ay, yv) && mskp_same_bits(r.anl, nlv);
+            // (the unit ran blind to the general_work calls: k_mskp.h, mskp_body's walk, says when that is sound)
+            bool clean = same && (r.end.a + 1 + cd <= base + ninp - pending) && ffnp < MSKP_SMAX;
+            if (p.max_noutput > 0)
+                clean = clean && msk_forecast(d_sps, p.max_noutput) <= (n - r.end.a) - 1 &&
+                        (ototal + oidx + dcnt + r.end.cnt + p.max_noutput <= p.out_cap);
+            else
+                clean = clean && (oidx + dcnt + r.end.cnt < noutput);
+            if (!clean) {
+                cand++;
+                candj = cand < ffK ? ffrs[cand].jA + 1 + ffnck : 0x7fffffff;
+                break;
+            }
+            if (owner && live) {
+                mskp_piece pc;
+                pc.out0 = ototal + oidx + dcnt;
+                pc.src0 = ffrs[cand].q0;
+                pc.cnt = r.end.cnt;
+                p.pieces[(long)cc * MSKP_SMAX + ffnp] = pc;
+            }
+            ffnp++;
+            moved = true;
+            dcnt += r.end.cnt;
+            a_new = r.end.a;
+            mu_new = r.end.mu;
+            om_new = r.end.omega;
+            div_new = r.end.div;
+            yv = r.end.y;
+            nlv = r.end.nl;
+            cur_new = r.end.cur;
+            status |= r.status;
+            cand++;
+            candj = cand < ffK ? ffrs[cand].jA + 1 + ffnck : 0x7fffffff;
+            if (r.kind == MSKP_KIND_NEXT && cand < ffK)
+                continue; // that unit ended where the next one's tag B is about to fire
+            break;
+        }
+        if (!moved)
+            return false;
+        // what this lane has staged leaves now (the owner lane wrote those slots itself): the count jumps
+        if constexpr (STG) {
+            if (owner) {
+                for (unsigned kk = nf; kk < (so >> SLOT_SH); kk++)
+                    st8((cf*)(osym0 + obrow) + kk, stage_get(kk));
+            }
+            nf = (so >> SLOT_SH) + (unsigned)dcnt;
+            so += (unsigned)dcnt << SLOT_SH;
+        }
+        ob += (unsigned)dcnt * 8u;
+        d_mu = mu_new;
+        d_omega = om_new;
+        d_div = div_new;
+        last_interp = yv;
+        prev_sq = cmul_exact(yv, yv);
+        d_dly_diff_1 = nlv;
+        // the tags from the unit's front tag on
+        gq = cur_new + ffnck;
+        if (gq > ntot)
+            gq = ntot;
+        qn = 0;
+        qhead = 0;
+        tq_fill();
+        // general_work calls that began and ended inside the units (only with max_noutput_items)
+        int rem = oidx + dcnt;
+        bool crossed = false;
+        int nout_cur = noutput;
+        while (p.max_noutput > 0 && rem >= nout_cur) {
+            rem -= nout_cur;
+            ototal += nout_cur;
+            nout_cur = p.max_noutput;
+            crossed = true;
+        }
+        const int q_new = a_new + pending; // logical index of in[iidx]
+        if (crossed) {
+            base = q_new; // (somewhere at or before: nothing reads it before the next call starts)
+            setup_round();
+        } else {
+            iidx = q_new - base;
+            tq_front();
+            nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
+        }
+        oidx = rem;
+        // The ring carries on at the unit's end: the slots of the chunk landed last are filled from there
+        // right away (every lane of the channel writes the same 64 values: no exchange to wait for), the
+        // chunk in flight is fetched again for this lane, and the lane goes on as if nothing had happened.
+        const int v_new = loaded_s - MSK_CHUNK + 1; // in[iidx - 1] = the first slot of that chunk
+        voff = a_new - v_new;
+        sb = (v_new + MSK_OFF) * SLOT_B;
+        {
+            const int slot0 = (loaded_s - MSK_CHUNK + MSK_OFF) & (MSK_RING - 1); // multiple of 64
+            // (on the device the NQ lanes of the channel each bring their share, loads first; the lane
+            // model's lanes are free-running threads with no barrier here: each brings all 64)
+            constexpr int SH = Ctx::wave_lds_coherent ? 1 : NQ;
+            for (int sh = 0; sh < SH; sh++) {
+                const int k0 = ((Ctx::wave_lds_coherent ? q : sh) * QS);
+                cf t[QS];
+#pragma unroll
+                for (int k = 0; k < QS; k++) {
+                    const int sr = loaded_s - MSK_CHUNK + k0 + k + voff;
+                    t[k] = mk(0.f, 0.f);
+                    if (sr >= 0 && sr < n)
+                        t[k] = myin[sr];
+                }
+#pragma unroll
+                for (int k = 0; k < QS; k++) {
+                    myring[(slot0 + k0 + k) * LPW] = t[k];
+                    if (slot0 == 0 && k0 + k < 8)
+                        myring[(MSK_RING + k0 + k) * LPW] = t[k];
+                }
+            }
+            if (more) { // (chunk `landed` is in flight, fetched for the old place)
+                const int s0 = landed * MSK_CHUNK + q * QS + voff;
+#pragma unroll
+                for (int k = 0; k < QS; k++) {
+                    r[k] = mk(0.f, 0.f);
+                    if (s0 + k < n && s0 + k >= 0)
+                        r[k] = myin[s0 + k];
+                }
+            }
+        }
+        tag_trig = (int)0x80000000;
+        fast_lim = (int)0x80000000;
+        return true;
+    };
     auto events = [&](const int PAR) -> int {
         if (!(oidx < noutput && iidx < ninp)) { // this general_work() call is over (:138)
             base += iidx;                       // consume_each(iidx)
@@ -489,6 +689,18 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         const bool waiting = more && !(spos - MSK_OFF + 8 + jump_margin <= loaded_s);
         // a time_est tag lands in [iidx, iidx + d_sps) (:140-164)
         if (!waiting && (nt_rel >= iidx) && ((float)nt_rel < ((float)iidx + d_sps))) {
+            if (FF) {
+                const int fi = gq - (qn - qhead); // list index of the front tag
+                while (cand < ffK && candj < fi) {
+                    cand++;
+                    candj = cand < ffK ? ffrs[cand].jA + 1 + ffnck : 0x7fffffff;
+                }
+                if (cand < ffK && fi == candj && ff_walk()) {
+                    // (at the unit's end now, at the top of an iteration: from the loop head again)
+                    bounds(sb >> SLOT_SH);
+                    return EV_OTHER_PARITY;
+                }
+            }
             const float center = nt_val;
             if (center == center) { // not NaN (:144-147)
                 const int old = iidx;
@@ -665,7 +877,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         f = f < chunk_lim ? f : chunk_lim;
         fast_lim = (tag_trig == TRIG_FORCED) ? fast_lim : f;
     };
-    more = landed < nchunks;
+    // (FF: a lane that has been fast-forwarded reads on elsewhere in its row: chunks go on as long as any lane wants one)
+    auto need_more = [&]() -> bool {
+        return FF ? cx.ballot(!done && landed * MSK_CHUNK < n + 8 - voff) != 0ull : landed < nchunks;
+    };
+    more = need_more();
     if (more)
         issue_chunk(landed);
     loaded_s = landed * MSK_CHUNK; // new samples [.., loaded_s) are in the rings
@@ -678,8 +894,29 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // lock step: nobody parked, every lane about to run an even iteration, none at its
         // bound -> pairs of iterations run on the whole wave, exec untouched, in a loop of
         // their own (so that the values the loop carries stay in place)
+        // (FF: channels whose step is over -- fast-forwarded to the end long before the others -- stand aside:
+        // they run along in the lock-step runs, exec untouched, on a state that is thrown away; what they
+        // were when they finished is kept here, and their stores are switched off)
+        const u64 DN = FF ? cx.ballot(done) : 0ull;
+        if (FF && done && !fin_saved) {
+            fin_saved = true;
+            fin_mu = d_mu;
+            fin_omega = d_omega;
+            fin_div = d_div;
+            fin_interp = last_interp;
+            fin_diff = d_dly_diff_1;
+            fin_status = status;
+            fin_worst = worst_imu;
+            if constexpr (STG) { // its last symbols leave now (the owner lane staged them itself)
+                if (owner) {
+                    for (unsigned kk = nf; kk < (so >> SLOT_SH); kk++)
+                        st8((cf*)(osym0 + obrow) + kk, stage_get(kk));
+                }
+                nf = so >> SLOT_SH;
+            }
+        }
         { PF_BEGIN
-        if (P == 0ull && E == ALL) {
+        if ((P & ~DN) == 0ull && (E | DN) == ALL && DN != ALL) {
             // How many (even, odd) pairs can EVERY lane run without looking up?  A pair moves
             // iidx by about pair_adv and emits one output (two if osps == 2), so a lane
             // with `room` items below its bound is good for room / pair_adv pairs (see pair_adv); the wave
@@ -697,12 +934,12 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             if (!lock_ok || !(d_mu >= 0.f && d_mu <= 1.f)) // (the loop below takes mu in [0, 1] for granted)
                 can = 0;
             int npairs = 0; // = min over the lanes of `can`
-            if (cx.ballot(can >= 1) == ALL) { // (the usual way out near an event: one ballot)
+            if ((cx.ballot(can >= 1) | DN) == ALL) { // (the usual way out near an event: one ballot)
                 npairs = MSK_PAIRS_MAX;
-                if (cx.ballot(can >= MSK_PAIRS_MAX) != ALL) {
+                if ((cx.ballot(can >= MSK_PAIRS_MAX) | DN) != ALL) {
                     npairs = 1;
                     for (int bit = MSK_PAIRS_MAX / 2; bit; bit >>= 1)
-                        if (npairs + bit < MSK_PAIRS_MAX && cx.ballot(can >= npairs + bit) == ALL)
+                        if (npairs + bit < MSK_PAIRS_MAX && (cx.ballot(can >= npairs + bit) | DN) == ALL)
                             npairs += bit;
                 }
             }
@@ -730,9 +967,9 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 if (!lock_ok || !(d_mu >= 0.f && d_mu <= 1.f) || tag_trig == TRIG_FORCED)
                     can2 = 0;
                 int ntrips = 0;
-                if (cx.ballot(can2 >= 1) == ALL) {
+                if ((cx.ballot(can2 >= 1) | DN) == ALL) {
                     ntrips = 1;
-                    while (ntrips < MSK_TAG_TRIPS && cx.ballot(can2 >= ntrips + 1) == ALL)
+                    while (ntrips < MSK_TAG_TRIPS && (cx.ballot(can2 >= ntrips + 1) | DN) == ALL)
                         ntrips++;
                 }
                 if (ntrips > 0) {
@@ -996,6 +1233,11 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         // Lanes that do wait satisfy the condition themselves, so when everybody waits the
         // chunk does land.
         { PF_BEGIN
+        if (FF && !more) { // (a fast-forward may have put a lane where the chunks had stopped coming)
+            more = need_more();
+            if (more)
+                issue_chunk(landed);
+        }
         if (more) {
             const bool clear = done || ((sb >> SLOT_SH) - MSK_OFF >= landed * MSK_CHUNK - (MSK_RING - MSK_CHUNK) + 2);
             if (cx.ballot(clear) == ALL) {
@@ -1006,7 +1248,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
                 land_chunk(landed);
                 cx.wave_sync(); // (lane model: the shares the other lanes wrote are in place)
                 landed++;
-                more = landed < nchunks;
+                more = need_more();
                 if (more)
                     issue_chunk(landed);
                 loaded_s = landed * MSK_CHUNK;
@@ -1041,7 +1283,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 #endif
     if constexpr (STG) { // what is left in the stage: fewer than FL symbols per channel, 8-byte stores
         flush_syms();
-        const unsigned left = (so >> SLOT_SH) - nf;
+        const unsigned left = fin_saved ? 0u : (so >> SLOT_SH) - nf;
 #pragma unroll
         for (unsigned j = 0; j < 2; j++) {
             const unsigned k = (unsigned)q + j * FLQ;
@@ -1051,6 +1293,15 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     }
     if (!live || !owner)
         return;
+    if (fin_saved) {
+        d_mu = fin_mu;
+        d_omega = fin_omega;
+        d_div = fin_div;
+        last_interp = fin_interp;
+        d_dly_diff_1 = fin_diff;
+        status = fin_status;
+        worst_imu = fin_worst;
+    }
     if (worst_imu >= (unsigned)MSK_ZERO_ROW)
         status |= MSK_ST_INTERP_RANGE;
     p.mu[c] = d_mu;
@@ -1072,8 +1323,16 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             status |= MSK_ST_CARRY_OVERFLOW;
             left = cap - 1;
         }
-        for (int k = 0; k <= left; k++)
-            cout[k] = myring[((base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)) * LPW];
+        if (FF) { // (the ring may stand elsewhere in the row: from memory)
+            for (int k = 0; k <= left; k++) {
+                const int qi = base - 1 + k; // logical item: -1 the item before nitems_read, then the carried, then the new ones
+                cout[k] = qi < pending ? cin[qi + 1] : myin[qi - pending];
+            }
+            p.npieces[c] = ffnp;
+        } else {
+            for (int k = 0; k <= left; k++)
+                cout[k] = myring[((base - 1 + k - pending + MSK_OFF) & (MSK_RING - 1)) * LPW];
+        }
         p.carry_len_out[c] = left;
         // tags the scheduler still holds: offset >= nitems_read
         tag_rec* cto = p.ctag_out + (long)c * p.ctag_cap;
@@ -1128,6 +1387,7 @@ struct TagPrepParams {
     const tag_rec* tags; const int* tag_count; int tag_cap;     // this call's, any keys (may be null)
     const unsigned long long* nread;
     msk_ctag* ct; int* ct_n; int ct_cap;
+    int* ct_nc; // (may be null) carried tags kept, in front of the new ones; -1: one of the new tags was dropped
 };
 
 template <class Ctx>
@@ -1173,18 +1433,33 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
     if (nc > p.ctag_cap)
         nc = p.ctag_cap;
     scan(p.ctag_in + (long)c * p.ctag_cap, nc);
+    const int kept_carried = w;
+    bool newdrop = false;
     if (p.tags) {
         int nn = p.tag_count[c];
         if (nn > p.tag_cap) { // the producer (corr_est) ran out of room: the list is incomplete
             nn = p.tag_cap;
             trunc = true;
         }
+        const int w0 = w;
         scan(p.tags + (long)c * p.tag_cap, nn);
+        if (p.ct_nc) { // (how many of the new tags have the key: all of them must have been kept)
+            int nkey = 0;
+            const tag_rec* list = p.tags + (long)c * p.tag_cap;
+            for (int k0 = 0; k0 < nn; k0 += 64) {
+                const int k = k0 + l;
+                nkey += aisx_popc64(cx.ballot(k < nn && list[k].key == KEY_TIME_EST));
+            }
+            newdrop = (w - w0) != nkey;
+        }
     }
     if (w > p.ct_cap)
         trunc = true;
-    if (l == 0)
+    if (l == 0) {
         p.ct_n[c] = (w < p.ct_cap ? w : p.ct_cap) | (trunc ? MSK_CTN_TRUNC : 0) | (wild ? MSK_CTN_WILD : 0);
+        if (p.ct_nc)
+            p.ct_nc[c] = (newdrop || trunc) ? -1 : kept_carried;
+    }
 }
 
 // Bit tail (python/ais_demod.py:48-52, lib/invert_impl.cc:62-64): workgroup (seg, ch)

@@ -59,7 +59,6 @@ constexpr int MSKP_SLOTS = MSKP_R + 8;   // + 4 mirror rows: five rows from any 
 static_assert(MSKP_BS % 8 == 0 && (MSKP_NB - MSKP_D) * MSKP_BS >= 24, "readable window of the rings");
 constexpr int MSKP_TQ = 8;               // time_est tags staged in LDS per lane
 constexpr int MSKP_TPRE = 64;            // room in front of a channel's new-tag list for the carried tags
-constexpr int MSKP_SMAX = 64;            // restart points per channel at most
 constexpr int MSKP_PREP_LDS_TAGS = 2048; // tags of a channel the restart search looks at
 constexpr int MSKP_GATHER_X = 4;         // workgroups per channel of the gather kernel
 constexpr int MSKP_NCLS = 7;             // units are handed to the waves by length class: < 256 items, < 512, ... >= 8192
@@ -77,36 +76,6 @@ constexpr int MSKP_LDS_TQ = MSKP_TQ * 64 * 8;
 // units kernel: 16 symbols per lane staged for 64-byte stores, [group][slot pair][lane of the group] 16 bytes
 constexpr int MSKP_LDS_SYM = 16 * 64 * 8;
 constexpr int MSKP_LDS_BYTES = MSKP_LDS_RING + MSKP_LDS_TQ + MSK_LDS_MMSE + MSKP_LDS_SYM;
-
-enum { MSKP_KIND_NONE = 0, MSKP_KIND_NEXT = 1, MSKP_KIND_HANDOFF = 2 };
-
-// restart point k of a channel: tags jA and jA + 1 of the channel's list of new time_est tags
-struct mskp_rst {
-    int jA;
-    int relA, relB; // row offsets of the two tags
-    int q0, cap;    // the unit's slots in the channel's staging row
-    int pad[3];
-};
-// the loop at the top of an iteration, before the tag test (:138-140)
-struct mskp_snap {
-    int a;          // iidx, as a row offset
-    float mu, omega;
-    int div;
-    cf y;           // d_dly_conj_1 = d_dly_conj_2 (:194-195)
-    cf nl;          // d_dly_diff_1
-    int cur;        // index of the front tag in the new-tag list
-    int cnt;        // symbols emitted
-};
-// what a unit leaves behind
-struct mskp_res {
-    mskp_snap end;
-    cf ay, anl;     // the delay registers it assumed at its restart point
-    int kind;       // MSKP_KIND_*: ended where the next restart point's tag B is about to fire / somewhere else
-    int status;
-};
-struct mskp_piece {
-    int out0, src0, cnt; // symbols [out0, out0 + cnt) of the output row = staging row [src0, src0 + cnt)
-};
 
 struct MskpParams {
     int nchan;
@@ -150,6 +119,7 @@ struct MskpPrepParams {
     long stage_stride;
     int tail;
     int min_gap;    // restart points at least this many items apart
+    int max_span;   // no unit runs from a restart point more than this many items before the next (the join's serial loop is faster on a long stretch)
     int* ucount; int* ulist; long ucap; // units by length class (may be null)
 };
 
@@ -184,16 +154,6 @@ AISX_HD long mskp_stage_stride(int max_items, float d_sps, float gain, float lim
 }
 
 AISX_HD bool mskp_tame(float v) { return v >= -1.0f && v <= 1.0f; } // (false for NaN)
-AISX_HD bool mskp_same_bits(cf a, cf b)
-{
-    unsigned ar, ai, br, bi;
-    __builtin_memcpy(&ar, &a.re, 4);
-    __builtin_memcpy(&ai, &a.im, 4);
-    __builtin_memcpy(&br, &b.re, 4);
-    __builtin_memcpy(&bi, &b.im, 4);
-    return ar == br && ai == bi;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Prepass: one wave per channel.
 // ---------------------------------------------------------------------------------------------
@@ -311,8 +271,8 @@ AISX_DI void mskp_prep_body(Ctx& cx, const MskpPrepParams& p)
             if (q + cap > p.stage_stride)
                 break;
             rs[k].q0 = (int)q;
-            rs[k].cap = cap;
-            q += cap;
+            rs[k].cap = (end - rs[k].relB) > p.max_span ? 0 : cap;
+            q += rs[k].cap;
             Kfit = k + 1;
         }
         K = Kfit;
@@ -320,13 +280,27 @@ AISX_DI void mskp_prep_body(Ctx& cx, const MskpPrepParams& p)
     p.nrst[c] = K;
     if (p.ucount) {
         // a wave of the units kernel lives as long as its longest unit: units of a kind go together
-        for (int k = 0; k < K; k++) {
+        // (one atomic per class and channel, not per unit: 4096 channels hammer seven counters)
+        int ncls[MSKP_NCLS], bcls[MSKP_NCLS];
+        for (int i = 0; i < MSKP_NCLS; i++)
+            ncls[i] = 0;
+        auto cls_of = [&](int k) -> int {
             const int span = (k + 1 < K ? rs[k + 1].relB : lim) - rs[k].relB;
             int cls = 0;
             while (cls < MSKP_NCLS - 1 && span >= (256 << cls))
                 cls++;
-            const int idx = cx.atomic_add_i32(p.ucount + cls, 1);
-            p.ulist[(long)cls * p.ucap + idx] = (c << 6) | k;
+            return cls;
+        };
+        for (int k = 0; k < K; k++)
+            if (rs[k].cap != 0)
+                ncls[cls_of(k)]++;
+        for (int i = 0; i < MSKP_NCLS; i++)
+            bcls[i] = ncls[i] ? cx.atomic_add_i32(p.ucount + i, ncls[i]) : 0;
+        for (int k = 0; k < K; k++) {
+            if (rs[k].cap == 0)
+                continue;
+            const int cls = cls_of(k);
+            p.ulist[(long)cls * p.ucap + bcls[cls]++] = (c << 6) | k;
         }
     }
 }
@@ -680,6 +654,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         relB = me.relB;
         q0 = me.q0;
         cap = me.cap;
+        if (cap == 0)
+            running = false; // (left to the join)
         lim_a = n - p.tail;
         if (k + 1 < K)
             stop_j = rs[k + 1].jA + 1;

@@ -47,6 +47,7 @@ struct EmuShared {
 };
 
 struct EmuCtx {
+    static constexpr bool wave_lds_coherent = false; // (lanes are free-running threads: only a barrier orders their LDS accesses)
     EmuShared* sh;
     int tid_, bx_, by_;
     int tid() const { return tid_; }
@@ -389,6 +390,7 @@ struct EmuMsk {
     int cur = 0;
     // time-parallel path (k_mskp.h): restart points per channel at most (-1: the serial kernel)
     int tp_smax = -1, tp_min_gap = 256, max_noutput = 0;
+    int tp_join = 0; // 0: mskp_body<JOIN>, 1: the serial kernel with fast-forward (MskParams::ff)
     unsigned long long total_in = 0;
     long tp_stat[4] = { 0, 0, 0, 0 }; // restart points, units accepted, symbols taken from units, symbols in all
 };
@@ -420,12 +422,15 @@ void emu_msk_set_time_parallel(void* hv, int smax, int min_gap, int max_noutput)
     h->tp_min_gap = min_gap;
     h->max_noutput = max_noutput;
 }
+void emu_msk_set_tp_join(void* hv, int which) { ((EmuMsk*)hv)->tp_join = which; }
 void emu_msk_tp_stats(void* hv, long* out)
 {
     for (int i = 0; i < 4; i++)
         out[i] = ((EmuMsk*)hv)->tp_stat[i];
 }
 
+static void emu_msk_fill(EmuMsk* h, MskParams& p);
+static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc);
 // the time-parallel kernels on the lane model: prepass, units, join, gather
 static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const tag_rec* tags, const int* tag_counts,
                          int tag_cap, cf* syms, long out_stride, int* produced)
@@ -448,6 +453,7 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
     pp.ctl = ctl.data(); pp.ctl_n = ctl_n.data(); pp.ctl_cap = ctl_cap;
     pp.smax = smax; pp.nrst = nrst.data(); pp.rst = rst.data(); pp.stage_stride = stage_stride;
     pp.tail = mskp_tail(h->d_sps); pp.min_gap = h->tp_min_gap;
+    pp.max_span = getenv("AISX_MSK_TP_MAXSPAN") ? atoi(getenv("AISX_MSK_TP_MAXSPAN")) : 0x3fffffff;
     const bool sorted = !getenv("AISX_MSK_TP_UNSORTED");
     std::vector<int> ucount(8, 0), ulist((size_t)nc * MSKP_SMAX * MSKP_NCLS, 0);
     pp.ucount = sorted ? ucount.data() : nullptr; pp.ulist = ulist.data(); pp.ucap = (long)nc * MSKP_SMAX;
@@ -472,7 +478,20 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
     p.ucount = pp.ucount; p.ulist = pp.ulist; p.ucap = pp.ucap;
     if (smax > 0)
         run_grid((nc * smax + 63) / 64 + (sorted ? MSKP_NCLS : 0), 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, false>(cx, p); });
-    run_grid((nc + p.jw - 1) / p.jw, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
+    if (h->tp_join == 0) {
+        run_grid((nc + p.jw - 1) / p.jw, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
+    } else { // the serial kernel as the join (MskParams::ff)
+        std::vector<int> ct_nc(nc, 0);
+        emu_msk_tagprep(h, tags, tag_counts, tag_cap, ct_nc.data());
+        MskParams m;
+        emu_msk_fill(h, m);
+        m.in = in; m.in_stride = in_stride; m.n = n; m.stream_mode = 1; m.gr_ninput = 0; m.gr_noutput = 0;
+        m.syms = syms; m.err = nullptr; m.mu_out = nullptr; m.out_stride = out_stride; m.out_cap = (int)out_stride;
+        m.sym_al16 = 0; m.produced = produced; m.inline_tags = 0;
+        m.ff = 1; m.nrst = nrst.data(); m.rst = rst.data(); m.res = res.data(); m.pieces = pieces.data(); m.npieces = npieces.data();
+        m.ct_nc = ct_nc.data();
+        emu_msk(&m);
+    }
     MskpGatherParams g;
     g.nchan = nc; g.pieces = pieces.data(); g.npieces = npieces.data(); g.stage = stage.data(); g.stage_stride = stage_stride;
     g.syms = syms; g.out_stride = out_stride;
@@ -507,10 +526,11 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.tq_private = 1;
     p.inline_tags = getenv("AISX_MSK_INLINE_TAGS") ? atoi(getenv("AISX_MSK_INLINE_TAGS")) : 1;
     p.max_noutput = h->max_noutput;
+    p.ff = 0; p.nrst = nullptr; p.rst = nullptr; p.res = nullptr; p.pieces = nullptr; p.npieces = nullptr; p.ct_nc = nullptr;
     p.lds_tab_off = p.lds_ring_off + msk_waves(h->lpw) * p.lds_wave_stride;
 }
 
-static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap)
+static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc)
 {
     h->ct_cap = EmuMsk::ctag_cap + (tags ? tag_cap : 0);
     h->ct.assign((size_t)h->nchan * h->ct_cap, msk_ctag{ 0, 0.f });
@@ -520,7 +540,7 @@ static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_count
     t.ctag_in = h->ctag[h->cur].data(); t.ctag_n_in = h->ctag_n[h->cur].data(); t.ctag_cap = EmuMsk::ctag_cap;
     t.tags = tags; t.tag_count = tag_counts; t.tag_cap = tag_cap;
     t.nread = h->nread.data();
-    t.ct = h->ct.data(); t.ct_n = h->ct_n.data(); t.ct_cap = h->ct_cap;
+    t.ct = h->ct.data(); t.ct_n = h->ct_n.data(); t.ct_cap = h->ct_cap; t.ct_nc = ct_nc;
     run_grid((h->nchan + 3) / 4, 1, 256, 64, [&](EmuCtx& cx) { tagprep_body(cx, t); });
 }
 
@@ -549,7 +569,7 @@ int emu_msk_process_stream(void* hv, const cf* in, long in_stride, int n, const 
     if (h->tp_smax >= 0 && h->osps == 1 && !err && !mu) {
         emu_mskp_run(h, in, in_stride, n, tags, tag_counts, tag_cap, syms, out_stride, produced);
     } else {
-        emu_msk_tagprep(h, tags, tag_counts, tag_cap);
+        emu_msk_tagprep(h, tags, tag_counts, tag_cap, nullptr);
         MskParams p;
         emu_msk_fill(h, p);
         p.in = in; p.in_stride = in_stride; p.n = n; p.stream_mode = 1; p.gr_ninput = 0; p.gr_noutput = 0;
@@ -579,7 +599,7 @@ int emu_msk_general_work(void* hv, int noutput, int ninput, const cf* in /* in[n
     h->nread[0] = nitems_read;
     h->carry_len[h->cur][0] = 0;
     h->ctag_n[h->cur][0] = 0;
-    emu_msk_tagprep(h, tags, &ntags, ntags + 1);
+    emu_msk_tagprep(h, tags, &ntags, ntags + 1, nullptr);
     MskParams p;
     emu_msk_fill(h, p);
     p.in = in; p.in_stride = ninput + 1; p.n = ninput; p.stream_mode = 0; p.gr_ninput = ninput; p.gr_noutput = noutput;

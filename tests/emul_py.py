@@ -42,6 +42,7 @@ def lib():
         L.emu_msk_set_lpw.argtypes = [vp, i32]
         L.emu_msk_set_time_parallel.argtypes = [vp, i32, i32, i32]
         L.emu_msk_tp_stats.argtypes = [vp, vp]
+        L.emu_msk_set_tp_join.argtypes = [vp, i32]
         L.emu_msk_process_stream.restype = i32
         L.emu_msk_process_stream.argtypes = [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp]
         L.emu_msk_general_work.restype = i32
@@ -104,12 +105,13 @@ class CorrEst:
 
 
 class MskStream:
-    def __init__(self, sps, gain, limit, osps=1, nchan=1, lpw=64, tp_smax=-1, tp_min_gap=256, max_noutput=0):
+    def __init__(self, sps, gain, limit, osps=1, nchan=1, lpw=64, tp_smax=-1, tp_min_gap=256, max_noutput=0, tp_join=0):
         self.h = lib().emu_msk_create(sps, gain, limit, osps, nchan)
         self.nchan = nchan
         lib().emu_msk_set_lpw(self.h, lpw)  # channels per wave: 16, 32 or 64
         # tp_smax >= 0: the time-parallel kernels (k_mskp.h) with that many restart points per channel at most
         lib().emu_msk_set_time_parallel(self.h, tp_smax, tp_min_gap, max_noutput)
+        lib().emu_msk_set_tp_join(self.h, tp_join)  # 0: the lane-per-channel join of k_mskp.h, 1: the serial kernel with fast-forward
 
     def tp_stats(self):
         a = np.zeros(4, np.int64)
