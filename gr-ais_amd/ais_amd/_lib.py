@@ -92,9 +92,11 @@ def lib():
     sig("aisx_msk_out_capacity", i32, [vp])
     sig("aisx_msk_reset", i32, [vp])
     sig("aisx_msk_process_stream", i32, [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp])
+    sig("aisx_msk_process_stream_after", i32, [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp, vp])
     sig("aisx_msk_last_status", i32, [vp, pi32, vp])
     sig("aisx_msk_restart_stats", i32, [vp, vp, vp])
     sig("aisx_msk_set_max_noutput_items", i32, [vp, i32])
+    sig("aisx_msk_set_time_parallel", i32, [vp, i32, i32, i32])
     sig("aisx_msk_get_max_noutput_items", i32, [vp])
     sig("aisx_msk_set_tail_stream", i32, [vp, vp, i32])
     sig("aisx_msk_wait_tail", i32, [vp, vp])

@@ -267,6 +267,11 @@ class msk_timing_recovery_cc:
         check(_lib.lib().aisx_msk_last_status(self._h, C.byref(st), _stream_ptr(stream)), "last_status")
         return st.value
 
+    def set_time_parallel(self, restart_points=64, join_kernel=-1, max_unit_items=0):
+        """The time-parallel recovery (include/aisx.h: aisx_msk_set_time_parallel); restart_points=0 switches it off."""
+        check(_lib.lib().aisx_msk_set_time_parallel(self._h, int(restart_points), int(join_kernel), int(max_unit_items)),
+              "set_time_parallel")
+
     def set_max_noutput_items(self, m):
         """gr::block::set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)."""
         check(_lib.lib().aisx_msk_set_max_noutput_items(self._h, int(m)), "set_max_noutput_items")

@@ -206,8 +206,11 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
         if (sk != sm)
             AISX_HIPCHK(hipStreamWaitEvent(sk, h->ev_ready[par], 0));
-        if ((rc = aisx_msk_process_stream(h->msk, (const aisx_cf32*)h->d_yc[par], h->yc_stride, m, tags, counts, tcap, d_syms, nullptr,
-                                          nullptr, d_bits, out_stride, d_produced, sk)) != AISX_OK)
+        // (ev_ready: what the time-parallel recovery's units wait for on their own stream -- they need this
+        // step's samples and tags, not the previous step's recovery, and run beside it)
+        if ((rc = aisx_msk_process_stream_after(h->msk, (const aisx_cf32*)h->d_yc[par], h->yc_stride, m, tags, counts, tcap, d_syms,
+                                                nullptr, nullptr, d_bits, out_stride, d_produced, sk,
+                                                h->serial ? nullptr : (void*)h->ev_ready[par])) != AISX_OK)
             return rc;
         AISX_HIPCHK(hipEventRecord(h->ev_msk_done[par], sk));
         // the bit tail (if any) was queued on s_tail behind the recovery

@@ -152,12 +152,17 @@ struct aisx_msk {
     int *d_produced = nullptr, *d_consumed = nullptr, *d_status = nullptr;
     float *d_mmse = nullptr, *d_atan = nullptr;
     // time-parallel path (k_mskp.h)
-    int tp_smax = MSKP_SMAX; // restart points per channel at most (0: the serial kernel)
+    int tp_smax = 0;       // the time-parallel recovery (k_mskp.h): restart points per channel at most; 0 = off, the serial kernel alone
     int tp_min_gap = 64;   // items between restart points at least
     int tp_jw = 16;        // channels per wave of the join kernel
     int tp_join = 1;       // the join: 1 = the serial kernel with fast-forward (k_msk.h, MskParams::ff), 0 = k_mskp_join
     int tp_max_span = 4096; // no unit from a restart point further than this from the next one (tp_join = 1: the serial kernel is faster there)
     int* d_ct_nc = nullptr;
+    // the units run on a stream of their own, one call ahead of the join (which needs the previous call's
+    // state): everything the prepass and the units leave for the join exists twice, by the call's parity
+    hipStream_t s_units = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_units[2] = { nullptr, nullptr }, ev_join[2] = { nullptr, nullptr };
+    bool ev_join_set[2] = { false, false };
     int max_noutput = 0;   // set_max_noutput_items(): output items one general_work call is offered at most (0: what fits)
     unsigned long long total_in = 0; // items handed to the block so far = absolute offset of the next row's item 0
     msk_ctag* d_ctl = nullptr;
@@ -277,6 +282,8 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         h->lpw = 8;
         if (const char* e = getenv("AISX_MSK_INLINE_TAGS"))
             h->inline_tags = atoi(e) != 0;
+        if (const char* e = getenv("AISX_MSK_TIME_PARALLEL")) // (experiments; the API is aisx_msk_set_time_parallel)
+            h->tp_smax = atoi(e) != 0 ? MSKP_SMAX : 0;
         if (const char* e = getenv("AISX_MSK_TP_SMAX")) // restart points per channel (0: the serial kernel)
             h->tp_smax = std::max(0, std::min(atoi(e), (int)MSKP_SMAX));
         if (const char* e = getenv("AISX_MSK_TP_GAP"))
@@ -380,6 +387,18 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     dev_free(h->d_ucount);
     dev_free(h->d_ulist);
     dev_free(h->d_ct_nc);
+    if (h->s_units) {
+        (void)hipStreamSynchronize(h->s_units);
+        (void)hipStreamDestroy(h->s_units);
+    }
+    if (h->ev_entry)
+        (void)hipEventDestroy(h->ev_entry);
+    for (int k = 0; k < 2; k++) {
+        if (h->ev_units[k])
+            (void)hipEventDestroy(h->ev_units[k]);
+        if (h->ev_join[k])
+            (void)hipEventDestroy(h->ev_join[k]);
+    }
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_stage[k]);
         dev_free(h->d_pieces[k]);
@@ -462,6 +481,17 @@ extern "C" int aisx_msk_set_max_noutput_items(aisx_msk* h, int max_noutput_items
     if (!h || max_noutput_items < 0)
         return AISX_ERR_INVALID;
     h->max_noutput = max_noutput_items;
+    return AISX_OK;
+}
+extern "C" int aisx_msk_set_time_parallel(aisx_msk* h, int restart_points_per_channel, int join_kernel, int max_unit_items)
+{
+    if (!h || restart_points_per_channel < 0)
+        return AISX_ERR_INVALID;
+    h->tp_smax = std::min(restart_points_per_channel, (int)MSKP_SMAX);
+    if (join_kernel >= 0)
+        h->tp_join = join_kernel != 0;
+    if (max_unit_items > 0)
+        h->tp_max_span = std::max(64, max_unit_items);
     return AISX_OK;
 }
 extern "C" int aisx_msk_get_max_noutput_items(const aisx_msk* h) { return h ? h->max_noutput : AISX_ERR_INVALID; }
@@ -554,6 +584,11 @@ static int msk_launch_tagprep(aisx_msk* h, const tag_rec* d_tags, const int* d_t
     t.ct_n = h->d_ct_n;
     t.ct_cap = h->ct_cap;
     t.ct_nc = d_ct_nc;
+    t.ctl_new = nullptr;
+    t.ctl_new_n = nullptr;
+    t.ctl_new_cap = 0;
+    t.ctl_new_pre = 0;
+    t.W = 0;
     hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 3) / 4), dim3(256), 0, st, t); // a wave per channel
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
@@ -598,10 +633,12 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
     bool fresh = false;
     if (need > h->ctl_cap || !h->d_ctl) {
         AISX_HIPCHK(hipStreamSynchronize(st));
+        if (h->s_units)
+            AISX_HIPCHK(hipStreamSynchronize(h->s_units));
         dev_free(h->d_ctl);
         h->d_ctl = nullptr;
         h->ctl_cap = 0;
-        if ((rc = dev_alloc(&h->d_ctl, (size_t)h->nchan * (size_t)need)) != AISX_OK)
+        if ((rc = dev_alloc(&h->d_ctl, 2 * (size_t)h->nchan * (size_t)need)) != AISX_OK)
             return rc;
         h->ctl_cap = need;
         fresh = true;
@@ -609,10 +646,17 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
     if (!h->d_rst) {
         const size_t nc = (size_t)h->nchan;
         h->stage_stride = mskp_stage_stride(h->max_items + aisx_msk::carry_cap, h->d_sps, h->gain, h->limit);
-        if ((rc = dev_alloc(&h->d_ctl_n, nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, nc)) != AISX_OK ||
-            (rc = dev_alloc(&h->d_rst, nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, nc * MSKP_SMAX)) != AISX_OK ||
-            (rc = dev_alloc(&h->d_ucount, 8)) != AISX_OK || (rc = dev_alloc(&h->d_ct_nc, nc)) != AISX_OK || (rc = dev_alloc(&h->d_ulist, nc * MSKP_SMAX * MSKP_NCLS)) != AISX_OK)
+        if ((rc = dev_alloc(&h->d_ctl_n, 2 * nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, 2 * nc)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_rst, 2 * nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_res, 2 * nc * MSKP_SMAX)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_ucount, 16)) != AISX_OK || (rc = dev_alloc(&h->d_ct_nc, nc)) != AISX_OK ||
+            (rc = dev_alloc(&h->d_ulist, 2 * nc * MSKP_SMAX * MSKP_NCLS)) != AISX_OK)
             return rc;
+        AISX_HIPCHK(hipStreamCreateWithFlags(&h->s_units, hipStreamNonBlocking));
+        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_entry, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) {
+            AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_units[k], hipEventDisableTiming));
+            AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+        }
         for (int k = 0; k < 2; k++)
             if ((rc = dev_alloc(&h->d_stage[k], nc * (size_t)h->stage_stride)) != AISX_OK ||
                 (rc = dev_alloc(&h->d_pieces[k], nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_npieces[k], nc)) != AISX_OK)
@@ -624,10 +668,9 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
     return AISX_OK;
 }
 
-extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
-                                       const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
-                                       float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
-                                       void* stream)
+static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_tag* d_tags,
+                              const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms, float* d_err, float* d_mu, uint8_t* d_bits,
+                              long out_stride, int* d_produced, void* stream, void* ready_event)
 {
     if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n || (d_tags && (!d_tag_counts || tag_cap < 1))) {
         set_err("aisx_msk_process_stream: bad argument");
@@ -643,11 +686,45 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
     }
     hipStream_t st = (hipStream_t)stream;
     const bool tp = msk_tp_applies(h, d_err, d_mu);
+    const int par = h->callpar;
+    h->callpar ^= 1;
     int rc, t_smax = 0;
     bool tp_sorted = false;
+    const size_t nc = (size_t)h->nchan;
+    // this call's copies of what the prepass and the units leave for the join
+    msk_ctag* ctl = nullptr;
+    int *ctl_n = nullptr, *nrst = nullptr, *ucount = nullptr, *ulist = nullptr;
+    mskp_rst* rst = nullptr;
+    mskp_res* res = nullptr;
+    hipStream_t su = st; // where the prepass and the units run
     if (tp) {
         if ((rc = msk_tp_buffers(h, d_tags ? tag_cap : 0, st)) != AISX_OK)
             return rc;
+        ctl = h->d_ctl + (size_t)par * nc * (size_t)h->ctl_cap;
+        ctl_n = h->d_ctl_n + par * nc;
+        nrst = h->d_nrst + par * nc;
+        rst = h->d_rst + par * nc * MSKP_SMAX;
+        res = h->d_res + par * nc * MSKP_SMAX;
+        ucount = h->d_ucount + par * 8;
+        ulist = h->d_ulist + par * nc * MSKP_SMAX * MSKP_NCLS;
+        // The units need the samples and the tags of this call, nothing of the call before: they run
+        // on their own stream, beside the join of the previous call.  They start when the caller says
+        // the inputs are there (ready_event; without one: when `stream` gets here), when the join of
+        // two calls ago has let go of this parity's records and the bit tail of its staging rows.
+        if (!getenv("AISX_MSK_TP_ONE_STREAM"))
+            su = h->s_units;
+        if (su != st) {
+            if (ready_event) {
+                AISX_HIPCHK(hipStreamWaitEvent(su, (hipEvent_t)ready_event, 0));
+            } else {
+                AISX_HIPCHK(hipEventRecord(h->ev_entry, st));
+                AISX_HIPCHK(hipStreamWaitEvent(su, h->ev_entry, 0));
+            }
+            if (h->ev_join_set[par])
+                AISX_HIPCHK(hipStreamWaitEvent(su, h->ev_join[par], 0));
+        }
+        if (h->tail_on && h->ev_tail_set[par])
+            AISX_HIPCHK(hipStreamWaitEvent(su, h->ev_tail[par], 0));
         MskpPrepParams t;
         t.nchan = h->nchan;
         t.tags = (const tag_rec*)d_tags;
@@ -658,41 +735,36 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         t.d_sps = h->d_sps;
         t.gain = h->gain;
         t.limit = h->limit;
-        t.ctl = h->d_ctl;
-        t.ctl_n = h->d_ctl_n;
+        t.ctl = ctl;
+        t.ctl_n = ctl_n;
         t.ctl_cap = h->ctl_cap;
         // (units run blind to the general_work calls: with a max_noutput_items the call boundaries must
         // leave an un-blocked loop alone, which needs d_sps >= 2 -- see mskp_body's walk)
         t.smax = (h->max_noutput > 0 && h->d_sps < 2.0f) ? 0 : h->tp_smax;
         t_smax = t.smax;
-        t.nrst = h->d_nrst;
-        t.rst = h->d_rst;
+        t.nrst = nrst;
+        t.rst = rst;
         t.stage_stride = h->stage_stride;
         t.tail = mskp_tail(h->d_sps);
         t.min_gap = h->tp_min_gap;
         t.max_span = h->tp_join ? h->tp_max_span : 0x3fffffff;
         // units sorted by length need every row within 4 GiB of the first (32-bit buffer offsets)
-        const bool sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !getenv("AISX_MSK_TP_UNSORTED");
-        t.ucount = sorted ? h->d_ucount : nullptr;
-        t.ulist = h->d_ulist;
+        tp_sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !getenv("AISX_MSK_TP_UNSORTED");
+        t.ucount = tp_sorted ? ucount : nullptr;
+        t.ulist = ulist;
         t.ucap = (long)h->nchan * MSKP_SMAX;
-        if (sorted)
-            AISX_HIPCHK(hipMemsetAsync(h->d_ucount, 0, sizeof(int) * 8, st));
-        tp_sorted = sorted;
-        hipLaunchKernelGGL(k_mskp_prep, dim3(h->nchan), dim3(64), 0, st, t);
+        if (tp_sorted)
+            AISX_HIPCHK(hipMemsetAsync(ucount, 0, sizeof(int) * 8, su));
+        hipLaunchKernelGGL(k_mskp_prep, dim3(h->nchan), dim3(64), 0, su, t);
         AISX_HIPCHK(hipGetLastError());
-        if (h->tp_join && (rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st, h->d_ct_nc)) != AISX_OK)
-            return rc;
     } else if ((rc = msk_launch_tagprep(h, (const tag_rec*)d_tags, d_tag_counts, tag_cap, st)) != AISX_OK) {
         return rc;
     }
-    if (h->ev_prep) {
-        AISX_HIPCHK(hipEventRecord(h->ev_prep, st));
+    if (h->ev_prep) { // (the caller's tag records have been read)
+        AISX_HIPCHK(hipEventRecord(h->ev_prep, su));
         h->ev_prep_set = true;
     }
     cf* syms = (cf*)d_syms;
-    const int par = h->callpar;
-    h->callpar ^= 1;
     if (h->tail_on && h->ev_tail_set[par]) // the bit tail of two calls ago may still read this parity's buffers
         AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_tail[par], 0));
     if (!syms) { // the kernel always writes symbols (the bit tail reads them back): give them a home
@@ -738,13 +810,13 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         p.ctag_out = h->d_ctag[h->cur ^ 1];
         p.ctag_n_out = h->d_ctag_n[h->cur ^ 1];
         p.ctag_cap = aisx_msk::ctag_cap;
-        p.ctl = h->d_ctl;
-        p.ctl_n = h->d_ctl_n;
+        p.ctl = ctl;
+        p.ctl_n = ctl_n;
         p.ctl_cap = h->ctl_cap;
         p.smax = h->tp_smax;
-        p.nrst = h->d_nrst;
-        p.rst = h->d_rst;
-        p.res = h->d_res;
+        p.nrst = nrst;
+        p.rst = rst;
+        p.res = res;
         p.stage = h->d_stage[par];
         p.stage_stride = h->stage_stride;
         p.syms = syms;
@@ -761,8 +833,8 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         p.padv = mskp_padv(h->d_sps, h->gain, h->limit);
         p.padv_inv = mskp_padv_inv(h->d_sps, h->gain, h->limit);
         p.jw = h->tp_jw;
-        p.ucount = tp_sorted ? h->d_ucount : nullptr;
-        p.ulist = h->d_ulist;
+        p.ucount = tp_sorted ? ucount : nullptr;
+        p.ulist = ulist;
         p.ucap = (long)h->nchan * MSKP_SMAX;
         p.tail = mskp_tail(h->d_sps);
         p.max_noutput = h->max_noutput;
@@ -774,11 +846,47 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         }
         if (t_smax > 0) {
             const long units = (long)h->nchan * h->tp_smax;
-            hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64 + (tp_sorted ? MSKP_NCLS : 0))), dim3(64), MSKP_LDS_BYTES, st, p);
+            hipLaunchKernelGGL(k_mskp_units, dim3((unsigned)((units + 63) / 64 + (tp_sorted ? MSKP_NCLS : 0))), dim3(64), MSKP_LDS_BYTES, su, p);
             AISX_HIPCHK(hipGetLastError());
         }
+        if (su != st) { // the join, on the caller's stream, behind the units
+            AISX_HIPCHK(hipEventRecord(h->ev_units[par], su));
+            AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_units[par], 0));
+        }
         if (h->tp_join) {
-            // the serial kernel as the join: the loop from the carried state, fast-forwarded through the units
+            // the serial kernel as the join: the loop from the carried state, fast-forwarded through the units;
+            // its tag list = the tags the scheduler still held + this call's, as the prepass compacted them
+            const int need = aisx_msk::ctag_cap + (h->ctl_cap - MSKP_TPRE);
+            if (need > h->ct_cap || !h->d_ct) {
+                AISX_HIPCHK(hipStreamSynchronize(st));
+                dev_free(h->d_ct);
+                h->d_ct = nullptr;
+                h->ct_cap = 0;
+                if ((rc = dev_alloc(&h->d_ct, nc * (size_t)need)) != AISX_OK)
+                    return rc;
+                h->ct_cap = need;
+                AISX_HIPCHK(hipDeviceSynchronize());
+            }
+            TagPrepParams tg;
+            tg.nchan = h->nchan;
+            tg.ctag_in = h->d_ctag[h->cur];
+            tg.ctag_n_in = h->d_ctag_n[h->cur];
+            tg.ctag_cap = aisx_msk::ctag_cap;
+            tg.tags = nullptr;
+            tg.tag_count = nullptr;
+            tg.tag_cap = 0;
+            tg.nread = h->d_nread;
+            tg.ct = h->d_ct;
+            tg.ct_n = h->d_ct_n;
+            tg.ct_cap = h->ct_cap;
+            tg.ct_nc = h->d_ct_nc;
+            tg.ctl_new = ctl;
+            tg.ctl_new_n = ctl_n;
+            tg.ctl_new_cap = h->ctl_cap;
+            tg.ctl_new_pre = MSKP_TPRE;
+            tg.W = h->total_in;
+            hipLaunchKernelGGL(k_msk_tagprep, dim3((h->nchan + 3) / 4), dim3(256), 0, st, tg);
+            AISX_HIPCHK(hipGetLastError());
             MskParams m;
             msk_fill_common(h, m);
             m.in = (const cf*)d_in;
@@ -796,9 +904,9 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
             m.produced = produced;
             m.inline_tags = 0; // (every tag reset through the general step, where the junctions are looked at)
             m.ff = 1;
-            m.nrst = h->d_nrst;
-            m.rst = h->d_rst;
-            m.res = h->d_res;
+            m.nrst = nrst;
+            m.rst = rst;
+            m.res = res;
             m.pieces = h->d_pieces[par];
             m.npieces = h->d_npieces[par];
             m.ct_nc = h->d_ct_nc;
@@ -807,6 +915,10 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         } else {
             hipLaunchKernelGGL(k_mskp_join, dim3((h->nchan + h->tp_jw - 1) / h->tp_jw), dim3(64), MSKP_LDS_BYTES, st, p);
             AISX_HIPCHK(hipGetLastError());
+        }
+        if (su != st) {
+            AISX_HIPCHK(hipEventRecord(h->ev_join[par], st));
+            h->ev_join_set[par] = true;
         }
         h->tp_calls++;
     } else {
@@ -866,6 +978,24 @@ extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long 
         }
     }
     return AISX_OK;
+}
+
+extern "C" int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
+                                       const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
+                                       float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
+                                       void* stream)
+{
+    return msk_process_stream(h, d_in, in_stride, n, d_tags, d_tag_counts, tag_cap, d_syms, d_err, d_mu, d_bits, out_stride, d_produced,
+                              stream, nullptr);
+}
+
+extern "C" int aisx_msk_process_stream_after(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n,
+                                             const aisx_tag* d_tags, const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms,
+                                             float* d_err, float* d_mu, uint8_t* d_bits, long out_stride, int* d_produced,
+                                             void* stream, void* ready_event)
+{
+    return msk_process_stream(h, d_in, in_stride, n, d_tags, d_tag_counts, tag_cap, d_syms, d_err, d_mu, d_bits, out_stride, d_produced,
+                              stream, ready_event);
 }
 
 extern "C" int aisx_msk_set_tail_stream(aisx_msk* h, void* tail_stream, int enable)
@@ -941,11 +1071,11 @@ extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream
     std::vector<mskp_res> rs(nc * MSKP_SMAX);
     std::vector<mskp_rst> rp(nc * MSKP_SMAX);
     AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    AISX_HIPCHK(hipMemcpy(nrst.data(), h->d_nrst, sizeof(int) * nc, hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(nrst.data(), h->d_nrst + par * nc, sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(np.data(), h->d_npieces[par], sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(pc.data(), h->d_pieces[par], sizeof(mskp_piece) * pc.size(), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(rs.data(), h->d_res, sizeof(mskp_res) * rs.size(), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(rp.data(), h->d_rst, sizeof(mskp_rst) * rp.size(), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(rs.data(), h->d_res + par * nc * MSKP_SMAX, sizeof(mskp_res) * rs.size(), hipMemcpyDeviceToHost));
+    AISX_HIPCHK(hipMemcpy(rp.data(), h->d_rst + par * nc * MSKP_SMAX, sizeof(mskp_rst) * rp.size(), hipMemcpyDeviceToHost));
     for (size_t c = 0; c < nc; c++) {
         out6[0] += nrst[c];                     // restart points chosen
         out6[1] += np[c];                       // units whose run was taken over

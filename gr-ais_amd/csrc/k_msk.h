@@ -538,6 +538,8 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     auto ff_walk = [&]() -> bool {
         bool moved = false;
         int dcnt = 0, a_new = 0, cur_new = 0;
+        int oidx_w = oidx, nout_w = noutput, otot_w = ototal; // the general_work call in progress, as the walk goes
+        bool crossed = false;
         cf yv = last_interp, nlv = d_dly_diff_1;
         float mu_new = 0.f, om_new = 0.f;
         int div_new = 0;
@@ -547,11 +549,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             const bool same = r.kind != MSKP_KIND_NONE && mskp_same_bits(r.ay, yv) && mskp_same_bits(r.anl, nlv);
             // (the unit ran blind to the general_work calls: k_mskp.h, mskp_body's walk, says when that is sound)
             bool clean = same && (r.end.a + 1 + cd <= base + ninp - pending) && ffnp < MSKP_SMAX;
-            if (p.max_noutput > 0)
+            // (a unit that gave up -- at a stale tag, say -- with a call boundary inside: whether that tag
+            // was dropped at the boundary or still blocks depends on where exactly the boundary fell)
+            if (p.max_noutput > 0 && r.kind == MSKP_KIND_NEXT)
                 clean = clean && msk_forecast(d_sps, p.max_noutput) <= (n - r.end.a) - 1 &&
                         (ototal + oidx + dcnt + r.end.cnt + p.max_noutput <= p.out_cap);
             else
-                clean = clean && (oidx + dcnt + r.end.cnt < noutput);
+                clean = clean && (oidx_w + r.end.cnt < nout_w);
             if (!clean) {
                 cand++;
                 candj = cand < ffK ? ffrs[cand].jA + 1 + ffnck : 0x7fffffff;
@@ -567,6 +571,13 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
             ffnp++;
             moved = true;
             dcnt += r.end.cnt;
+            oidx_w += r.end.cnt;
+            while (p.max_noutput > 0 && oidx_w >= nout_w) { // calls that began and ended inside the unit
+                oidx_w -= nout_w;
+                otot_w += nout_w;
+                nout_w = p.max_noutput;
+                crossed = true;
+            }
             a_new = r.end.a;
             mu_new = r.end.mu;
             om_new = r.end.omega;
@@ -606,26 +617,20 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
         qn = 0;
         qhead = 0;
         tq_fill();
-        // general_work calls that began and ended inside the units (only with max_noutput_items)
-        int rem = oidx + dcnt;
-        bool crossed = false;
-        int nout_cur = noutput;
-        while (p.max_noutput > 0 && rem >= nout_cur) {
-            rem -= nout_cur;
-            ototal += nout_cur;
-            nout_cur = p.max_noutput;
-            crossed = true;
-        }
         const int q_new = a_new + pending; // logical index of in[iidx]
+        tq_front();
         if (crossed) {
-            base = q_new; // (somewhere at or before: nothing reads it before the next call starts)
-            setup_round();
+            // The call in progress began somewhere inside the units, at or before a_new and -- units stop at
+            // the first stale tag -- at or before the front tag: nothing reads nitems_read before the call ends
+            // except the tag range's lower end (:127), so any such place will do.
+            ototal = otot_w;
+            base = (fr_rel != TQ_NONE && fr_rel < q_new) ? fr_rel : q_new;
+            setup_round(); // (noutput, ninp, the front tag)
         } else {
-            iidx = q_new - base;
-            tq_front();
             nt_rel = (fr_rel != TQ_NONE && fr_rel - base < ninp) ? fr_rel - base : 0x7fffffff;
         }
-        oidx = rem;
+        iidx = q_new - base;
+        oidx = oidx_w;
         // The ring carries on at the unit's end: the slots of the chunk landed last are filled from there
         // right away (every lane of the channel writes the same 64 values: no exchange to wait for), the
         // chunk in flight is fetched again for this lane, and the lane goes on as if nothing had happened.
@@ -1388,6 +1393,8 @@ struct TagPrepParams {
     const unsigned long long* nread;
     msk_ctag* ct; int* ct_n; int ct_cap;
     int* ct_nc; // (may be null) carried tags kept, in front of the new ones; -1: one of the new tags was dropped
+    // (may be null) this call's time_est tags as k_mskp.h's prepass left them (row offsets): taken instead of `tags`
+    const msk_ctag* ctl_new; const int* ctl_new_n; int ctl_new_cap; int ctl_new_pre; unsigned long long W;
 };
 
 template <class Ctx>
@@ -1435,7 +1442,37 @@ AISX_DI void tagprep_body(Ctx& cx, const TagPrepParams& p)
     scan(p.ctag_in + (long)c * p.ctag_cap, nc);
     const int kept_carried = w;
     bool newdrop = false;
-    if (p.tags) {
+    if (p.ctl_new) {
+        int nn = p.ctl_new_n[c];
+        if (nn & MSK_CTN_TRUNC)
+            trunc = true;
+        if (nn & MSK_CTN_WILD)
+            wild = true;
+        nn &= MSK_CTN_WILD - 1;
+        const msk_ctag* list = p.ctl_new + (long)c * p.ctl_new_cap + p.ctl_new_pre;
+        const long long shift = (long long)(p.W - R); // row item 0 relative to nitems_read
+        for (int k0 = 0; k0 < nn; k0 += 64) {
+            const int k = k0 + l;
+            msk_ctag e;
+            e.rel = 0;
+            e.val = 0.f;
+            if (k < nn)
+                e = list[k];
+            const long long d = shift + (long long)e.rel;
+            const bool keep = (k < nn) && d >= 0; // (offset >= nitems_read)
+            if (cx.ballot((k < nn) && !keep) != 0ull)
+                newdrop = true;
+            const unsigned long long m = cx.ballot(keep);
+            const int pos = w + aisx_popc64(m & ((1ull << l) - 1ull));
+            if (keep && pos < p.ct_cap) {
+                msk_ctag o;
+                o.rel = d > 0x7ffffff0ll ? 0x7ffffff0 : (int)d;
+                o.val = e.val;
+                out[pos] = o;
+            }
+            w += aisx_popc64(m);
+        }
+    } else if (p.tags) {
         int nn = p.tag_count[c];
         if (nn > p.tag_cap) { // the producer (corr_est) ran out of room: the list is incomplete
             nn = p.tag_cap;

@@ -1060,7 +1060,9 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
             //    reset the loop lies behind iidx one iteration later when d_sps >= 2; a stale tag would
             //    be dropped, but a unit stops at a stale tag).
             bool clean = same && (r.end.a + 1 + cd <= ninp_row) && np < MSKP_SMAX;
-            if (p.max_noutput > 0)
+            // (a unit that gave up -- at a stale tag, say -- with a call boundary inside: whether that tag was
+            // dropped at the boundary or still blocks depends on where exactly the boundary fell: run serially)
+            if (p.max_noutput > 0 && r.kind == MSKP_KIND_NEXT)
                 clean = clean && msk_forecast(d_sps, p.max_noutput) <= (n - r.end.a) - 1 &&
                         (cnt + r.end.cnt + p.max_noutput <= p.out_cap);
             else

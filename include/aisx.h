@@ -173,6 +173,14 @@ int aisx_msk_reset(aisx_msk* h);
 int aisx_msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_tag* d_tags,
                             const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms, float* d_err, float* d_mu,
                             uint8_t* d_bits, long out_stride, int* d_produced, void* stream);
+/* The same call for a pipelined caller.  With the time-parallel recovery (k_mskp.h; osps 1, err / mu
+ * ports open) the units of a call need its samples and tags but nothing of the call before: they run
+ * on a stream of the handle's own, beside the previous call's join on `stream`.  `ready_event` (a
+ * hipEvent_t, may be null) is what that stream waits for before it reads d_in / d_tags; without it it
+ * waits for `stream` to reach this call, and nothing overlaps.  Results are identical. */
+int aisx_msk_process_stream_after(aisx_msk* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_tag* d_tags,
+                                  const int* d_tag_counts, int tag_cap, aisx_cf32* d_syms, float* d_err, float* d_mu,
+                                  uint8_t* d_bits, long out_stride, int* d_produced, void* stream, void* ready_event);
 /* status word per channel of the last call, or-ed over channels (0 = clean):
  * 1 interpolator index out of range (upstream throws), 2 carry buffer overflow,
  * 4 carried-tag buffer overflow, 8 output rows full (results truncated),
@@ -191,6 +199,17 @@ enum {
  * a stale time_est tag blocks the later ones until the call ends (reference :140-142), so the value
  * bounds how long.  Takes effect with the next aisx_msk_process_stream. */
 int aisx_msk_set_max_noutput_items(aisx_msk* h, int max_noutput_items);
+/* The time-parallel recovery (gr-ais_amd/csrc/k_mskp.h), off by default.  The reference loop (:138-202) is a
+ * recurrence, but two time_est tags one symbol apart reset it to a state that follows from the tags and
+ * the samples alone: the loop is entered at up to `restart_points_per_channel` such pairs per call
+ * (<= 64; 0 = off) by one lane each ("units"), and a join pass runs the serial loop from the carried
+ * state, compares the two delay registers bit for bit at every restart point it reaches and takes over
+ * the unit's symbols and end state where they agree.  Results are identical to the serial kernel's;
+ * which is faster depends on the traffic.  join_kernel: 1 = the serial kernel
+ * with fast-forward (default), 0 = one lane per channel, -1 = leave; max_unit_items: no unit is started
+ * at a restart point further than this from the next one (0 = leave).  Applies to stream calls with
+ * osps 1 and the err / mu ports open; everything else takes the serial kernel. */
+int aisx_msk_set_time_parallel(aisx_msk* h, int restart_points_per_channel, int join_kernel, int max_unit_items);
 int aisx_msk_get_max_noutput_items(const aisx_msk* h);
 int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
 /* Diagnostics of the time-parallel recovery (k_mskp.h) for the last aisx_msk_process_stream call,

@@ -430,7 +430,8 @@ void emu_msk_tp_stats(void* hv, long* out)
 }
 
 static void emu_msk_fill(EmuMsk* h, MskParams& p);
-static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc);
+static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc,
+                            const msk_ctag* ctl_new = nullptr, const int* ctl_new_n = nullptr, int ctl_new_cap = 0);
 // the time-parallel kernels on the lane model: prepass, units, join, gather
 static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const tag_rec* tags, const int* tag_counts,
                          int tag_cap, cf* syms, long out_stride, int* produced)
@@ -482,7 +483,7 @@ static void emu_mskp_run(EmuMsk* h, const cf* in, long in_stride, int n, const t
         run_grid((nc + p.jw - 1) / p.jw, 1, 64, MSKP_LDS_BYTES, [&](EmuCtx& cx) { mskp_body<EmuCtx, true>(cx, p); });
     } else { // the serial kernel as the join (MskParams::ff)
         std::vector<int> ct_nc(nc, 0);
-        emu_msk_tagprep(h, tags, tag_counts, tag_cap, ct_nc.data());
+        emu_msk_tagprep(h, tags, tag_counts, tag_cap, ct_nc.data(), ctl.data(), ctl_n.data(), ctl_cap); // (new tags as the prepass left them)
         MskParams m;
         emu_msk_fill(h, m);
         m.in = in; m.in_stride = in_stride; m.n = n; m.stream_mode = 1; m.gr_ninput = 0; m.gr_noutput = 0;
@@ -530,7 +531,8 @@ static void emu_msk_fill(EmuMsk* h, MskParams& p)
     p.lds_tab_off = p.lds_ring_off + msk_waves(h->lpw) * p.lds_wave_stride;
 }
 
-static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc)
+static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_counts, int tag_cap, int* ct_nc,
+                            const msk_ctag* ctl_new, const int* ctl_new_n, int ctl_new_cap)
 {
     h->ct_cap = EmuMsk::ctag_cap + (tags ? tag_cap : 0);
     h->ct.assign((size_t)h->nchan * h->ct_cap, msk_ctag{ 0, 0.f });
@@ -541,6 +543,7 @@ static void emu_msk_tagprep(EmuMsk* h, const tag_rec* tags, const int* tag_count
     t.tags = tags; t.tag_count = tag_counts; t.tag_cap = tag_cap;
     t.nread = h->nread.data();
     t.ct = h->ct.data(); t.ct_n = h->ct_n.data(); t.ct_cap = h->ct_cap; t.ct_nc = ct_nc;
+    t.ctl_new = ctl_new; t.ctl_new_n = ctl_new_n; t.ctl_new_cap = ctl_new_cap; t.ctl_new_pre = MSKP_TPRE; t.W = h->total_in;
     run_grid((h->nchan + 3) / 4, 1, 256, 64, [&](EmuCtx& cx) { tagprep_body(cx, t); });
 }
 
