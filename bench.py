@@ -146,8 +146,8 @@ def cpu_baseline(chain, family, sps, T, budget_s=6.0):
       B1  one thread, whole channels of T samples one after the other (the like-for-like of one
           GNU Radio flowgraph of one channel);
       B2  one worker thread per hardware thread, each running whole channels.
-    `value` is B2, `cores` the threads it used; B1 and the portable -O2 build's figures (what
-    rounds 1-2 reported) stand next to it."""
+    `value` is the better of B2 and the same with one thread per two hardware threads, `cores` the threads
+    that run used; B1 and the portable -O2 build's figures (what rounds 1-2 reported) stand next to it."""
     import tempfile
 
     import oracle_py as orc
@@ -189,7 +189,8 @@ def cpu_baseline(chain, family, sps, T, budget_s=6.0):
                 "the per-sample work is short dependent float chains (NCO phase, timing loop) that SMT siblings share one "
                 "core's ports for, and the radix-2 FFT walks its 16 KB block twelve times" %
                 (b2 / b1, ncores, half / b1, max(1, ncores // 2), 8.0 * T * 7 / 1e6))
-    return dict(value=b2, unit="complex MS/s", cores=ncores, kind="port",
+    best, best_cores = (b2, ncores) if b2 >= half else (half, max(1, ncores // 2))
+    return dict(value=best, unit="complex MS/s", cores=best_cores, kind="port", all_threads_value=b2,
                 sample="B2: %d channels x %d samples on %d threads in %.1f s wall; B1: %d channels on one thread (%.1f s); chain=%s; "
                        "oracle/ais_oracle.c (%s; radix-2 FFT standing in for FFTW/VOLK)" % (n2, T, ncores, w2, n1, w1, chain, flags),
                 single_thread_value=b1, scaling_B2_over_B1=b2 / b1, half_threads_value=half,
@@ -199,7 +200,7 @@ def cpu_baseline(chain, family, sps, T, budget_s=6.0):
                 reference_volk_path="unavailable (no GNU Radio / VOLK in the image)")
 
 
-def oracle_replay(chain, tmpl, sps, xk, nsteps):
+def oracle_replay(chain, tmpl, sps, xk, nsteps, max_noutput=0):
     """The oracle stepping `nsteps` times over the same samples (one row of xk per channel), as the
     benchmark does; returns, per channel, the last step's (bits, tags).  One thread per channel."""
     import concurrent.futures as cf
@@ -214,7 +215,7 @@ def oracle_replay(chain, tmpl, sps, xk, nsteps):
             for _ in range(nsteps):
                 _, _, tags = o.work(xk[c])
             return None, tags
-        dem = orc.Demod(sps, tmpl, stages=3 if chain == "stock" else 0)
+        dem = orc.Demod(sps, tmpl, stages=3 if chain == "stock" else 0, max_noutput=max_noutput)
         for _ in range(nsteps):
             bits, _, tags = dem.step(xk[c])
         return bits, tags
@@ -223,12 +224,12 @@ def oracle_replay(chain, tmpl, sps, xk, nsteps):
         return list(ex.map(run, range(len(xk))))
 
 
-def parity_gates(chain, tmpl, sps, T, family, rank, xk, nsteps, gpu_tags, gpu_bits, gpu_prod, thresh):
+def parity_gates(chain, tmpl, sps, T, family, rank, xk, nsteps, gpu_tags, gpu_bits, gpu_prod, thresh, max_noutput=0):
     """the last step of the channels in xk, HIP path vs oracle."""
     from parity import compare_bursts, compare_detections
 
     t0 = time.perf_counter()
-    ref = oracle_replay(chain, tmpl, sps, xk, nsteps)
+    ref = oracle_replay(chain, tmpl, sps, xk, nsteps, max_noutput)
     K = len(xk)
     tot = dict(detections=0, matched=0, offsets_equal=0, lone=0, lone_near_threshold=0)
     mag = tim = 0.0
@@ -254,8 +255,11 @@ def parity_gates(chain, tmpl, sps, T, family, rank, xk, nsteps, gpu_tags, gpu_bi
            "mag_gate_1e-5": bool(mag <= 1e-5), "time_est_gate_1e-4": bool(tim <= 1e-4),
            "oracle_seconds": round(time.perf_counter() - t0, 2)}
     if chain != "corr":
+        # bursts_within_4: the burst's bits are in the HIP stream within +-4 bit positions of where the oracle has
+        # them (a time_est that differs in its last place can slip one symbol in the noise before a burst);
+        # bursts_in_place: at exactly the same position
         out.update(bursts_compared=ncmp, bursts_identical=near, bursts_identical_same_position=same,
-                   symbol_counts_equal=count_equal)
+                   bursts_in_place=same, bursts_within_4=near, symbol_counts_equal=count_equal)
     return out
 
 
@@ -418,7 +422,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(chain, want_parity):
+    def measure(chain, want_parity, lookahead=True, msk_tp=False, msk_Q=0):
         """K timed steps of `chain` on this rank's channel shard; returns the wall time (max over
         ranks), the correlator kernel's per-launch times inside the timed region and (rank 0) the
         parity gates of the last step.  The step is the product's pipelined chain
@@ -438,6 +442,11 @@ def main():
                                 preamble_symbols=tmpl, fused_front_end=True)
         corr = dem.preamble_detect
         corr.set_profiling(True)
+        if chain != "corr":
+            if msk_Q:
+                dem.clockrec.set_max_noutput_items(msk_Q)
+            if msk_tp:
+                dem.clockrec.set_time_parallel(64, 1, 16384)
         y_corr = [torch.empty((nchan, T), dtype=torch.complex64, device=device) for _ in range(2)] if chain == "corr" else None
         state = dict(k=0, last=None)
 
@@ -445,7 +454,7 @@ def main():
             if chain == "corr":
                 corr.work(x, out=y_corr[state["k"] & 1])
             else:
-                state["last"] = dem.work_pipelined(x, x_next=x if stock else None)
+                state["last"] = dem.work_pipelined(x, x_next=x if (stock and lookahead) else None)
             state["k"] += 1
 
         for _ in range(args.warmup):
@@ -477,7 +486,9 @@ def main():
                 gbits = last["bits"][:K].cpu().numpy() if chain != "corr" else None
                 gprod = last["produced"][:K].cpu().numpy() if chain != "corr" else None
                 res["parity"] = parity_gates(chain, tmpl, sps, T, args.template, rank, x[:K].cpu().numpy(),
-                                             args.warmup + args.steps, tags[tags["chan"] < K], gbits, gprod, corr.threshold())
+                                             args.warmup + args.steps, tags[tags["chan"] < K], gbits, gprod, corr.threshold(), msk_Q)
+            if msk_tp:
+                res["restart_stats"] = dem.clockrec.restart_stats()
         barrier()
         # the same kernel with the chip to itself (no timing-recovery kernel alongside), on the
         # data it sees in the chain: behind the front end for the stock chain
@@ -534,6 +545,11 @@ def main():
     side = not args.single_chain
     # the default run also times the two-block chain the metric string names, and the correlator alone
     extra = measure("core", False) if (args.chain == "stock" and side) else None
+    # the caveats of the headline as numbers: the same steps without the one-buffer look-ahead (x_next = None: every
+    # step estimates for itself), and with the time-parallel timing recovery (opt-in, include/aisx.h)
+    nola = measure("stock", False, lookahead=False) if (args.chain == "stock" and side and world == 1) else None
+    tpm = measure(args.chain, True, msk_tp=True, msk_Q=256) if (args.chain != "corr" and side and world == 1) else None
+    tpq = measure(args.chain, False, msk_tp=False, msk_Q=256) if (args.chain != "corr" and side and world == 1) else None
     corr_only = None
     if side and world == 1:
         corr_only = [measure_corr_only(c, f) for c in (256, 4096) for f in ("S", "P")]
@@ -610,6 +626,19 @@ def main():
                 "corr_kernel_ms": float(np.mean(extra["kern_ms"])),
                 "detections_last_step": extra["ndet"],
                 "msk_status": int(extra["st"]),
+            }
+        if nola is not None:
+            line["no_lookahead_ms_per_step"] = nola["el"] / args.steps * 1e3
+        if tpm is not None:
+            line["msk_time_parallel"] = {
+                "what": "the same steps with aisx_msk_set_time_parallel(64 restart points, serial kernel as join, units <= 16384 items) "
+                        "and set_max_noutput_items(256); off by default",
+                "ms_per_step": tpm["el"] / args.steps * 1e3,
+                "ms_per_step_serial_kernel_same_max_noutput_items": tpq["el"] / args.steps * 1e3,
+                "corr_kernel_ms": float(np.mean(tpm["kern_ms"])),
+                "restart_stats_last_step": tpm.get("restart_stats"),
+                "parity": tpm["parity"],
+                "msk_status": int(tpm["st"]),
             }
         if corr_only is not None:
             line["corr_only"] = corr_only

@@ -103,6 +103,7 @@ def lib():
     sig("aisx_msk_wait_prepass", i32, [vp, vp])
     sig("aisx_msk_general_work_host", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, i32, pi32, pi32])
     sig("aisx_freqsync_create", i32, [pvp, f64, f64, i32, i32, i32])
+    sig("aisx_freqest_create", i32, [pvp, f32, i32, i32, i32])
     sig("aisx_freqsync_destroy", i32, [vp])
     sig("aisx_freqsync_reset", i32, [vp])
     sig("aisx_freqsync_process", i32, [vp, vp, lng, i32, vp, lng, vp, lng, pi32, vp])

@@ -383,6 +383,12 @@ class freqest:
     def __init__(self, sample_rate, data_rate, fftlen, nchan=1):
         self._fs = square_and_fft_sync_cc(float(sample_rate), float(data_rate), fftlen, nchan=nchan, max_items=fftlen)
         self.nchan, self.fftlen = nchan, fftlen
+        if nchan == 1 and float(sample_rate) != int(sample_rate):
+            # the block's own make(): d_offset / d_binsize from the float rate (lib/freqest_impl.cc:46-47)
+            h = C.c_void_p()
+            check(_lib.lib().aisx_freqest_create(C.byref(h), float(sample_rate), int(data_rate), int(fftlen), 64), "freqest")
+            _lib.lib().aisx_freqsync_destroy(self._fs._h)
+            self._fs._h = h
 
     def work(self, vecs, stream=None):
         v = _dev_c64(vecs, self.nchan)

@@ -168,6 +168,24 @@ extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, doub
     return AISX_OK;
 }
 
+extern "C" int aisx_freqest_create(aisx_freqsync** out, float sample_rate, int data_rate, int fftlen, int max_vectors)
+{
+    // freqest::make(float sample_rate, int data_rate, int fftlen) (include/ais/freqest.h:46): the block alone,
+    // with a sample rate that need not be a whole number (lib/freqest_impl.cc:46-47 keep the float)
+    if (max_vectors < 1 || data_rate < 1) {
+        if (out)
+            *out = nullptr;
+        set_err("aisx_freqest_create: bad argument");
+        return AISX_ERR_INVALID;
+    }
+    int rc = aisx_freqsync_create(out, (double)sample_rate, (double)data_rate, fftlen, 1, max_vectors * fftlen);
+    if (rc != AISX_OK)
+        return rc;
+    (*out)->offset = (int)(fftlen * ((float)data_rate / sample_rate));
+    (*out)->binsize = sample_rate / (float)fftlen;
+    return AISX_OK;
+}
+
 extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
 {
     if (!h)

@@ -260,6 +260,11 @@ typedef struct aisx_freqsync aisx_freqsync;
 int aisx_freqsync_create(aisx_freqsync** h, double samplerate, double bits_per_sec, int fftlen, int nchan,
                          int max_items);
 int aisx_freqsync_destroy(aisx_freqsync* h);
+/* freqest::make(sample_rate, data_rate, fftlen) (include/ais/freqest.h:46) for the block on its own
+ * (nchan == 1, aisx_freqest_work / aisx_freqest_work_host): d_offset and d_binsize from the FLOAT sample
+ * rate as lib/freqest_impl.cc:46-47 compute them (aisx_freqsync_create truncates it to an int first, as
+ * python/gmsk_sync.py:25 does).  max_vectors bounds noutput_items of one work() call. */
+int aisx_freqest_create(aisx_freqsync** h, float sample_rate, int data_rate, int fftlen, int max_vectors);
 int aisx_freqsync_reset(aisx_freqsync* h);
 /* n new items per channel; every complete fftlen-vector is processed (one
  * freqest work() call per channel); *n_out = items written per channel (a

@@ -1,0 +1,4 @@
+// tests/gr_mock
+#pragma once
+#include <complex>
+typedef std::complex<float> gr_complex;
