@@ -29,6 +29,16 @@ __global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk(MskParams p)
     msk_body<DevCtx, AUX, OSPS2, LPW>(cx, p);
 }
 
+// the same kernel as the join of the time-parallel recovery (MskParams::ff)
+template <int LPW>
+__global__ __launch_bounds__(64 * msk_waves(LPW)) void k_msk_ff(MskParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    __builtin_amdgcn_s_setprio(MSK_PRIO);
+    msk_body<DevCtx, false, false, LPW, true>(cx, p);
+}
+
 __global__ __launch_bounds__(BT_T) void k_bittail(BitTailParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[260 * 4];
@@ -101,12 +111,24 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
         return e ? atoi(e) * 1024 : 0;
     }();
     const int lds = std::min(msk_lds_bytes(p.lpw) + pad, 160 * 1024);
-    if (!big_lds[v]) {
-        AISX_HIPCHK(hipFuncSetAttribute((const void*)fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        big_lds[v] = true;
+    kfn fn = fns[v];
+    bool* big = &big_lds[v];
+    if (p.ff) { // the join of the time-parallel recovery: a build of its own (stream mode, osps 1, no err / mu)
+        static const kfn ffs[5] = { k_msk_ff<16>, k_msk_ff<32>, k_msk_ff<64>, k_msk_ff<8>, k_msk_ff<4> };
+        static bool big_ff[5] = { false };
+        if (p.err || p.mu_out || p.osps == 2) {
+            set_err("msk_launch: the join build has no err / mu ports and osps == 1");
+            return AISX_ERR_INVALID;
+        }
+        fn = ffs[li];
+        big = &big_ff[li];
+    }
+    if (!*big) {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        *big = true;
     }
     // a workgroup = msk_waves(lpw) waves with lpw channels each
-    hipLaunchKernelGGL(fns[v], dim3(nwg), dim3(64 * msk_waves(p.lpw)), lds, st, p);
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(64 * msk_waves(p.lpw)), lds, st, p);
     AISX_HIPCHK(hipGetLastError());
     return AISX_OK;
 }

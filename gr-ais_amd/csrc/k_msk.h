@@ -205,9 +205,11 @@ extern long msk_stats[8];
 // AUX: the err / mu output ports are connected (:187-189).  OSPS2: osps == 2 (:186).
 // LPW: channels (active lanes) per wave; the LDS layouts are [.][LPW], so a build with few
 // channels per wave leaves most of the CU's LDS to whatever else runs there.
-template <class Ctx, bool AUX, bool OSPS2, int LPW>
+// FFT: the build that can run as the join of the time-parallel recovery (MskParams::ff; AUX and OSPS2 off).
+template <class Ctx, bool AUX, bool OSPS2, int LPW, bool FFT = false>
 AISX_DI void msk_body(Ctx& cx, const MskParams& p)
 {
+    static_assert(!FFT || (!AUX && !OSPS2), "the join build has no err / mu ports and osps == 1");
     constexpr int SLOT_B = LPW * 8;                                   // bytes per ring slot row
     constexpr int SLOT_SH = LPW == 64 ? 9 : (LPW == 32 ? 8 : (LPW == 16 ? 7 : (LPW == 8 ? 6 : 5))); // log2(SLOT_B)
     static_assert(LPW == 4 || LPW == 8 || LPW == 16 || LPW == 32 || LPW == 64, "channels per wave");
@@ -340,7 +342,7 @@ AISX_DI void msk_body(Ctx& cx, const MskParams& p)
     tq_fill();
 
     // ---- JOIN of the time-parallel recovery: the next restart point this lane may meet
-    const bool FF = p.ff != 0;
+    constexpr bool FF = FFT; // (the launcher picks the build by p.ff)
     // (FF: what a channel was when its step ended, see the main loop)
     bool fin_saved = false;
     float fin_mu = 0.f, fin_omega = 0.f;

@@ -289,7 +289,9 @@ void emu_msk(const MskParams* p)
     auto go = [&](auto lpw_tag) {
         constexpr int L = decltype(lpw_tag)::value;
         run_grid((p->nchan + msk_wg_channels(L) - 1) / msk_wg_channels(L), 1, 64 * msk_waves(L), p->lds_tab_off + MSK_LDS_MMSE, [&](EmuCtx& cx) {
-            if (p->osps == 2)
+            if (p->ff)
+                msk_body<EmuCtx, false, false, L, true>(cx, *p);
+            else if (p->osps == 2)
                 aux ? msk_body<EmuCtx, true, true, L>(cx, *p) : msk_body<EmuCtx, false, true, L>(cx, *p);
             else
                 aux ? msk_body<EmuCtx, true, false, L>(cx, *p) : msk_body<EmuCtx, false, false, L>(cx, *p);
