@@ -12,7 +12,14 @@ import os as _os
 # the pipelined chain (ais_demod.work_pipelined, aisx_chain_*) keeps four streams busy; with the HIP
 # runtime's default of four hardware queues two of them would share one and run in turn.  Read by
 # the runtime at its first call, i.e. after this import.
+import sys as _sys
+
+_t = _sys.modules.get("torch")
+# (a process that has already made HIP calls -- torch.cuda initialised -- keeps the queue count it started with:
+# ais_demod.work_pipelined warns once when that is the case)
+HW_QUEUES_SET_TOO_LATE = "GPU_MAX_HW_QUEUES" not in _os.environ and _t is not None and _t.cuda.is_initialized()
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+del _t
 
 from .framing import hdlc_deframer_bp, pdu_to_nmea  # noqa: F401
 from .modulate import gmsk_mod, modulate_vector_bc  # noqa: F401

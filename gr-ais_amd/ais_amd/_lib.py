@@ -30,11 +30,23 @@ class NoDeviceError(AisxError):
 
 
 _lib = None
+_torch_first = False
 
 
-def lib():
-    global _lib
+def lib(device=True):
+    """libaisx.so, loaded once.  device=False: a host-only helper is asking (HDLC deframer, NMEA: plain C++
+    in the same library) -- torch is then not imported on its account."""
+    global _lib, _torch_first
     if _lib is not None:
+        if device and not _torch_first:
+            import sys
+            import warnings
+
+            if "torch" not in sys.modules:
+                warnings.warn("ais_amd: libaisx.so was loaded by a host-only helper before torch; torch ships its own copy of "
+                              "the HIP runtime, and a process with two of them may see no device through the second: import "
+                              "torch (or ais_amd.blocks) first in processes that use both", RuntimeWarning, stacklevel=2)
+            _torch_first = True  # (say it once)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -43,10 +55,15 @@ def lib():
     # torch ships its own copy of the HIP runtime: load it FIRST, so that libaisx.so binds to the
     # runtime that owns the devices torch hands out pointers of (the other order leaves this
     # process with two runtimes, and the second one sees no device)
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    import sys
+
+    if device or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401
+
+            _torch_first = True
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, f32, f64, u64, lng = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_uint64, C.c_long
     pvp, pi32 = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
@@ -65,6 +82,7 @@ def lib():
     sig("aisx_corr_destroy", i32, [vp])
     sig("aisx_corr_symbols", i32, [vp, vp, i32])
     sig("aisx_corr_set_symbols", i32, [vp, vp, i32])
+    sig("aisx_corr_geometry", i32, [vp, pi32, pi32])
     sig("aisx_corr_history", i32, [vp])
     sig("aisx_corr_output_multiple", i32, [vp])
     sig("aisx_corr_max_noutput_items", i32, [vp])
@@ -101,9 +119,13 @@ def lib():
     sig("aisx_msk_set_tail_stream", i32, [vp, vp, i32])
     sig("aisx_msk_wait_tail", i32, [vp, vp])
     sig("aisx_msk_wait_prepass", i32, [vp, vp])
+    sig("aisx_msk_set_head_start", i32, [vp, i32])
+    sig("aisx_msk_geometry", i32, [vp, pi32, pi32])
     sig("aisx_msk_general_work_host", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, i32, pi32, pi32])
     sig("aisx_freqsync_create", i32, [pvp, f64, f64, i32, i32, i32])
     sig("aisx_freqest_create", i32, [pvp, f32, i32, i32, i32])
+    sig("aisx_freqsync_geometry", i32, [vp, pi32, pi32, pi32])
+    sig("aisx_freqsync_drop_ahead", i32, [vp, vp])
     sig("aisx_freqsync_destroy", i32, [vp])
     sig("aisx_freqsync_reset", i32, [vp])
     sig("aisx_freqsync_process", i32, [vp, vp, lng, i32, vp, lng, vp, lng, pi32, vp])
@@ -115,6 +137,7 @@ def lib():
     sig("aisx_freqsync_estimate_ahead", i32, [vp, vp, lng, i32, vp, vp])
     sig("aisx_agc_create", i32, [pvp, i32, f32, i32, i32])
     sig("aisx_agc_destroy", i32, [vp])
+    sig("aisx_agc_geometry", i32, [vp, pi32, pi32, pi32, pi32])
     sig("aisx_agc_reset", i32, [vp])
     sig("aisx_agc_set_floor", i32, [vp, f32])
     sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
@@ -126,6 +149,7 @@ def lib():
     sig("aisx_chain_wait_input", i32, [vp, C.c_longlong, vp, i32])
     sig("aisx_chain_synchronize", i32, [vp])
     sig("aisx_chain_read_corr_output", i32, [vp, C.c_longlong, i32, i32, vp, lng, pi32, vp])
+    sig("aisx_chain_read_tags", i32, [vp, C.c_longlong, vp, i32, pi32, vp])
     sig("aisx_chain_stream", vp, [vp, i32])
     sig("aisx_pfb_create", i32, [pvp, i32, i32, vp, i32, i32, i32])
     sig("aisx_pfb_destroy", i32, [vp])

@@ -441,6 +441,30 @@ class feedforward_agc_cc:
         return out
 
 
+_hwq_warned = False
+
+
+def _warn_if_few_hw_queues():
+    """The chain keeps four streams busy; the HIP runtime reads GPU_MAX_HW_QUEUES (default 4, shared by every
+    stream of the process) at its first call.  Correct results either way -- but the streams then run in turn."""
+    global _hwq_warned
+    import os
+    import warnings
+
+    from . import HW_QUEUES_SET_TOO_LATE
+
+    try:
+        few = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8
+    except ValueError:
+        few = True
+    if (HW_QUEUES_SET_TOO_LATE or few) and not _hwq_warned:
+        _hwq_warned = True
+        warnings.warn("ais_amd: the pipelined chain wants GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the first HIP call "
+                      "(%s); with the runtime's four hardware queues its streams share queues and the step is slower"
+                      % ("the process had initialised torch.cuda before ais_amd was imported" if HW_QUEUES_SET_TOO_LATE
+                         else "it is %s" % os.environ.get("GPU_MAX_HW_QUEUES", "unset")), RuntimeWarning, stacklevel=3)
+
+
 class ais_demod:
     """ais.ais_demod(options) (python/ais_demod.py:21-56): the demod chain
     freq_sync -> agc -> corr_est (preamble_detect) -> msk timing recovery (clockrec)
@@ -489,6 +513,7 @@ class ais_demod:
     # -- pipelined step (aisx_chain_*): the path bench.py times ------------------------------
     def _chain_handle(self):
         if getattr(self, "_chain", None) is None:
+            _warn_if_few_hw_queues()
             h = C.c_void_p()
             stock = self.stages == "stock"
             check(_lib.lib().aisx_chain_create(C.byref(h), self.freq_sync._h if stock else None, self.agc._h if stock else None,
@@ -560,6 +585,16 @@ class ais_demod:
         check(_lib.lib().aisx_chain_read_corr_output(self._chain_handle(), step, chan0, nch, out.data_ptr(), out.stride(0),
                                                      C.byref(n), _stream_ptr(stream)), "ais_demod.corr_output")
         return out[:, : n.value]
+
+    def step_tags(self, step, stream=None):
+        """corr_est's tags of pipelined step `step` (one of the last AISX_CHAIN_DEPTH) on the host, by step
+        number (aisx_chain_read_tags): a step whose front end emitted no whole vector has none."""
+        cap = self.nchan * self.preamble_detect._cap
+        buf = np.zeros(cap, dtype=TAG_DTYPE)
+        nt = C.c_int(0)
+        check(_lib.lib().aisx_chain_read_tags(self._chain_handle(), int(step), buf.ctypes.data_as(C.c_void_p), cap, C.byref(nt),
+                                              _stream_ptr(stream)), "ais_demod.step_tags")
+        return buf[: nt.value].copy()
 
     def chain_stream(self, which):
         """the chain's streams as raw hipStream_t values: 0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk"""

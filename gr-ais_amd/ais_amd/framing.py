@@ -13,14 +13,14 @@ from ._lib import check
 class hdlc_deframer_bp:
     def __init__(self, length_min, length_max):
         h = C.c_void_p()
-        check(_lib.lib().aisx_hdlc_create(C.byref(h), int(length_min), int(length_max)), "hdlc_deframer_bp")
+        check(_lib.lib(device=False).aisx_hdlc_create(C.byref(h), int(length_min), int(length_max)), "hdlc_deframer_bp")
         self._h = h
         self._max = int(length_max)
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().aisx_hdlc_destroy(h)
+            _lib.lib(device=False).aisx_hdlc_destroy(h)
             self._h = None
 
     def work(self, bits):
@@ -30,7 +30,7 @@ class hdlc_deframer_bp:
         buf = np.zeros(maxp * (self._max + 2), dtype=np.uint8)
         offs = np.zeros(maxp + 1, dtype=np.int32)
         n = C.c_int(0)
-        check(_lib.lib().aisx_hdlc_work(self._h, b.ctypes.data_as(C.c_void_p), b.size, buf.ctypes.data_as(C.c_void_p),
+        check(_lib.lib(device=False).aisx_hdlc_work(self._h, b.ctypes.data_as(C.c_void_p), b.size, buf.ctypes.data_as(C.c_void_p),
                                         buf.size, offs.ctypes.data_as(C.c_void_p), maxp, C.byref(n)), "hdlc work")
         return [bytes(buf[offs[k]:offs[k + 1]]) for k in range(n.value)]
 
@@ -42,6 +42,6 @@ class pdu_to_nmea:
     def msg_to_sentence(self, pdu):
         p = np.frombuffer(bytes(pdu), dtype=np.uint8)
         out = C.create_string_buffer(4096)
-        n = check(_lib.lib().aisx_pdu_to_nmea(self.designator.encode(), p.ctypes.data_as(C.c_void_p), p.size, out, 4096),
+        n = check(_lib.lib(device=False).aisx_pdu_to_nmea(self.designator.encode(), p.ctypes.data_as(C.c_void_p), p.size, out, 4096),
                   "pdu_to_nmea")
         return out.raw[:n].decode("latin-1")

@@ -4,6 +4,7 @@
 // choreography that makes the stages of neighbouring steps overlap.
 // Host code only: every kernel is launched through the stages' own entry points.
 #include <stdlib.h>
+#include <string>
 
 #include "aisx_host.h"
 
@@ -18,6 +19,10 @@ struct aisx_chain {
     int serial = 0; // AISX_CHAIN_SERIAL: every stage on s_main (A/B runs)
     // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead
     hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr;
+    long long corr_calls = 0;          // aisx_corr_process calls made so far
+    long long corr_call_of[8] = { 0 }; // [step % NBUF]: corr_calls behind that step's call, 0 for a step without one
+    bool failed = false;               // a step failed half way: see aisx_chain_step
+    int msk_cus = 0; // compute units set aside for the timing recovery's stream (0: streams share the chip)
     static constexpr int NBUF = AISX_CHAIN_DEPTH;
     cf* d_y = nullptr; // front-end output (stock chain): one buffer, written and read on s_main
     long y_stride = 0;
@@ -73,6 +78,49 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
     int rc = require_device();
     if (rc != AISX_OK)
         return rc;
+    {
+        // the stage handles are borrowed: their channel counts and capacities must cover what the chain
+        // will hand them (rows of d_y / d_yc are sized here, the kernels' grids there)
+        int nc = 0, mi = 0, fl = 0, W = 0, fused_ok = 0;
+        const int need = max_items + (fs ? fftlen : 0); // a step emits every whole vector of (pending + new) items
+        bool ok = true;
+        char why[160] = "";
+        auto bad = [&](const char* stage, const char* what, int got, int want) {
+            if (ok)
+                snprintf(why, sizeof why, "%s handle: %s %d, the chain needs %d", stage, what, got, want);
+            ok = false;
+        };
+        aisx_corr_geometry(corr, &nc, &mi);
+        if (nc != nchan)
+            bad("corr_est", "nchan", nc, nchan);
+        else if (mi < need)
+            bad("corr_est", "max_items", mi, need);
+        aisx_msk_geometry(msk, &nc, &mi);
+        if (nc != nchan)
+            bad("msk_timing_recovery", "nchan", nc, nchan);
+        else if (mi < need)
+            bad("msk_timing_recovery", "max_items", mi, need);
+        if (fs) {
+            aisx_freqsync_geometry(fs, &nc, &mi, &fl);
+            if (nc != nchan)
+                bad("freq_sync", "nchan", nc, nchan);
+            else if (fl != fftlen)
+                bad("freq_sync", "fftlen", fl, fftlen);
+            else if (mi < max_items)
+                bad("freq_sync", "max_items", mi, max_items);
+            aisx_agc_geometry(agc, &nc, &mi, &W, &fused_ok);
+            if (nc != nchan)
+                bad("agc", "nchan", nc, nchan);
+            else if (mi < need)
+                bad("agc", "max_items", mi, need);
+            else if (!fused_ok)
+                bad("agc", "window (a multiple of 8 in [16, 2048] for the fused front end)", W, 512);
+        }
+        if (!ok) {
+            set_err("aisx_chain_create: %s", why);
+            return AISX_ERR_INVALID;
+        }
+    }
     aisx_chain* h = new aisx_chain();
     h->fs = fs;
     h->agc = agc;
@@ -92,8 +140,37 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             return AISX_ERR_HIP;                                                                   \
         }                                                                                          \
     } while (0)
-    for (hipStream_t* s : { &h->s_main, &h->s_msk, &h->s_tail, &h->s_walk })
-        CKH(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    {
+        // AISX_CHAIN_MSK_CUS = N: the timing recovery's stream owns N compute units (CU-mask bits [0, N): the
+        // driver deals mask bits round the XCDs, so N / 8 CUs in each), the other streams the remaining ones
+        int ncu = 0, msk_cus = 0, walk_with_msk = 0, tail_with_msk = 0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        CKH(hipGetDevice(&dev));
+        CKH(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+        if (const char* e = getenv("AISX_CHAIN_MSK_CUS"))
+            msk_cus = atoi(e);
+        if (const char* e = getenv("AISX_CHAIN_WALK_WITH_MSK"))
+            walk_with_msk = atoi(e);
+        if (const char* e = getenv("AISX_CHAIN_TAIL_WITH_MSK"))
+            tail_with_msk = atoi(e);
+        if (h->serial || msk_cus < 0 || msk_cus >= ncu)
+            msk_cus = 0;
+        auto make = [&](hipStream_t* s, int lo, int hi) -> hipError_t {
+            if (msk_cus == 0)
+                return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int b = lo; b < hi; b++)
+                mask[(size_t)b / 32] |= 1u << (b % 32);
+            return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+        };
+        CKH(make(&h->s_main, msk_cus, ncu));
+        CKH(make(&h->s_msk, 0, msk_cus));
+        CKH(tail_with_msk ? make(&h->s_tail, 0, msk_cus) : make(&h->s_tail, msk_cus, ncu));
+        CKH(walk_with_msk ? make(&h->s_walk, 0, msk_cus) : make(&h->s_walk, msk_cus, ncu));
+        h->msk_cus = msk_cus;
+    }
     CKH(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     for (int k = 0; k < aisx_chain::NBUF; k++) {
         CKH(hipEventCreateWithFlags(&h->ev_ready[k], hipEventDisableTiming));
@@ -116,7 +193,11 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
     if (!h->serial) {
         // the bit tail of step k beside the recovery of step k + 1; the next step's sample passes
         // behind this step's tag prepass (aisx_msk_wait_prepass: the first call arms the event)
-        if ((rc = aisx_msk_set_tail_stream(msk, h->s_tail, 1)) != AISX_OK || (rc = aisx_msk_wait_prepass(msk, h->s_main)) != AISX_OK) {
+        int us = 20; // AISX_MSK_HEADSTART_US: the recovery kernel's head start at the dispatcher (aisx_msk_set_head_start)
+        if (const char* e = getenv("AISX_MSK_HEADSTART_US"))
+            us = atoi(e);
+        if ((rc = aisx_msk_set_tail_stream(msk, h->s_tail, 1)) != AISX_OK || (rc = aisx_msk_set_head_start(msk, us < 0 ? 0 : us)) != AISX_OK ||
+            (rc = aisx_msk_wait_prepass(msk, h->s_main)) != AISX_OK) {
             chain_free(h);
             return rc;
         }
@@ -133,6 +214,10 @@ extern "C" int aisx_chain_destroy(aisx_chain* h)
 
 extern "C" int aisx_chain_depth(void) { return aisx_chain::NBUF; }
 
+static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next, long next_stride,
+                            int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride, int* d_produced, void* stream,
+                            long long* step);
+
 extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next,
                                long next_stride, int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride,
                                int* d_produced, void* stream, long long* step)
@@ -142,6 +227,30 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         set_err("aisx_chain_step: bad argument (n = %d, max_items = %d)", n, h ? h->max_items : -1);
         return AISX_ERR_INVALID;
     }
+    if (h->failed) {
+        set_err("aisx_chain_step: an earlier step failed half way (its stages had been issued in part): the stage handles' "
+                "streams and histories no longer match; aisx_*_reset the stages and create a new chain");
+        return AISX_ERR_INVALID;
+    }
+    const int rc = chain_step_issue(h, d_in, in_stride, n, d_in_next, next_stride, n_next, d_syms, d_bits, out_stride, d_produced, stream,
+                                    step);
+    if (rc != AISX_OK) {
+        // Not transactional: stages issued before the failure have run (histories advanced, preparations
+        // queued).  What was prepared ahead is dropped, and the chain refuses further steps.
+        const std::string msg = aisx_last_error();
+        if (h->fs)
+            aisx_freqsync_drop_ahead(h->fs, h->s_main);
+        h->ahead_in = nullptr;
+        h->failed = true;
+        set_err("%s", msg.c_str());
+    }
+    return rc;
+}
+
+static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next, long next_stride,
+                            int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride, int* d_produced, void* stream,
+                            long long* step)
+{
     int rc;
     const int par = (int)(h->nsteps % aisx_chain::NBUF);
     hipStream_t sm = h->s_main, sk = h->serial ? h->s_main : h->s_msk;
@@ -192,12 +301,18 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
     }
     if (m == 0) { // not one whole vector yet: nothing reaches the correlator (stream_to_vector holds the items)
         AISX_HIPCHK(hipMemsetAsync(d_produced, 0, sizeof(int) * h->nchan, sm));
+        // (the events of this slot are recorded afresh on s_main: behind what they stood for -- step k - NBUF's
+        // bit tail -- so that a wait for that step through the reused slot still holds)
+        if (h->nsteps >= aisx_chain::NBUF)
+            AISX_HIPCHK(hipStreamWaitEvent(sm, h->ev_done[par], 0));
+        h->corr_call_of[par] = 0;
         AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
         AISX_HIPCHK(hipEventRecord(h->ev_msk_done[par], sm));
         AISX_HIPCHK(hipEventRecord(h->ev_done[par], sm));
     } else {
         if ((rc = aisx_corr_process(h->corr, (const aisx_cf32*)y, ys, (aisx_cf32*)h->d_yc[par], h->yc_stride, nullptr, 0, m, sm)) != AISX_OK)
             return rc;
+        h->corr_call_of[par] = ++h->corr_calls;
         const aisx_tag* tags = nullptr;
         const int* counts = nullptr;
         int tcap = 0;
@@ -272,6 +387,24 @@ extern "C" int aisx_chain_read_corr_output(aisx_chain* h, long long step, int ch
     AISX_HIPCHK(hipMemcpy2DAsync(d_dst, sizeof(cf) * dst_stride, h->d_yc[par] + (size_t)chan0 * h->yc_stride, sizeof(cf) * h->yc_stride,
                                  sizeof(cf) * m, nch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return AISX_OK;
+}
+
+extern "C" int aisx_chain_read_tags(aisx_chain* h, long long step, aisx_tag* host_tags, int host_cap, int* ntags, void* stream)
+{
+    if (!h || !ntags || step < 0 || step >= h->nsteps || h->nsteps - step > aisx_chain::NBUF) {
+        set_err("aisx_chain_read_tags: step %lld is not among the last %d issued", step, aisx_chain::NBUF);
+        return AISX_ERR_INVALID;
+    }
+    *ntags = 0;
+    const long long call = h->corr_call_of[step % aisx_chain::NBUF];
+    if (call == 0) // that step's front end emitted no whole vector: corr_est was not called
+        return AISX_OK;
+    const long long back = h->corr_calls - call;
+    if (back > 2) { // (cannot happen while NBUF <= 3: every later step made at most one call)
+        set_err("aisx_chain_read_tags: the tags of step %lld have been overwritten", step);
+        return AISX_ERR_INVALID;
+    }
+    return aisx_corr_read_tags_back(h->corr, (int)back, host_tags, host_cap, ntags, stream);
 }
 
 extern "C" int aisx_chain_synchronize(aisx_chain* h)

@@ -462,6 +462,17 @@ extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int
     return corr_upload_taps(h);
 }
 
+extern "C" int aisx_corr_geometry(const aisx_corr* h, int* nchan, int* max_items)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (nchan)
+        *nchan = h->nchan;
+    if (max_items)
+        *max_items = h->max_items;
+    return AISX_OK;
+}
+
 extern "C" int aisx_corr_history(const aisx_corr* h) { return h ? h->N + 1 : AISX_ERR_INVALID; }
 extern "C" int aisx_corr_output_multiple(const aisx_corr* h) { return h ? h->out_multiple : AISX_ERR_INVALID; }
 extern "C" int aisx_corr_max_noutput_items(const aisx_corr*) { return 24 * 1024; }

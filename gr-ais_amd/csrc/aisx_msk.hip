@@ -158,6 +158,7 @@ struct aisx_msk {
     bool tail_on = false;
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_msk = nullptr, ev_tail[2] = { nullptr, nullptr };
+    unsigned head_start_ticks = 0; // aisx_msk_set_head_start
     hipEvent_t ev_prep = nullptr; // behind the tag prepass of the last aisx_msk_process_stream (aisx_msk_wait_prepass)
     bool ev_prep_set = false;
     bool ev_tail_set[2] = { false, false };
@@ -1063,16 +1064,38 @@ extern "C" int aisx_msk_wait_prepass(aisx_msk* h, void* stream)
         // it becomes ready on its own stream: which of the two queues the dispatcher serves first
         // is then a race (it used to be decided by two already-satisfied barrier packets that
         // happened to stand behind this one on `stream`: ~10 us).  A wave that sleeps for
-        // AISX_MSK_HEADSTART_US (default 20) on `stream` decides it.
-        static const int us = [] {
-            const char* e = getenv("AISX_MSK_HEADSTART_US");
-            return e ? atoi(e) : 20;
-        }();
-        if (us > 0) {
-            hipLaunchKernelGGL(k_msk_headstart, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)(us * 100));
+        // aisx_msk_set_head_start()'s microseconds on `stream` decides it (off unless asked for).
+        if (h->head_start_ticks > 0) {
+            hipLaunchKernelGGL(k_msk_headstart, dim3(1), dim3(64), 0, (hipStream_t)stream, h->head_start_ticks);
             AISX_HIPCHK(hipGetLastError());
         }
     }
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_set_head_start(aisx_msk* h, int microseconds)
+{
+    if (!h || microseconds < 0 || microseconds > 1000) {
+        set_err("aisx_msk_set_head_start: 0..1000 microseconds");
+        return AISX_ERR_INVALID;
+    }
+    // the sleeping wave counts wall_clock64() ticks: the constant-rate counter, hipDeviceAttributeWallClockRate kHz
+    int dev = 0, khz = 0;
+    AISX_HIPCHK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000; // gfx950: 100 MHz
+    h->head_start_ticks = (unsigned)((long long)microseconds * khz / 1000);
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (nchan)
+        *nchan = h->nchan;
+    if (max_items)
+        *max_items = h->max_items;
     return AISX_OK;
 }
 

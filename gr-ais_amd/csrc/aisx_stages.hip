@@ -168,6 +168,33 @@ extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, doub
     return AISX_OK;
 }
 
+extern "C" int aisx_freqsync_geometry(const aisx_freqsync* h, int* nchan, int* max_items, int* fftlen)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (nchan)
+        *nchan = h->nchan;
+    if (max_items)
+        *max_items = h->max_items;
+    if (fftlen)
+        *fftlen = h->fftlen;
+    return AISX_OK;
+}
+
+// forget what aisx_freqsync_estimate_ahead has queued (nothing of it was committed); `stream` = where the
+// next pass will run: it waits for the walks the dropped preparations still have in flight
+extern "C" int aisx_freqsync_drop_ahead(aisx_freqsync* h, void* stream)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (h->ahead_cnt > 0) {
+        h->ahead_cnt = 0;
+        if (h->walk_pending)
+            AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_walk, 0));
+    }
+    return AISX_OK;
+}
+
 extern "C" int aisx_freqest_create(aisx_freqsync** out, float sample_rate, int data_rate, int fftlen, int max_vectors)
 {
     // freqest::make(float sample_rate, int data_rate, int fftlen) (include/ais/freqest.h:46): the block alone,
@@ -400,6 +427,21 @@ struct aisx_agc {
     cf* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
 };
+
+extern "C" int aisx_agc_geometry(const aisx_agc* h, int* nchan, int* max_items, int* nsamples, int* fused_ok)
+{
+    if (h && fused_ok)
+        *fused_ok = agc8_applies(h->W) ? 1 : 0;
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (nchan)
+        *nchan = h->nchan;
+    if (max_items)
+        *max_items = h->max_items;
+    if (nsamples)
+        *nsamples = h->W;
+    return AISX_OK;
+}
 
 extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, int nchan, int max_items)
 {

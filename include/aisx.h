@@ -88,6 +88,7 @@ int aisx_corr_symbols(const aisx_corr* h, aisx_cf32* out, int cap);
  * multiple and mark_delay as :143-161 do (up to 2048 samples).  Must not be called
  * while a call on this handle is in flight (the reference holds d_setlock, :135). */
 int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int nsym);
+int aisx_corr_geometry(const aisx_corr* h, int* nchan, int* max_items); /* what aisx_corr_create was given */
 int aisx_corr_history(const aisx_corr* h);         /* history() = nsym + 1   (:95)  */
 int aisx_corr_output_multiple(const aisx_corr* h); /* fft_filter nsamples    (:84-85) */
 int aisx_corr_max_noutput_items(const aisx_corr* h); /* 24*1024              (:111-112) */
@@ -143,6 +144,7 @@ typedef struct aisx_msk aisx_msk;
  * AISX_ERR_OUT_OF_RANGE if gain <= 0 or osps not in {1,2} (impl :61,:82). */
 int aisx_msk_create(aisx_msk** h, float sps, float gain, float limit, int osps, int nchan, int max_items);
 int aisx_msk_destroy(aisx_msk* h);
+int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items); /* what aisx_msk_create was given */
 int aisx_msk_set_gain(aisx_msk* h, float gain); /* :80-84, AISX_ERR_OUT_OF_RANGE if gain <= 0 */
 float aisx_msk_get_gain(const aisx_msk* h);     /* :86-88 */
 int aisx_msk_set_limit(aisx_msk* h, float limit); /* :90-92 */
@@ -234,11 +236,16 @@ int aisx_msk_wait_tail(aisx_msk* h, void* stream);
  * fill every CU first and the recovery waits for a contiguous 90 KB until they drain (measured:
  * 1.6 ms of a 6 ms step, every other step).  A caller that pipelines the next step's sample passes
  * beside the recovery calls this on their stream right after aisx_msk_process_stream.  The first
- * call only arms the event (returns at once).  The event fires for both queues at the same instant;
- * a one-wave kernel that sleeps AISX_MSK_HEADSTART_US (environment, default 20) is queued on `stream`
- * behind the wait, so that the recovery kernel reaches the dispatcher first (without it: a race, and
- * 0.3 ms per 5.6 ms step when it is lost). */
+ * call only arms the event (returns at once).  An event wait and nothing else, unless
+ * aisx_msk_set_head_start has been called on the handle. */
 int aisx_msk_wait_prepass(aisx_msk* h, void* stream);
+/* The event of aisx_msk_wait_prepass fires for both queues at the same instant: which of them the
+ * dispatcher serves first is a race (0.3 ms per 5.6 ms step when the recovery kernel loses it).  With
+ * microseconds > 0, aisx_msk_wait_prepass also queues a one-wave kernel that sleeps that long on `stream`
+ * behind the wait (ticks of the constant-rate wall clock, hipDeviceAttributeWallClockRate), so that the
+ * recovery kernel gets there first.  Default 0: off.  aisx_chain_create switches it on for its own
+ * streams (20 us; environment AISX_MSK_HEADSTART_US, 0 = off). */
+int aisx_msk_set_head_start(aisx_msk* h, int microseconds);
 /* GNU Radio path (nchan == 1), host pointers as general_work() receives them
  * (impl :107-206): tags = the time_est tags get_tags_in_range would return or
  * any superset, nitems_read = nitems_read(0).  *consumed is what to pass to
@@ -260,6 +267,11 @@ typedef struct aisx_freqsync aisx_freqsync;
 int aisx_freqsync_create(aisx_freqsync** h, double samplerate, double bits_per_sec, int fftlen, int nchan,
                          int max_items);
 int aisx_freqsync_destroy(aisx_freqsync* h);
+int aisx_freqsync_geometry(const aisx_freqsync* h, int* nchan, int* max_items, int* fftlen);
+/* forget what aisx_freqsync_estimate_ahead has queued (nothing of it is committed before the pass it was
+ * made for); `stream`: where the next pass will run -- it waits for what the dropped preparations still
+ * have in flight */
+int aisx_freqsync_drop_ahead(aisx_freqsync* h, void* stream);
 /* freqest::make(sample_rate, data_rate, fftlen) (include/ais/freqest.h:46) for the block on its own
  * (nchan == 1, aisx_freqest_work / aisx_freqest_work_host): d_offset and d_binsize from the FLOAT sample
  * rate as lib/freqest_impl.cc:46-47 compute them (aisx_freqsync_create truncates it to an int first, as
@@ -296,6 +308,8 @@ int aisx_freqest_work_host(aisx_freqsync* h, int noutput_items, const aisx_cf32*
 typedef struct aisx_agc aisx_agc;
 int aisx_agc_create(aisx_agc** h, int nsamples, float reference, int nchan, int max_items);
 int aisx_agc_destroy(aisx_agc* h);
+/* what aisx_agc_create was given; *fused_ok: the window is one aisx_freqsync_agc_process serves */
+int aisx_agc_geometry(const aisx_agc* h, int* nchan, int* max_items, int* nsamples, int* fused_ok);
 int aisx_agc_reset(aisx_agc* h);
 /* the initial max_env of [GR] feedforward_agc_cc_impl::work: 1e-4 (default; GNU Radio 3.7/3.8
  * "float max_env = 1e-4; // avoid divide by zero, indirectly set max gain") or the 1e-12 of the
@@ -344,6 +358,9 @@ typedef struct aisx_chain aisx_chain;
  * setters, profiling go through them) and must outlive the chain; they must be fresh or reset
  * when the chain is created (it keeps count of the items stream_to_vector holds back), and while
  * a chain drives them they must not be called directly.  One thread at a time per chain.
+ * aisx_chain_create checks the handles against its own arguments (same nchan; corr / msk / agc sized for
+ * max_items + fftlen, freq_sync for max_items and the same fftlen; an AGC window the fused front end
+ * serves) and returns AISX_ERR_INVALID otherwise.
  * The chain owns four streams, AISX_CHAIN_DEPTH sets of inter-stage buffers and the events that
  * order them: the sample passes of step k + 1 (one stream) run beside the timing recovery of step
  * k (a strict recurrence per channel, on its own stream), its bit tail and the NCO phase walk of
@@ -365,7 +382,12 @@ int aisx_chain_depth(void);            /* AISX_CHAIN_DEPTH */
  * count, and the samples must not change in between -- a live source therefore runs one buffer
  * ahead: step k is issued when block k + 1 has arrived.  Without it (NULL) every step estimates
  * for itself: same results, the phase walk (~2 ms at 65536 items) no longer hidden.
- * d_in may be reused once aisx_chain_wait_input(step) has passed (d_in_next: its own step's). */
+ * d_in may be reused once aisx_chain_wait_input(step) has passed (d_in_next: its own step's).
+ * A step is NOT transactional: when it fails after its first stage call (a HIP error, a handle
+ * misused behind the chain's back), stages already issued have advanced their histories.  The chain
+ * then drops what was prepared ahead and refuses every further step (AISX_ERR_INVALID): reset the
+ * stage handles and create a new chain.  Argument errors are reported before anything is issued and
+ * leave the chain usable. */
 int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_stride, int n, const aisx_cf32* d_in_next,
                     long next_stride, int n_next, aisx_cf32* d_syms, uint8_t* d_bits, long out_stride, int* d_produced,
                     void* stream, long long* step);
@@ -380,6 +402,10 @@ int aisx_chain_synchronize(aisx_chain* h); /* everything issued so far has run *
  * AISX_CHAIN_DEPTH steps. */
 int aisx_chain_read_corr_output(aisx_chain* h, long long step, int chan0, int nch, aisx_cf32* d_dst, long dst_stride, int* n,
                                 void* stream);
+/* corr_est's tags of `step` on the host (as aisx_corr_read_tags_back, but by step number: steps whose
+ * front end emitted no whole vector made no corr_est call and have no tags).  Valid for the last
+ * AISX_CHAIN_DEPTH steps; synchronises `stream`. */
+int aisx_chain_read_tags(aisx_chain* h, long long step, aisx_tag* host_tags, int host_cap, int* ntags, void* stream);
 /* the chain's streams (0 sample passes, 1 timing recovery, 2 bit tail, 3 phase walk), e.g. to
  * read a stage handle's results in order with the step that produced them */
 void* aisx_chain_stream(aisx_chain* h, int which);

@@ -112,3 +112,17 @@ def test_hdlc_rejects_frames_without_room_for_the_fcs_and_nmea_padding_quirk():
         assert len(body) == 6 and body[-1] == "0" and s.split(",")[6].startswith("4*")
     s = ais_amd.pdu_to_nmea("A").msg_to_sentence(bytes([0xFF, 0xFF]))
     assert s.split(",")[5] == "ww" + chr((0xF0 - 256 + 48) & 0xFF) and s.split(",")[6].startswith("2*")
+
+
+def test_framing_helpers_do_not_import_torch():
+    """The host-only helpers (HDLC deframer, NMEA) load libaisx.so without importing torch on their account."""
+    import os
+    import subprocess
+    import sys
+
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr-ais_amd")
+    code = ("import sys; sys.path.insert(0, %r); import ais_amd; d = ais_amd.hdlc_deframer_bp(11, 64); "
+            "s = ais_amd.pdu_to_nmea('A').msg_to_sentence(b'abc'); "
+            "assert 'torch' not in sys.modules, 'torch imported'; print('ok', s)") % pkg
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]

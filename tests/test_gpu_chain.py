@@ -61,11 +61,13 @@ def _run_both(ais, stages, lens, xs, nchan, next_known, wrong_next_at=()):
             for j, (ra, ta, rb) in enumerate(pend):
                 if ra["produced"] is None:  # less than one fftlen-vector so far: nothing reaches corr_est
                     assert int(rb["produced"].abs().sum()) == 0
+                    assert len(b.step_tags(rb["step"])) == 0
                     continue
                 nbits += _same(ra, rb, nchan)
                 # (tags of a step whose front end emitted nothing are not in the rotation)
                 back = sum(1 for q in pend[j + 1:] if q[0]["produced"] is not None)
                 assert ta.tobytes() == b.preamble_detect.tags(back=back).tobytes(), (i, j)
+                assert ta.tobytes() == b.step_tags(rb["step"]).tobytes(), (i, j)  # ... by step number: no counting
             pend = []
     assert b.clockrec.last_status() == 0
     return nbits
@@ -163,3 +165,47 @@ def test_chain_argument_checks(ais):
         dem.corr_output(3)
     assert dem.corr_output(0, 1, 2).shape == (2, T)
 
+
+
+def test_chain_create_checks_the_borrowed_handles(ais):
+    """aisx_chain_create: a stage handle built for another channel count or a smaller capacity is refused
+    (AISX_ERR_INVALID -> ValueError) instead of writing past the chain's rows at the first step."""
+    import ctypes as C
+    from ais_amd import _lib
+
+    L = _lib.lib()
+    tmpl = np.ones(112, np.complex64)
+
+    def handles(nchan_corr=8, mi_msk=4096 + 1024, agc_w=512, fft_fs=1024):
+        fs, agc, corr, msk = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert L.aisx_freqsync_create(C.byref(fs), 38400.0, 9600.0, fft_fs, 8, 4096) == 0
+        assert L.aisx_agc_create(C.byref(agc), agc_w, 2.0, 8, 4096 + 1024) == 0
+        assert L.aisx_corr_create(C.byref(corr), tmpl.ctypes.data_as(C.c_void_p), 112, 4.0, 1, 0.9, nchan_corr, 4096 + 1024, 512) == 0
+        assert L.aisx_msk_create(C.byref(msk), 4.0, 0.04, 0.01, 1, 8, mi_msk) == 0
+        return fs, agc, corr, msk
+
+    def create(hs):
+        ch = C.c_void_p()
+        rc = L.aisx_chain_create(C.byref(ch), hs[0], hs[1], hs[2], hs[3], 8, 4096, 1024)
+        msg = L.aisx_last_error().decode()
+        if rc == 0:
+            L.aisx_chain_destroy(ch)
+        L.aisx_freqsync_destroy(hs[0]), L.aisx_agc_destroy(hs[1]), L.aisx_corr_destroy(hs[2]), L.aisx_msk_destroy(hs[3])
+        return rc, msg
+
+    assert create(handles())[0] == 0
+    rc, msg = create(handles(nchan_corr=16))
+    assert rc == _lib.AISX_ERR_INVALID and "corr_est" in msg and "nchan" in msg
+    rc, msg = create(handles(mi_msk=4096))
+    assert rc == _lib.AISX_ERR_INVALID and "msk_timing_recovery" in msg and "max_items" in msg
+    rc, msg = create(handles(agc_w=500))
+    assert rc == _lib.AISX_ERR_INVALID and "agc" in msg and "window" in msg
+
+
+def test_wait_prepass_is_an_event_wait_unless_a_head_start_is_asked_for(ais):
+    blk = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=4, max_items=4096)
+    from ais_amd import _lib
+
+    L = _lib.lib()
+    assert L.aisx_msk_set_head_start(blk._h, 20) == 0 and L.aisx_msk_set_head_start(blk._h, 0) == 0
+    assert L.aisx_msk_set_head_start(blk._h, -1) == _lib.AISX_ERR_INVALID
