@@ -171,6 +171,46 @@ AISX_HD void nco_sincos(float phase, const float* tab, float* s, float* c)
     *s = es.re * (float)(x >> 1) + es.im;
     *c = ec.re * (float)(xc >> 1) + ec.im;
 }
+
+// [GR] frequency_modulator_fc: d_phase = fmod(d_phase + pi, 2 pi) - pi.  fmod is an
+// exact operation; for |u| < 4 pi it is u or u -/+ 2 pi (exact by Sterbenz).
+AISX_HD float nco_wrap(float ph)
+{
+    const float F_PI = 3.14159265358979323846f;
+    const float TWO_PI = 2.0f * F_PI;
+    const float u = ph + F_PI;
+    float r;
+    const float au = fabsf(u);
+    if (au < TWO_PI)
+        r = u;
+    else if (au < 2.0f * TWO_PI)
+        r = (u > 0.f) ? (u - TWO_PI) : (u + TWO_PI);
+    else
+        r = fmodf(u, TWO_PI);
+    return r - F_PI;
+}
+
+// the same for |ph + pi| < 4 pi: u, or u -/+ 2 pi -- as selects
+AISX_HD float nco_wrap_small(float ph)
+{
+    const float F_PI = 3.14159265358979323846f;
+    const float TWO_PI = 2.0f * F_PI;
+    const float u = ph + F_PI;
+    const float w = u - copysignf(TWO_PI, u);
+    const float r = (fabsf(u) < TWO_PI) ? u : w;
+    return r - F_PI;
+}
+
+// The NCO phase walk (k_freqsync.h fs_walk_body) leaves every NCO_CK-th phase in memory; readers (k_agc.h) walk
+// the ones in between again.  2, 4 or 8: bytes per sample against the length of the dependent chains.
+#ifndef NCO_CKN
+#define NCO_CKN 8
+#endif
+constexpr int NCO_CK = NCO_CKN;
+static_assert(NCO_CK == 2 || NCO_CK == 4 || NCO_CK == 8, "checkpoints every 2, 4 or 8 items");
+// one step of the recurrence; `small`: |d| < 6 (then the fmod of the wrap is a select: the same value)
+AISX_HD float nco_phase_step(float ph, float d, bool small) { return small ? nco_wrap_small(ph + d) : nco_wrap(ph + d); }
+
 constexpr int NCO_TAB_FLOATS = 2048; // s_sine_table: 1024 x {slope, offset}
 
 // std::abs(std::complex<float>) as glibc's hypotf evaluates it

@@ -179,6 +179,30 @@ struct DevCtx {
     // `buffer_load_dwordx4 ... lds`: the data never passes through VGPRs, M0 carries the
     // wave-uniform destination.  The compiler does not see the transfer: it completes with
     // wait_dma() (vmcnt), and a barrier makes it visible to the other waves.
+    // Cache policy of these streaming transfers (every byte is read once, apart from the windows' overlap):
+    // AISX_DMA_POL = 0 none | 1 nt | 2 sc1 | 3 sc0 sc1 | 4 sc0 nt sc1 | 5 sc0 | 6 nt sc1 on the load, AISX_STORE_AUX = the aux bits of
+    // buf_store64 (1 sc0, 2 nt, 16 sc1).  Defaults: what measured best (DESIGN_APPENDIX.md).
+#ifndef AISX_DMA_POL
+#define AISX_DMA_POL 1
+#endif
+#if AISX_DMA_POL == 0
+#define AISX_DMA_POLICY ""
+#elif AISX_DMA_POL == 1
+#define AISX_DMA_POLICY " nt"
+#elif AISX_DMA_POL == 2
+#define AISX_DMA_POLICY " sc1"
+#elif AISX_DMA_POL == 3
+#define AISX_DMA_POLICY " sc0 sc1"
+#elif AISX_DMA_POL == 4
+#define AISX_DMA_POLICY " sc0 nt sc1"
+#elif AISX_DMA_POL == 5
+#define AISX_DMA_POLICY " sc0"
+#elif AISX_DMA_POL == 6
+#define AISX_DMA_POLICY " nt sc1"
+#endif
+#ifndef AISX_STORE_AUX
+#define AISX_STORE_AUX 2
+#endif
     __device__ __forceinline__ void dma16(const Buf& b, unsigned byte_off, unsigned lds_dst) const
     {
         v4i w;
@@ -188,10 +212,10 @@ struct DevCtx {
         w.w = 0x00020000;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
 #ifdef AISX_DMA_NOSAVE
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(byte_off), "s"(w), "s"(dst) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen" AISX_DMA_POLICY " lds" : : "v"(byte_off), "s"(w), "s"(dst) : "memory", "m0");
 #else
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" AISX_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(byte_off), "s"(w), "s"(dst)
                      : "memory");
@@ -235,7 +259,7 @@ struct DevCtx {
         d.x = __float_as_uint(v.re);
         d.y = __float_as_uint(v.im);
         __builtin_amdgcn_raw_buffer_store_b64(d, __builtin_amdgcn_make_buffer_rsrc((void*)b.base, 0, (int)b.nbytes, 0x00020000),
-                                              (int)voff, (int)soff, 0);
+                                              (int)voff, (int)soff, AISX_STORE_AUX);
     }
 };
 

@@ -77,7 +77,8 @@ struct aisx_freqsync {
     // still reads its own.
     struct Slot {
         int* d_maxpos = nullptr;
-        float* d_phases = nullptr;
+        float* d_phases = nullptr; // phi[c][8 j]: every eighth phase of the walk (FSW_CK)
+        float* d_dvec = nullptr;   // the phase increment of each vector
         float* d_fhat = nullptr;
         hipEvent_t ev_read = nullptr; // the last sample pass that read this slot
         bool read_pending = false;
@@ -223,6 +224,7 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
     for (int k = 0; k < 2; k++) {
         dev_free(h->slot[k].d_maxpos);
         dev_free(h->slot[k].d_phases);
+        dev_free(h->slot[k].d_dvec);
         dev_free(h->slot[k].d_fhat);
         if (h->slot[k].ev_read)
             (void)hipEventDestroy(h->slot[k].ev_read);
@@ -533,6 +535,8 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.ntiles = (n + TL - 1) / TL;
     p.phases = nullptr;
     p.phases_stride = 0;
+    p.dvec = nullptr;
+    p.dvec_stride = 0;
     p.sintab = nullptr;
     p.pend_in = nullptr;
     p.pend_out = nullptr;
@@ -567,7 +571,9 @@ static int fs_fused_prepare(aisx_freqsync* h)
         if (!s.d_fhat && (rc = dev_alloc(&s.d_fhat, (size_t)h->nchan * h->max_vec)) != AISX_OK)
             return rc;
         if (!s.d_phases) {
-            h->phases_stride = ((long)h->max_vec * h->fftlen + 3) & ~3L;
+            h->phases_stride = ((long)h->max_vec * (h->fftlen / FSW_CK) + 3) & ~3L;
+            if ((rc = dev_alloc(&s.d_dvec, (size_t)h->nchan * h->max_vec)) != AISX_OK)
+                return rc;
             if ((rc = dev_alloc(&s.d_phases, (size_t)h->nchan * (size_t)h->phases_stride, false)) != AISX_OK)
                 return rc;
         }
@@ -621,6 +627,8 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     w.phase_out = h->d_phase3[(h->phase_cur + depth + 1) % 3];
     w.phases = s.d_phases;
     w.phases_stride = h->phases_stride;
+    w.dvec = s.d_dvec;
+    w.dvec_stride = h->max_vec;
     w.nvec = nvec;
     w.binsize = h->binsize;
     w.sensitivity = h->sensitivity;
@@ -733,6 +741,8 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.ntiles = total > 0 ? (total + AGC8_TL - 1) / AGC8_TL : 1; // (a call without a whole vector still moves the pending items)
     p.phases = s.d_phases;
     p.phases_stride = h->phases_stride;
+    p.dvec = s.d_dvec;
+    p.dvec_stride = h->max_vec;
     p.sintab = h->d_sintab;
     p.pend_in = h->d_pend[h->cur];
     p.pend_out = h->d_pend[h->cur ^ 1];

@@ -35,7 +35,10 @@ struct AgcParams {
     // square_and_fft_sync_cc's output WITHOUT that output ever being stored: item m of it is
     // raw[m] * e^{j phases[m]} (python/gmsk_sync.py:26-28,33; the phases come from fs_walk_body,
     // k_freqsync.h), raw = the pending partial vector followed by the new samples `in`.
-    const float* phases; long phases_stride; // [nchan][n]
+    // `phases` holds the phase of every NCO_CK-th item (phi[NCO_CK j], fs_walk_body's checkpoints), `dvec` each
+    // vector's increment: the phases in between are walked again here (nco_phase_step, the walk's statement).
+    const float* phases; long phases_stride; // [nchan][n / NCO_CK]
+    const float* dvec; long dvec_stride;     // [nchan][n / 1024]
     const float* sintab;                     // gr::fxpt's sine table (NCO_TAB_FLOATS floats, aisx_tables.h)
     const cf* pend_in; cf* pend_out;         // [nchan][1024] pending partial vector in / out
     int npend, n_raw;                        // valid pending items; new raw samples per channel
@@ -189,10 +192,21 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     auto raw_item = [&](int m) -> cf { // raw sample m >= 0 behind the pending partial vector
         return (m < p.npend) ? pend[m] : xin[m - p.npend];
     };
+    const float* dv = mixed ? p.dvec + (long)c * p.dvec_stride : nullptr;
+    auto phase_at = [&](int m) -> float { // NCO phase of item m: from the checkpoint at or before it
+        float ph = phi[m / NCO_CK];
+        const float d = dv[m >> 10]; // (a checkpoint and the items behind it lie in one vector)
+        const bool small = fabsf(d) < 6.0f;
+#pragma nounroll
+        for (int k = m % NCO_CK; k > 0; k--)
+            ph = nco_phase_step(ph, d, small);
+        return ph;
+    };
     auto item = [&](int m) -> cf { // item m >= 0 of the block's input (needs the table in LDS)
-        return mixed ? mix(raw_item(m), phi[m]) : xin[m];
+        return mixed ? mix(raw_item(m), phase_at(m)) : xin[m];
     };
 
+    bool allsmall = true; // every phase increment this wave's groups meet is small (|d| < 6: nco_wrap_small applies)
     // One group in two steps, so that in the fused build every global load of the tile is in
     // flight before the barrier that publishes the sine table: (1) load -- raw samples and, where
     // they are still to be mixed, their NCO phases (mask `mx`); (2) mix, envelopes, prefix maxima
@@ -201,12 +215,22 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
         cf v[AGC8_G];
         float f[AGC8_G];
         unsigned mx;
+        float ck[AGC8_G / NCO_CK], d; // walk: f[] is still to be walked from the checkpoints with increment d (finish_group)
+        bool walk;
     };
     auto load_group = [&](int g, Grp& G) {
         const int s0 = base + g * AGC8_G;
         const int m0 = s0 - H; // first item of the group in the block's input
         G.mx = 0;
-        if (s0 >= H && g * AGC8_G + AGC8_G <= E && (!mixed || m0 >= p.npend)) { // wholly inside the new samples: 16-byte loads
+        G.walk = false;
+        G.d = 0.f;
+#pragma unroll
+        for (int i = 0; i < AGC8_G / NCO_CK; i++)
+            G.ck[i] = 0.f;
+        // wholly inside the new samples: 16-byte loads.  (A tile's last group looks at fewer than 8 items; where the
+        // row goes on behind them it still takes this path -- the envelopes of the others are zeroed in finish_group.)
+        const int avail = mixed ? p.npend + p.n_raw : n;
+        if (s0 >= H && (g * AGC8_G + AGC8_G <= E || m0 + AGC8_G <= avail) && (!mixed || m0 >= p.npend)) {
             const cf_pair_agc* src = (const cf_pair_agc*)(xin + (m0 - (mixed ? p.npend : 0)));
 #pragma unroll
             for (int k = 0; k < AGC8_G / 2; k++) {
@@ -215,14 +239,16 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                 G.v[2 * k + 1] = q.b;
             }
             if (mixed) {
-                // (the window is a multiple of 8, so m0 = 1 mod 8: phases m0 - 1 .. m0 + 6 are two
-                // aligned 16-byte quads, phase m0 + 7 opens the next one)
-                typedef float f4 __attribute__((vector_size(16)));
-                const f4* q4 = (const f4*)(phi + (m0 - 1));
-                const f4 a = q4[0], b = q4[1];
-                G.f[0] = a[1]; G.f[1] = a[2]; G.f[2] = a[3];
-                G.f[3] = b[0]; G.f[4] = b[1]; G.f[5] = b[2]; G.f[6] = b[3];
-                G.f[7] = phi[m0 + 7];
+                // (the window is a multiple of 8, so m0 = 1 mod 8: the checkpoint phi[m0 - 1] opens the group, every
+                // NCO_CK-th item behind it is one, and phi[m0 + 7] is its last item -- possibly the first of the next vector)
+                const int j = (m0 - 1) / NCO_CK;
+                const float d = dv[(m0 - 1) >> 10];
+#pragma unroll
+                for (int i = 0; i < AGC8_G / NCO_CK; i++)
+                    G.ck[i] = phi[j + i];
+                G.f[7] = phi[j + AGC8_G / NCO_CK];
+                G.d = d;
+                G.walk = true;
                 G.mx = 0xffu;
             }
         } else {
@@ -238,7 +264,15 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
                         G.v[k] = xin[s - H];
                     else {
                         G.v[k] = raw_item(s - H);
-                        G.f[k] = phi[s - H];
+                        // (one step from the item before it where that one was walked too: a group at the edge of a
+                        // tile must not cost its wave a walk per item)
+                        const int m = s - H;
+                        if (k > 0 && ((G.mx >> (k - 1)) & 1u) && m % NCO_CK != 0) {
+                            const float d = dv[m >> 10];
+                            G.f[k] = nco_phase_step(G.f[k - 1], d, fabsf(d) < 6.0f);
+                        } else {
+                            G.f[k] = phase_at(m);
+                        }
                         G.mx |= 1u << k;
                     }
                 }
@@ -250,6 +284,23 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
     auto finish_group = [&](int g, bool keep, Grp& G) {
         cf (&v)[AGC8_G] = G.v;
         if (mixed) {
+            if (G.walk) { // the phases between the checkpoints: the walk's statement again (k_freqsync.h); chains of NCO_CK - 1
+                const float d = G.d;
+                // item m0 + k is (k + 1) items behind the group's first checkpoint
+                auto chains = [&](auto wrap) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        if ((k + 1) % NCO_CK == 0)
+                            G.f[k] = G.ck[(k + 1) / NCO_CK];
+                        else
+                            G.f[k] = wrap((((k + 1) % NCO_CK == 1) ? G.ck[(k + 1) / NCO_CK] : G.f[k - 1]) + d);
+                    }
+                };
+                if (allsmall) // (always, for estimates inside the band: the wrap as a select, no branch)
+                    chains([](float x) { return nco_wrap_small(x); });
+                else
+                    chains([](float x) { return nco_wrap(x); });
+            }
 #pragma unroll
             for (int k = 0; k < AGC8_G; k++)
                 if ((G.mx >> k) & 1u)
@@ -299,6 +350,9 @@ AISX_DI void agc8_body(Ctx& cx, const AgcParams& p)
             for (int i = t; i < NCO_TAB_FLOATS / 4; i += AGC8_T) // (8 KB, L2-resident: two 16-byte loads per thread)
                 ((f4*)ST)[i] = ((const f4*)p.sintab)[i];
             cx.sync();
+            // (decided here, behind the barrier the loads fly over and where all lanes are present; wave-uniform)
+            const bool mine_small = (!have1 || !G1.walk || fabsf(G1.d) < 6.0f) && (!have2 || !G2.walk || fabsf(G2.d) < 6.0f);
+            allsmall = cx.ballot(!mine_small) == 0ull;
         }
         if (have1)
             finish_group(t, true, G1);

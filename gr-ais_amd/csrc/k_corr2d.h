@@ -63,11 +63,18 @@ AISX_DI void corr2d_main_body(Ctx& cx, const CorrParams& p)
     const cf* const myT = ldsT + (t & 7);
     auto tw2 = [&](int k2) -> cf { return ld8(myT + k2 * 8); };
 
-    unsigned vmask_int = 0; // value n1 of this thread is window item t + 128 n1: an output iff >= N
+    // value n1 of this thread is window item t + 128 n1: an output iff >= N.  Built where a hit needs it (from
+    // a copy of t the optimiser cannot trace: kept across the tile loop it cost the N = 112 build a spilled VGPR)
+    auto vmask_of = [&]() -> unsigned {
+        int tt = t;
+        cx.pin(tt);
+        unsigned m = 0;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; n1++)
-        if (t + CF_T * n1 >= N)
-            vmask_int |= 1u << n1;
+        for (int n1 = 0; n1 < 16; n1++)
+            if (tt + CF_T * n1 >= N)
+                m |= 1u << n1;
+        return m;
+    };
 
     const auto bin = cx.make_buf(xin, (unsigned)n * 8u);
     const auto bout = cx.make_buf(xout, (unsigned)n * 8u);
@@ -255,6 +262,7 @@ AISX_DI void corr2d_main_body(Ctx& cx, const CorrParams& p)
 #pragma unroll
                 for (int n1 = 0; n1 < 16; n1++)
                     hit |= (!(mag2(x[n1]) <= p.thresh)) ? (1u << n1) : 0u;
+                const unsigned vmask_int = vmask_of();
                 hit &= vmask_int;
                 corr_emit_hits(cx, p, hit, vmask_int, x, xcorr, abits, kb, CF_T);
             }

@@ -194,60 +194,35 @@ AISX_DI void fs_freqest_body(Ctx& cx, const FsFreqestParams& p)
     }
 }
 
-// [GR] frequency_modulator_fc: d_phase = fmod(d_phase + pi, 2 pi) - pi.  fmod is an
-// exact operation; for |u| < 4 pi it is u or u -/+ 2 pi (exact by Sterbenz).
-AISX_HD float nco_wrap(float ph)
-{
-    const float F_PI = 3.14159265358979323846f;
-    const float TWO_PI = 2.0f * F_PI;
-    const float u = ph + F_PI;
-    float r;
-    const float au = fabsf(u);
-    if (au < TWO_PI)
-        r = u;
-    else if (au < 2.0f * TWO_PI)
-        r = (u > 0.f) ? (u - TWO_PI) : (u + TWO_PI);
-    else
-        r = fmodf(u, TWO_PI);
-    return r - F_PI;
-}
-
-// the same for |ph + pi| < 4 pi: u, or u -/+ 2 pi -- as selects
-AISX_HD float nco_wrap_small(float ph)
-{
-    const float F_PI = 3.14159265358979323846f;
-    const float TWO_PI = 2.0f * F_PI;
-    const float u = ph + F_PI;
-    const float w = u - copysignf(TWO_PI, u);
-    const float r = (fabsf(u) < TWO_PI) ? u : w;
-    return r - F_PI;
-}
-
 // ---------------------------------------------------------------------------
 // The NCO phase walk on its own (fs_walk_body): the phases depend on the frequency estimates
 // only, not on the samples, so the recurrence can run apart from the mixing -- one lane per
-// channel, 64 channels per wave -- and leave phi[c][i] in memory; the mixing then has no order in
-// time any more and is done where the samples are read next (the AGC's load stage, k_agc.h).
+// channel, 64 channels per wave; the mixing then has no order in time any more and is done where
+// the samples are read next (the AGC's load stage, k_agc.h).
 // The walk is what fs_mix_body's wave 0 does, statement for statement (stale-maxpos rule
 // lib/freqest_impl.cc:68 vs :74, f = (float(maxpos) - fftlen/2) * binsize / 2 (:84), [GR]
-// frequency_modulator_fc's d_phase += k f; fmod wrap).  A wave keeps 64 steps of its 64 channels
-// in LDS and flushes them row by row: 256 contiguous bytes per channel and flush.
+// frequency_modulator_fc's d_phase += k f; fmod wrap).  It leaves every FSW_CK-th phase in memory
+// -- phi[c][FSW_CK j], 4 / FSW_CK bytes per sample instead of 4 -- and the per-vector increment d = k f:
+// the reader walks the phases in between again (the same statement, aisx_common.h nco_phase_step).  A
+// wave keeps FSW_BLK checkpoints of its 64 channels in LDS and flushes them row by row.
 constexpr int FSW_T = 64;
-// steps per flush.  Small on purpose: 3 KB of LDS per wave -- the walk is meant to run beside the
+constexpr int FSW_CK = NCO_CK; // samples per checkpoint (aisx_common.h)
+// checkpoints per flush.  Small on purpose: 3 KB of LDS per wave -- the walk is meant to run beside the
 // timing recovery (84 KB per workgroup) AND the correlator (72 KB) on the same CU, which leaves 4
 #ifndef FSW_BLK
 #define FSW_BLK 8
 #endif
 constexpr int FSW_PITCH = FSW_BLK + 4; // floats per LDS row (rows 16-byte aligned)
 constexpr int FSW_LDS_BYTES = FSW_T * FSW_PITCH * 4;
-static_assert(FS_F % FSW_BLK == 0 && FSW_BLK % 4 == 0 && FSW_BLK <= 64, "whole 16-byte quads, whole blocks per vector");
+static_assert(FS_F % (FSW_BLK * FSW_CK) == 0 && FSW_BLK % 4 == 0 && FSW_BLK <= 64, "whole 16-byte quads, whole blocks per vector");
 
 struct FsWalkParams {
     int nchan;
     const int* maxpos; long maxpos_stride; // [nchan][nvec] from fs_est_body
     float* fhat; long fhat_stride;         // optional [nchan][nvec]
     const float* phase_in; float* phase_out; // [nchan] NCO phase (d_phase) before / after (may be the same array)
-    float* phases; long phases_stride;     // [nchan][nvec * fftlen] out; stride a multiple of 4
+    float* phases; long phases_stride;     // [nchan][nvec * fftlen / FSW_CK] out: the phase of every FSW_CK-th item; stride a multiple of 4
+    float* dvec; long dvec_stride;         // [nchan][nvec] out: the phase increment of each vector's items
     int nvec;
     float binsize, sensitivity;
 };
@@ -260,7 +235,7 @@ AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
     const int cbase = cx.bx() * FSW_T;
     const int c = cbase + l;
     const bool live = c < p.nchan;
-    float* R = (float*)cx.lds(); // [64][FSW_PITCH]: row = channel of the wave, column = step of the block
+    float* R = (float*)cx.lds(); // [64][FSW_PITCH]: row = channel of the wave, column = checkpoint of the block
     float* mine = R + l * FSW_PITCH;
     float ph = live ? p.phase_in[c] : 0.f;
     unsigned int maxpos = 0; // freqest_impl.cc:68 -- initialised once per work() call
@@ -274,35 +249,33 @@ AISX_DI void fs_walk_body(Ctx& cx, const FsWalkParams& p)
             if (p.fhat)
                 p.fhat[(long)c * p.fhat_stride + v] = f;
             d = p.sensitivity * f;
+            p.dvec[(long)c * p.dvec_stride + v] = d;
         }
         // with |d| < 2 pi the fmod of the wrap is a select (nco_wrap_small); one wave-uniform
         // decision per vector keeps the recurrence free of branches
         const bool small = cx.ballot(!(fabsf(d) < 6.0f)) == 0ull;
-        for (int b = 0; b < FS_F / FSW_BLK; b++) {
+        for (int b = 0; b < FS_F / (FSW_BLK * FSW_CK); b++) {
             if (small) {
-#pragma unroll 4
-                for (int i = 0; i < FSW_BLK; i += 4) {
-                    ph4 q;
+#pragma unroll 2
+                for (int i = 0; i < FSW_BLK; i++) {
                     ph = nco_wrap_small(ph + d);
-                    q[0] = ph;
-                    ph = nco_wrap_small(ph + d);
-                    q[1] = ph;
-                    ph = nco_wrap_small(ph + d);
-                    q[2] = ph;
-                    ph = nco_wrap_small(ph + d);
-                    q[3] = ph;
-                    *(ph4*)(mine + i) = q;
+                    mine[i] = ph; // item FSW_CK j
+#pragma unroll
+                    for (int k = 1; k < FSW_CK; k++)
+                        ph = nco_wrap_small(ph + d);
                 }
             } else {
                 for (int i = 0; i < FSW_BLK; i++) {
                     ph = nco_wrap(ph + d);
                     mine[i] = ph;
+                    for (int k = 1; k < FSW_CK; k++)
+                        ph = nco_wrap(ph + d);
                 }
             }
             cx.wave_sync();
-            // flush: QPR lanes x 16 bytes cover one channel's FSW_BLK phases, 64 / QPR channels per pass
+            // flush: QPR lanes x 16 bytes cover one channel's FSW_BLK checkpoints, 64 / QPR channels per pass
             constexpr int QPR = FSW_BLK / 4;
-            const long col = (long)v * FS_F + b * FSW_BLK + 4 * (l % QPR);
+            const long col = (long)v * (FS_F / FSW_CK) + b * FSW_BLK + 4 * (l % QPR);
 #pragma unroll 4
             for (int pass = 0; pass < QPR; pass++) {
                 const int r = pass * (FSW_T / QPR) + l / QPR;

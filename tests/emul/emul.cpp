@@ -685,7 +685,7 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.in = in; p.in_stride = in_stride; p.out = out; p.out_stride = out_stride;
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = agc8_applies(h->W) ? (n + AGC8_TL - 1) / AGC8_TL : (n + AGC_TL - 1) / AGC_TL;
-    p.phases = nullptr; p.phases_stride = 0; p.sintab = nullptr; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
+    p.phases = nullptr; p.phases_stride = 0; p.dvec = nullptr; p.dvec_stride = 0; p.sintab = nullptr; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
     if (agc8_applies(p.W))
         run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else
@@ -751,8 +751,8 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
     EmuFs* h = (EmuFs*)fv;
     EmuAgc* a = (EmuAgc*)av;
     const int nvec = (h->npend + n) / FS_F, total = nvec * FS_F;
-    const long pstride = ((long)h->max_vec * FS_F + 3) & ~3L;
-    std::vector<float> phases((size_t)h->nchan * pstride);
+    const long pstride = ((long)h->max_vec * (FS_F / FSW_CK) + 3) & ~3L;
+    std::vector<float> phases((size_t)h->nchan * pstride), dvec((size_t)h->nchan * h->max_vec);
     if (nvec > 0) {
         FsEstParams e;
         e.in = in; e.in_stride = in_stride; e.pend = h->pend[h->cur].data(); e.npend = h->npend; e.wtab = h->wtab.data();
@@ -760,7 +760,7 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
         run_grid((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
         FsWalkParams w;
         w.nchan = h->nchan; w.maxpos = h->maxpos.data(); w.maxpos_stride = h->max_vec; w.fhat = fhat; w.fhat_stride = fhat_stride;
-        w.phase_in = h->phase.data(); w.phase_out = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.nvec = nvec; w.binsize = h->binsize;
+        w.phase_in = h->phase.data(); w.phase_out = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.dvec = dvec.data(); w.dvec_stride = h->max_vec; w.nvec = nvec; w.binsize = h->binsize;
         w.sensitivity = h->sens;
         run_grid((h->nchan + FSW_T - 1) / FSW_T, 1, FSW_T, FSW_LDS_BYTES, [&](EmuCtx& cx) { fs_walk_body(cx, w); });
     }
@@ -769,7 +769,7 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
     p.hist_in = a->hist[a->cur].data(); p.hist_out = a->hist[a->cur ^ 1].data();
     p.n = total; p.W = a->W; p.reference = a->ref; p.floor_env = AGC_FLOOR_DEFAULT;
     p.ntiles = total > 0 ? (total + AGC8_TL - 1) / AGC8_TL : 1;
-    p.phases = phases.data(); p.phases_stride = pstride; p.sintab = &aisx_sine_table[0][0]; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
+    p.phases = phases.data(); p.phases_stride = pstride; p.dvec = dvec.data(); p.dvec_stride = h->max_vec; p.sintab = &aisx_sine_table[0][0]; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
     p.npend = h->npend; p.n_raw = n;
     run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
     h->npend = h->npend + n - total;

@@ -2,8 +2,8 @@
 """A/B runs of bench.py with alternative builds of libaisx.so on ONE GPU box (box-to-box the
 step time moves by about 1 %, more than most kernel changes are worth):
 
-    hipcc ... -o exp/libaisx_a.so ...; hipcc ... -o exp/libaisx_b.so ...
-    gpurun -- 'for v in a b a b; do python tools/ab_bench.py exp/libaisx_$v.so --no-cpu-baseline | tail -1; done'
+    hipcc ... -o tools/scratch/libaisx_a.so ...; hipcc ... -o tools/scratch/libaisx_b.so ...
+    gpurun -- 'for v in a b a b; do python tools/ab_bench.py tools/scratch/libaisx_$v.so --no-cpu-baseline | tail -1; done'
 
 Everything after the library path goes to bench.py unchanged."""
 import os

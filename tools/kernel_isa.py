@@ -36,8 +36,12 @@ def main(path, sub=""):
             elif i.startswith("s_"):
                 c["salu"] += 1
         res = {}
-        k = txt.find(".name:           %s\n" % name)
-        meta = txt[max(0, k - 1500):k + 1500] if k >= 0 else ""
+        # the kernel's own entry of amdhsa.kernels (entries start with "  - .agpr_count" or "  - .args")
+        meta = ""
+        for entry in re.split(r"\n  - \.a", txt[txt.find("amdhsa.kernels"):]):
+            if re.search(r"\.name:\s+%s\n" % re.escape(name), entry):
+                meta = entry
+                break
         for key in ("vgpr_count", "agpr_count", "sgpr_count", "group_segment_fixed_size", "vgpr_spill_count", "private_segment_fixed_size"):
             mm = re.search(r"\.%s:\s*(\d+)" % key, meta)
             if mm:

@@ -1,15 +1,15 @@
 #!/bin/bash
-# tools/mkvariant.sh NAME TU "FLAGS": exp/libaisx_NAME.so = the product library with translation
+# tools/mkvariant.sh NAME TU "FLAGS": tools/scratch/libaisx_NAME.so = the product library with translation
 # unit TU (aisx_lib | aisx_msk | aisx_stages | aisx_chain) rebuilt with extra compiler FLAGS (for tools/ab_bench.py)
 set -e
 cd "$(dirname "$0")/../gr-ais_amd"
 make -s
 name=$1; tu=$2; flags=$3
-mkdir -p ../exp/obj
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $flags -c -o ../exp/obj/${tu}_${name}.o csrc/${tu}.hip
+mkdir -p ../tools/scratch/obj
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $flags -c -o ../tools/scratch/obj/${tu}_${name}.o csrc/${tu}.hip
 objs=""
 for o in aisx_lib aisx_msk aisx_stages aisx_chain; do
-  if [ $o = $tu ]; then objs="$objs ../exp/obj/${tu}_${name}.o"; else objs="$objs build/$o.hip.o"; fi
+  if [ $o = $tu ]; then objs="$objs ../tools/scratch/obj/${tu}_${name}.o"; else objs="$objs build/$o.hip.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../exp/libaisx_${name}.so $objs build/aisx_framing.cpp.o
-echo exp/libaisx_${name}.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../tools/scratch/libaisx_${name}.so $objs build/aisx_framing.cpp.o
+echo tools/scratch/libaisx_${name}.so
