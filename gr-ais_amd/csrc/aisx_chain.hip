@@ -19,7 +19,6 @@ struct aisx_chain {
     int serial = 0; // AISX_CHAIN_SERIAL: every stage on s_main (A/B runs)
     // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead
     hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr;
-    hipStream_t s_res = nullptr; // (AISX_CHAIN_RESOLVE_STREAM=1) corr_est's resolver of step k beside the estimates of step k + 2
     hipStream_t s_est = nullptr; // (AISX_CHAIN_EST_STREAM=1) the frequency estimates of the steps ahead, beside the sample passes
     long long corr_calls = 0;          // aisx_corr_process calls made so far
     long long corr_call_of[8] = { 0 }; // [step % NBUF]: corr_calls behind that step's call, 0 for a step without one
@@ -49,9 +48,7 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
-    if (h->corr && h->s_res)
-        (void)aisx_corr_set_resolve_stream(h->corr, nullptr);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est, h->s_res })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est })
         if (s)
             (void)hipStreamSynchronize(s);
     dev_free(h->d_y);
@@ -63,7 +60,7 @@ static void chain_free(aisx_chain* h)
     }
     if (h->ev_in)
         (void)hipEventDestroy(h->ev_in);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est, h->s_res })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est })
         if (s)
             (void)hipStreamDestroy(s);
     delete h;
@@ -174,14 +171,6 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         CKH(tail_with_msk ? make(&h->s_tail, 0, msk_cus) : make(&h->s_tail, msk_cus, ncu));
         CKH(walk_with_msk ? make(&h->s_walk, 0, msk_cus) : make(&h->s_walk, msk_cus, ncu));
         h->msk_cus = msk_cus;
-        // AISX_CHAIN_RESOLVE_STREAM=1: corr_est's resolver of step k on a stream of its own, beside the estimates of
-        // step k + 2 (measured: the step gets LONGER, 6.05 against 5.72 ms -- the small kernel the recovery waits for
-        // then shares the dispatcher with a kernel of thousands of workgroups; 6.68 with a high-priority stream)
-        bool res_stream = false;
-        if (const char* e = getenv("AISX_CHAIN_RESOLVE_STREAM"))
-            res_stream = !h->serial && atoi(e) != 0;
-        if (res_stream)
-            CKH(make(&h->s_res, msk_cus, ncu));
         if (const char* e = getenv("AISX_CHAIN_EST_STREAM"))
             if (atoi(e) != 0 && !h->serial && fs)
                 CKH(make(&h->s_est, msk_cus, ncu));
@@ -205,10 +194,6 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             chain_free(h);
             return rc;
         }
-    if (h->s_res && (rc = aisx_corr_set_resolve_stream(corr, h->s_res)) != AISX_OK) {
-        chain_free(h);
-        return rc;
-    }
     if (!h->serial) {
         // the bit tail of step k beside the recovery of step k + 1; the next step's sample passes
         // behind this step's tag prepass (aisx_msk_wait_prepass: the first call arms the event)
@@ -303,9 +288,6 @@ static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride
             if (d_in_next && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, se, sw)) != AISX_OK)
                 return rc;
         }
-        // (the resolver of the previous step, on its own stream, reads d_y once more)
-        if ((rc = aisx_corr_wait_resolve(h->corr, sm)) != AISX_OK)
-            return rc;
         int nout = 0;
         if ((rc = aisx_freqsync_agc_process(h->fs, h->agc, d_in, in_stride, n, (aisx_cf32*)h->d_y, h->y_stride, nullptr, 0, &nout,
                                             sm)) != AISX_OK)
@@ -343,8 +325,7 @@ static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride
         int tcap = 0;
         if ((rc = aisx_corr_tags_device(h->corr, &tags, &counts, &tcap)) != AISX_OK)
             return rc;
-        // the step's input is free and its tags are complete behind the resolver
-        AISX_HIPCHK(hipEventRecord(h->ev_ready[par], h->s_res ? h->s_res : sm));
+        AISX_HIPCHK(hipEventRecord(h->ev_ready[par], sm));
         if (sk != sm)
             AISX_HIPCHK(hipStreamWaitEvent(sk, h->ev_ready[par], 0));
         // (ev_ready: what the time-parallel recovery's units wait for on their own stream -- they need this
@@ -439,7 +420,7 @@ extern "C" int aisx_chain_synchronize(aisx_chain* h)
 {
     if (!h)
         return AISX_ERR_INVALID;
-    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail, h->s_est, h->s_res })
+    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail, h->s_est })
         if (s)
             AISX_HIPCHK(hipStreamSynchronize(s));
     return AISX_OK;

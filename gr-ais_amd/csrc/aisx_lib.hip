@@ -250,10 +250,6 @@ struct aisx_corr {
     int prof = 0; // aisx_corr_set_profiling
     static constexpr int NEV = 64; // ring of event pairs: one per call, read back after the timed region
     hipEvent_t ev0[NEV] = {}, ev1[NEV] = {};
-    // aisx_corr_set_resolve_stream: the resolver of a call on a stream of its own, beside what the caller queues next
-    hipStream_t s_resolve = nullptr;
-    hipEvent_t ev_main = nullptr, ev_res = nullptr;
-    bool res_pending = false;
     long ncalls_prof = 0;
     // GNU Radio path staging
     cf *d_st_in = nullptr, *d_st_out = nullptr, *d_st_corr = nullptr;
@@ -369,9 +365,6 @@ extern "C" int aisx_corr_destroy(aisx_corr* h)
     dev_free(h->d_st_in);
     dev_free(h->d_st_out);
     dev_free(h->d_st_corr);
-    for (hipEvent_t e : { h->ev_main, h->ev_res })
-        if (e)
-            (void)hipEventDestroy(e);
     for (int k = 0; k < aisx_corr::NEV; k++) {
         if (h->ev0[k])
             (void)hipEventDestroy(h->ev0[k]);
@@ -537,8 +530,6 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         nseg = (ntiles + tps - 1) / tps;
     }
 
-    if (h->res_pending) // the previous call's resolver (on its own stream) still reads the hit bits and the scratch row
-        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_res, 0));
     AISX_HIPCHK(hipMemsetAsync(h->d_abits, 0, sizeof(unsigned long long) * (size_t)h->nchan * h->abits_stride, st));
     CorrParams p;
     p.in = (const cf*)d_in;
@@ -609,47 +600,12 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.tag_cap = h->tag_cap;
     r.tag_count = h->d_tag_count;
     r.atan_tab = h->d_atan;
-    hipStream_t sr = st;
-    if (h->s_resolve) {
-        sr = h->s_resolve;
-        AISX_HIPCHK(hipEventRecord(h->ev_main, st));
-        AISX_HIPCHK(hipStreamWaitEvent(sr, h->ev_main, 0));
-    }
-    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, sr, r);
+    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
     AISX_HIPCHK(hipGetLastError());
-    if (h->s_resolve) {
-        AISX_HIPCHK(hipEventRecord(h->ev_res, sr));
-        h->res_pending = true;
-    }
     h->hist_cur ^= 1;
     h->corr_hist_zero = 0;
     h->written += (uint64_t)n;
     h->last_emit_port1 = r.emit_port1;
-    return AISX_OK;
-}
-
-extern "C" int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (h->res_pending) { // (switching over: what is in flight ends first)
-        AISX_HIPCHK(hipEventSynchronize(h->ev_res));
-        h->res_pending = false;
-    }
-    if (resolve_stream && !h->ev_main) {
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-        AISX_HIPCHK(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
-    }
-    h->s_resolve = (hipStream_t)resolve_stream;
-    return AISX_OK;
-}
-
-extern "C" int aisx_corr_wait_resolve(aisx_corr* h, void* stream)
-{
-    if (!h)
-        return AISX_ERR_INVALID;
-    if (h->res_pending)
-        AISX_HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->ev_res, 0));
     return AISX_OK;
 }
 
@@ -715,8 +671,6 @@ extern "C" int aisx_corr_read_tags_back(aisx_corr* h, int back, aisx_tag* host_t
     const tag_rec* d_tags = h->d_tags2[bi];
     const int* d_tag_count = h->d_tag_count2[bi];
     hipStream_t st = (hipStream_t)stream;
-    if (h->res_pending) // (the resolvers run on a stream of their own, in order: the last one done, all are)
-        AISX_HIPCHK(hipStreamWaitEvent(st, h->ev_res, 0));
     std::vector<int> counts(h->nchan);
     AISX_HIPCHK(hipMemcpyAsync(counts.data(), d_tag_count, sizeof(int) * h->nchan, hipMemcpyDeviceToHost, st));
     AISX_HIPCHK(hipStreamSynchronize(st));

@@ -108,15 +108,6 @@ int aisx_corr_reset(aisx_corr* h); /* zero history, nitems_written = 0 */
  * aisx_corr_read_tags). */
 int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride,
                       aisx_cf32* d_corr, long corr_stride, int n, void* stream);
-/* The resolver (the climb, the centre of mass and the seven tags per hit: a small kernel behind the main
- * one) of every following aisx_corr_process call runs on `resolve_stream` instead of the call's stream,
- * which is then free for what the caller queues next (the chain: the next step's frequency estimates).
- * d_out is complete on the call's stream as before; the TAGS are complete on resolve_stream:
- * aisx_corr_wait_resolve makes another stream wait for them (the call's stream, before it overwrites d_in,
- * which the resolver reads once more; the consumer of aisx_corr_tags_device).  aisx_corr_read_tags* wait by
- * themselves, and so does the next aisx_corr_process.  NULL: off (default), everything on the call's stream. */
-int aisx_corr_set_resolve_stream(aisx_corr* h, void* resolve_stream);
-int aisx_corr_wait_resolve(aisx_corr* h, void* stream);
 /* measurement hook: when on, aisx_corr_process brackets the main correlator
  * kernel with hipEvents on the launch stream; aisx_corr_last_kernel_ms waits for
  * the last bracket and returns its duration. */

@@ -209,16 +209,3 @@ def test_wait_prepass_is_an_event_wait_unless_a_head_start_is_asked_for(ais):
     L = _lib.lib()
     assert L.aisx_msk_set_head_start(blk._h, 20) == 0 and L.aisx_msk_set_head_start(blk._h, 0) == 0
     assert L.aisx_msk_set_head_start(blk._h, -1) == _lib.AISX_ERR_INVALID
-
-
-def test_chain_experiment_streams_give_the_same_results(ais, monkeypatch):
-    """AISX_CHAIN_RESOLVE_STREAM / AISX_CHAIN_EST_STREAM (off by default: measured slower): corr_est's resolver and the
-    frequency estimates on streams of their own (aisx_corr_set_resolve_stream) -- the results must not move."""
-    from ais_amd import synth
-
-    monkeypatch.setenv("AISX_CHAIN_RESOLVE_STREAM", "1")
-    monkeypatch.setenv("AISX_CHAIN_EST_STREAM", "1")
-    nchan = 40
-    lens = [4096, 4096, 700, 8192, 4096, 1024, 3000, 4096]
-    xs = np.stack([synth.make_channel(70 + c, sum(lens), "S", 4, amp=1.0, cfo_max=300.0)[0] for c in range(nchan)])
-    assert _run_both(ais, "stock", lens, xs, nchan, next_known=lambda i: i % 3 != 2) > 0
