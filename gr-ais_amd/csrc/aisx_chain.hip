@@ -19,7 +19,6 @@ struct aisx_chain {
     int serial = 0; // AISX_CHAIN_SERIAL: every stage on s_main (A/B runs)
     // streams: sample passes | timing recovery | its bit tail | NCO phase walk one step ahead
     hipStream_t s_main = nullptr, s_msk = nullptr, s_tail = nullptr, s_walk = nullptr;
-    hipStream_t s_est = nullptr; // (AISX_CHAIN_EST_STREAM=1) the frequency estimates of the steps ahead, beside the sample passes
     long long corr_calls = 0;          // aisx_corr_process calls made so far
     long long corr_call_of[8] = { 0 }; // [step % NBUF]: corr_calls behind that step's call, 0 for a step without one
     bool failed = false;               // a step failed half way: see aisx_chain_step
@@ -48,7 +47,7 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamSynchronize(s);
     dev_free(h->d_y);
@@ -60,7 +59,7 @@ static void chain_free(aisx_chain* h)
     }
     if (h->ev_in)
         (void)hipEventDestroy(h->ev_in);
-    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk, h->s_est })
+    for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamDestroy(s);
     delete h;
@@ -171,9 +170,6 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         CKH(tail_with_msk ? make(&h->s_tail, 0, msk_cus) : make(&h->s_tail, msk_cus, ncu));
         CKH(walk_with_msk ? make(&h->s_walk, 0, msk_cus) : make(&h->s_walk, msk_cus, ncu));
         h->msk_cus = msk_cus;
-        if (const char* e = getenv("AISX_CHAIN_EST_STREAM"))
-            if (atoi(e) != 0 && !h->serial && fs)
-                CKH(make(&h->s_est, msk_cus, ncu));
     }
     CKH(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     for (int k = 0; k < aisx_chain::NBUF; k++) {
@@ -279,13 +275,10 @@ static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride
         const bool stale = h->ahead_in != nullptr && !prepared;
         const bool early = !h->serial && !stale && h->npend == 0 && n % h->fftlen == 0;
         hipStream_t sw = h->serial ? sm : h->s_walk;
-        hipStream_t se = h->s_est ? h->s_est : sm;
-        if (h->s_est)
-            AISX_HIPCHK(hipStreamWaitEvent(se, h->ev_in, 0));
         if (early) {
             if (!prepared && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in, in_stride, n, sm, sw)) != AISX_OK)
                 return rc;
-            if (d_in_next && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, se, sw)) != AISX_OK)
+            if (d_in_next && (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, sm, sw)) != AISX_OK)
                 return rc;
         }
         int nout = 0;
@@ -295,7 +288,7 @@ static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride
         h->npend = h->npend + n - nout;
         h->ahead_in = nullptr;
         if (!early && !h->serial && d_in_next &&
-            (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, se, sw)) != AISX_OK)
+            (rc = aisx_freqsync_estimate_ahead(h->fs, d_in_next, next_stride, n_next, sm, sw)) != AISX_OK)
             return rc;
         if (d_in_next && !h->serial) {
             h->ahead_in = d_in_next;
@@ -340,8 +333,6 @@ static int chain_step_issue(aisx_chain* h, const aisx_cf32* d_in, long in_stride
         // the next step's sample passes start behind this step's tag prepass, i.e. when the recovery
         // kernel stands at the head of its queue (aisx_msk_wait_prepass; include/aisx.h)
         if (!h->serial && (rc = aisx_msk_wait_prepass(h->msk, sm)) != AISX_OK)
-            return rc;
-        if (h->s_est && (rc = aisx_msk_wait_prepass(h->msk, h->s_est)) != AISX_OK)
             return rc;
     }
     h->m_of[par] = m;
@@ -420,9 +411,8 @@ extern "C" int aisx_chain_synchronize(aisx_chain* h)
 {
     if (!h)
         return AISX_ERR_INVALID;
-    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail, h->s_est })
-        if (s)
-            AISX_HIPCHK(hipStreamSynchronize(s));
+    for (hipStream_t s : { h->s_main, h->s_walk, h->s_msk, h->s_tail })
+        AISX_HIPCHK(hipStreamSynchronize(s));
     return AISX_OK;
 }
 
