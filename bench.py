@@ -113,7 +113,7 @@ def pmc_traffic(nchan, T, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     summary (collected in separate --pmc passes, see profiles/), if it was taken on
     this workload; (None, None) otherwise."""
-    for name in ("r03_corr_main_pmc.json", "r02_corr_main_pmc.json", "r01_corr_main_pmc.json"):
+    for name in ("r04_corr_main_pmc.json", "r04_corr2d_main_pmc.json", "r03_corr_main_pmc.json", "r02_corr_main_pmc.json", "r01_corr_main_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(path))
