@@ -211,33 +211,11 @@ struct DevCtx {
         w.z = (int)b.nbytes;
         w.w = 0x00020000;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-#ifdef AISX_DMA_NOSAVE
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen" AISX_DMA_POLICY " lds" : : "v"(byte_off), "s"(w), "s"(dst) : "memory", "m0");
-#else
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" AISX_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(byte_off), "s"(w), "s"(dst)
                      : "memory");
-#endif
-    }
-    // four such transfers into four consecutive KiB of LDS with ONE setting of M0 (experiment)
-    __device__ __forceinline__ void dma16x4(const Buf& b, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) const
-    {
-        v4i w;
-        w.x = (int)(unsigned)(size_t)b.base;
-        w.y = (int)(unsigned)(((size_t)b.base >> 32) & 0xffffu);
-        w.z = (int)b.nbytes;
-        w.w = 0x00020000;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %0, %4, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %1, %4, 0 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %2, %4, 0 offen offset:2048 lds\n\t"
-                     "buffer_load_dwordx4 %3, %4, 0 offen offset:3072 lds"
-                     :
-                     : "v"(o0), "v"(o1 - 1024u), "v"(o2 - 2048u), "v"(o3 - 3072u), "s"(w), "s"(dst)
-                     : "memory", "m0");
     }
     // all of this wave's vector-memory operations (DMA included) have completed
     __device__ __forceinline__ void wait_dma() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -445,10 +445,6 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     };
 
     // ---- the rings: progress = row offset - org; block B = progress [8B, 8B + 8)
-#ifdef MSKP_PROF
-    long long pf_dma = 0;
-    long pf_ndma = 0;
-#endif
     int org = 0;
     int L = 0; // blocks readable so far (wave-uniform): progress [8 (L + MSKP_D - MSKP_NB), 8 L); MSKP_D more are in flight
     auto fetch = [&](int r) -> cf {
@@ -500,15 +496,6 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         for (int h = 0; h < MSKP_BS / 8; h++) { // eight samples of every lane at a time
             const int p0 = MSKP_BS * B + 8 * h; // progress of the first of them
             const int row0 = (p0 >> 1) & (MSKP_ROWS - 1);
-#ifdef MSKP_EXP_M0ONCE
-            { // (timing experiment: wrong placement)
-                unsigned o[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    o[j] = s_base[j] + (unsigned)(p0 + 2 * q) * 8u;
-                cx.dma16x4(inbuf, o[0], o[1], o[2], o[3], cx.lds_addr(ring_b + row0 * 256));
-            }
-#else
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (j >= ngrp)
@@ -525,15 +512,12 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
                 } else if (cx.ballot(fast) != 0ull) {
                     if (fast) {
                         const unsigned off = s_base[j] + (unsigned)(p0 + 2 * q) * 8u;
-#ifndef MSKP_NODMA
                         cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + row0 * 256));
-#endif
                         if (row0 == 0)
                             cx.dma16(inbuf, off, cx.lds_addr(ring_b + j * MSKP_GRP_B + MSKP_ROWS * 256));
                     }
                 }
             }
-#endif
             const int r0 = org + p0;
             const bool slow = JOIN && valid && running && !(r0 >= 0 && r0 + 8 <= n);
             if (JOIN && cx.ballot(slow) != 0ull) {
@@ -1112,16 +1096,8 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
     // ---- the recurrence
     bool all_done = false;
     int since_walk = 0, since_flush = 0;
-#ifdef MSKP_PROF
-    long long pf_t0 = __builtin_readcyclecounter(), pf_wait = 0, pf_issue = 0, pf_trip = 0, pf_walk = 0;
-    long pf_epochs = 0, pf_trips = 0, pf_lanes = 0, pf_kind[4] = { 0, 0, 0, 0 };
-    long long pf_run8 = 0;
-#define PFB long long pf_a = __builtin_readcyclecounter();
-#define PFE(acc) acc += __builtin_readcyclecounter() - pf_a;
-#else
 #define PFB
 #define PFE(acc)
-#endif
     while (!all_done) {
         // block L has arrived when at most the MSKP_D - 1 younger blocks (four transfers each; whatever
         // else is in flight is younger still) are outstanding; then the next one goes out, into the
@@ -1133,9 +1109,6 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
         { PFB
         issue_block(L + MSKP_D - 1);
         PFE(pf_issue) }
-#ifdef MSKP_PROF
-        pf_epochs++;
-#endif
         for (;;) {
             // lanes waiting at a junction are served when nobody runs any more, or every
             // MSKP_WALK_EVERY trips (the walk reads records from memory: the whole wave waits)
@@ -1157,53 +1130,23 @@ AISX_DI void mskp_body(Ctx& cx, const MskpParams& p)
             { PFB
             const int npairs = fast_run_pairs();
             if (npairs == 8) {
-#ifdef MSKP_PROF
-                const long long r0 = __builtin_readcyclecounter();
-#endif
                 run_pairs(8);
-#ifdef MSKP_PROF
-                pf_run8 += __builtin_readcyclecounter() - r0;
-#endif
             } else if (npairs == 4)
                 run_pairs(4);
             else if (npairs == 2)
                 run_pairs(2);
             if (npairs == 0 || single) {
-#ifdef MSKP_PROF
-                const long long r0 = __builtin_readcyclecounter();
-#endif
                 if (!fast_trip())
                     trip();
-#ifdef MSKP_PROF
-                pf_dma += __builtin_readcyclecounter() - r0;
-                pf_ndma++;
-#endif
             }
-#ifdef MSKP_PROF
-            pf_kind[npairs == 8 ? 0 : (npairs == 4 ? 1 : (npairs == 2 ? 2 : 3))]++;
-#endif
             since_flush += npairs + 1;
             PFE(pf_trip) }
-#ifndef MSKP_EXP_NOFLUSH
             if (since_flush >= 4) { // (at most 7 symbols wait in a lane's stage behind a flush, a run adds 8)
                 since_flush = 0;
                 flush_syms();
             }
-#else
-            flushed = cnt & ~7;
-#endif
-#ifdef MSKP_PROF
-            pf_trips++;
-            pf_lanes += aisx_popc64(cx.ballot(running));
-#endif
         }
     }
-#ifdef MSKP_PROF
-    if (lane == 0 && JOIN && pf_epochs > 1300)
-        printf("mskp prof %s wave %d: singles %lld / %ld run8 %lld cycles %lld wait %lld issue %lld trip %lld walk %lld | epochs %ld trips %ld running-lane-trips %ld | run8 %ld run4 %ld run2 %ld none %ld\n",
-               JOIN ? "join" : "units", wv, pf_dma, pf_ndma, pf_run8, (long long)(__builtin_readcyclecounter() - pf_t0), pf_wait, pf_issue, pf_trip, pf_walk,
-               pf_epochs, pf_trips, pf_lanes, pf_kind[0], pf_kind[1], pf_kind[2], pf_kind[3]);
-#endif
     cx.template wait_vm<0>();
 
     if (!valid)
