@@ -1,6 +1,6 @@
 /* Export macro of the gr::ais blocks built over libaisx.so (role of the reference's include/ais/api.h). */
-#ifndef INCLUDED_AIS_API_H
-#define INCLUDED_AIS_API_H
+#ifndef AISX_GR_AIS_API_H
+#define AISX_GR_AIS_API_H
 
 #include <gnuradio/attributes.h>
 

@@ -3,21 +3,20 @@
  * of the sync word and tagged corr_start / phase_est / time_est / corr_est, port 1 = the correlator
  * output).  Flowgraphs, GRC files and python/ais_demod.py:39-42 keep working unchanged; what changes
  * is lib/corr_est_cc_impl.cc, whose work() runs on the MI355X through libaisx.so. */
-#ifndef INCLUDED_AIS_CORR_EST_CC_H
-#define INCLUDED_AIS_CORR_EST_CC_H
+#ifndef AISX_GR_AIS_CORR_EST_CC_H
+#define AISX_GR_AIS_CORR_EST_CC_H
 
 #include <ais/api.h>
 #include <gnuradio/sync_block.h>
 
 #include <vector>
 
-namespace gr {
-namespace ais {
+namespace gr { namespace ais {
 
 class AIS_API corr_est_cc : virtual public sync_block
 {
 public:
-    typedef boost::shared_ptr<corr_est_cc> sptr;
+    using sptr = boost::shared_ptr<corr_est_cc>; // (GNU Radio 3.8: boost; 3.9 and later spell it std::shared_ptr)
 
     /* symbols: the sync word at `sps` samples per symbol; mark_delay: where on the correlation peak the
      * tags go; threshold: fraction of the sync word's autocorrelation peak (squared) that counts as a hit */
@@ -27,7 +26,6 @@ public:
     virtual void set_symbols(const std::vector<gr_complex>& symbols) = 0;
 };
 
-} // namespace ais
-} // namespace gr
+}} // namespace gr::ais
 
 #endif

@@ -15,8 +15,7 @@
 
 #include <stdexcept>
 
-namespace gr {
-namespace ais {
+namespace gr { namespace ais {
 
 corr_est_cc::sptr corr_est_cc::make(const std::vector<gr_complex>& symbols, float sps, unsigned int mark_delay, float threshold)
 {
@@ -98,5 +97,4 @@ int corr_est_cc_impl::work(int noutput_items, gr_vector_const_void_star& input_i
     return noutput_items;
 }
 
-} // namespace ais
-} // namespace gr
+}} // namespace gr::ais

@@ -15,8 +15,7 @@
 
 #include <stdexcept>
 
-namespace gr {
-namespace ais {
+namespace gr { namespace ais {
 
 freqest::sptr freqest::make(float sample_rate, int data_rate, int fftlen)
 {
@@ -44,5 +43,4 @@ int freqest_impl::work(int noutput_items, gr_vector_const_void_star& input_items
     return rc; // = noutput_items (:87)
 }
 
-} // namespace ais
-} // namespace gr
+}} // namespace gr::ais

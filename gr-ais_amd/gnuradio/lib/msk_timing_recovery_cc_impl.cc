@@ -15,8 +15,7 @@
 
 #include <stdexcept>
 
-namespace gr {
-namespace ais {
+namespace gr { namespace ais {
 
 msk_timing_recovery_cc::sptr msk_timing_recovery_cc::make(float sps, float gain, float limit, int osps)
 {
@@ -103,5 +102,4 @@ int msk_timing_recovery_cc_impl::general_work(int noutput_items, gr_vector_int& 
     return produced;        // :205
 }
 
-} // namespace ais
-} // namespace gr
+}} // namespace gr::ais
