@@ -1100,10 +1100,11 @@ extern "C" int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items)
 }
 
 // what the time-parallel path made of the last call (diagnostics; waits for `stream`)
-extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream)
+extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out10, void* stream)
 {
-    if (!h || !out6)
+    if (!h || !out10)
         return AISX_ERR_INVALID;
+    long long* const out6 = out10; // (ten entries: include/aisx.h)
     for (int i = 0; i < 10; i++)
         out6[i] = 0;
     out6[5] = h->tp_calls;
@@ -1116,6 +1117,9 @@ extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out6, void* stream
     std::vector<mskp_res> rs(nc * MSKP_SMAX);
     std::vector<mskp_rst> rp(nc * MSKP_SMAX);
     AISX_HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    // (a pipelined caller's join runs on a stream of its own: its records are complete behind ev_join)
+    if (h->ev_join_set[par])
+        AISX_HIPCHK(hipEventSynchronize(h->ev_join[par]));
     AISX_HIPCHK(hipMemcpy(nrst.data(), h->d_nrst + par * nc, sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(np.data(), h->d_npieces[par], sizeof(int) * nc, hipMemcpyDeviceToHost));
     AISX_HIPCHK(hipMemcpy(pc.data(), h->d_pieces[par], sizeof(mskp_piece) * pc.size(), hipMemcpyDeviceToHost));
