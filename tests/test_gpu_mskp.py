@@ -170,3 +170,36 @@ def test_pipelined_chain_time_parallel_equals_the_serial_kernel(ais, join):
             bits, _, _ = dem.step(xh[c])
         same += int(len(bits) == gp[c] and np.array_equal(bits, gb[c, : gp[c]]))
     assert same >= 12  # (a time_est that differs in its last place may slip a symbol in the noise: parity.py)
+
+
+def test_time_parallel_at_the_benchmark_size_equals_the_serial_kernel(ais):
+    """BASELINE config 3's shape (4096 channels x 65536 samples, the stock template) through the pipelined chain with
+    the time-parallel recovery on (Q = 256, units <= 16384 items) against its twin with the serial kernel under the
+    same Q: symbol counts and bits of ALL 4096 channels and the tags, over two steps -- the size-independent
+    property that the restart points change nothing; and most symbols must have come from units."""
+    import torch
+
+    import bench
+
+    nchan, T, steps, Q = 4096, 65536, 2, 256
+    tmpl = bench.make_template("S", 4)
+    x = bench.make_input(nchan, T, "S", 4, torch.device("cuda", 0), 0, True)
+    a = ais.ais_demod(OPTS, nchan=nchan, max_items=T, stages="stock", preamble_symbols=tmpl, fused_front_end=True)
+    b = ais.ais_demod(OPTS, nchan=nchan, max_items=T, stages="stock", preamble_symbols=tmpl, fused_front_end=True)
+    a.clockrec.set_max_noutput_items(Q)
+    b.clockrec.set_max_noutput_items(Q)
+    b.clockrec.set_time_parallel(64, join_kernel=1, max_unit_items=16384)
+    ra = [a.work_pipelined(x, x_next=x) for _ in range(steps)]
+    rb = [b.work_pipelined(x, x_next=x) for _ in range(steps)]
+    a.synchronize()
+    b.synchronize()
+    assert a.clockrec.last_status() == 0 and b.clockrec.last_status() == 0
+    st = b.clockrec.restart_stats()
+    assert st["calls"] == steps and st["restart_points"] > 30 * nchan
+    assert st["units_taken"] >= 0.9 * st["restart_points"] and st["symbols_from_units"] >= 0.8 * nchan * T / 4
+    for qa, qb in zip(ra, rb):
+        assert torch.equal(qa["produced"], qb["produced"])
+        w = int(qa["produced"].max())
+        idx = torch.arange(w, device="cuda").view(1, -1) < qa["produced"].view(-1, 1)
+        assert torch.equal(qa["bits"][:, :w][idx], qb["bits"][:, :w][idx])
+    assert a.preamble_detect.tags().tobytes() == b.preamble_detect.tags().tobytes()
