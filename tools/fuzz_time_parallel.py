@@ -1,4 +1,6 @@
-"""Random ragged streams through the time-parallel timing recovery on the device against the oracle (bit-exact or it\nprints FAILED): call lengths, join kernel, max_noutput_items, share of failing junctions, tag density, a NaN tag, sps are\ndrawn per seed.  `gpurun -- python tools/fuzz_time_parallel.py`; 24 seeds take ~10 s.  Uses tests/test_gpu_mskp.py:_stream."""
+"""Random ragged streams through the time-parallel timing recovery on the device against the oracle (bit-exact or it
+prints FAILED): call lengths, join kernel, max_noutput_items, share of failing junctions, tag density, a NaN tag, sps are
+drawn per seed.  `gpurun -- python tools/fuzz_time_parallel.py`; 24 seeds take ~10 s.  Uses tests/test_gpu_mskp.py:_stream."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gr-ais_amd"), os.path.join(ROOT, "tests")):
