@@ -734,7 +734,9 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         // on their own stream, beside the join of the previous call.  They start when the caller says
         // the inputs are there (ready_event; without one: when `stream` gets here), when the join of
         // two calls ago has let go of this parity's records and the bit tail of its staging rows.
-        if (!getenv("AISX_MSK_TP_ONE_STREAM"))
+        // (experiment switches, read once: units on the call's stream; unsorted unit list)
+        static const bool one_stream = getenv("AISX_MSK_TP_ONE_STREAM") != nullptr;
+        if (!one_stream)
             su = h->s_units;
         if (su != st) {
             if (ready_event) {
@@ -772,7 +774,8 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         t.min_gap = h->tp_min_gap;
         t.max_span = h->tp_join ? h->tp_max_span : 0x3fffffff;
         // units sorted by length need every row within 4 GiB of the first (32-bit buffer offsets)
-        tp_sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !getenv("AISX_MSK_TP_UNSORTED");
+        static const bool tp_unsorted_env = getenv("AISX_MSK_TP_UNSORTED") != nullptr;
+        tp_sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !tp_unsorted_env;
         t.ucount = tp_sorted ? ucount : nullptr;
         t.ulist = ulist;
         t.ucap = (long)h->nchan * MSKP_SMAX;
