@@ -376,6 +376,44 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
     return AISX_OK;
 }
 
+// everything the time-parallel path allocates on first use (and nothing else): after this the handle is as if
+// the path had never run
+static void msk_tp_free(aisx_msk* h)
+{
+    if (h->s_units) {
+        (void)hipStreamSynchronize(h->s_units);
+        (void)hipStreamDestroy(h->s_units);
+        h->s_units = nullptr;
+    }
+    auto drop = [](auto*& p) {
+        dev_free(p);
+        p = nullptr;
+    };
+    drop(h->d_ctl);
+    h->ctl_cap = 0;
+    drop(h->d_ctl_n);
+    drop(h->d_nrst);
+    drop(h->d_rst);
+    drop(h->d_res);
+    drop(h->d_ucount);
+    drop(h->d_ulist);
+    drop(h->d_ct_nc);
+    if (h->ev_entry)
+        (void)hipEventDestroy(h->ev_entry);
+    h->ev_entry = nullptr;
+    for (int k = 0; k < 2; k++) {
+        if (h->ev_units[k])
+            (void)hipEventDestroy(h->ev_units[k]);
+        if (h->ev_join[k])
+            (void)hipEventDestroy(h->ev_join[k]);
+        h->ev_units[k] = h->ev_join[k] = nullptr;
+        h->ev_join_set[k] = false;
+        drop(h->d_stage[k]);
+        drop(h->d_pieces[k]);
+        drop(h->d_npieces[k]);
+    }
+}
+
 extern "C" int aisx_msk_destroy(aisx_msk* h)
 {
     if (!h)
@@ -402,31 +440,7 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
         (void)hipEventDestroy(h->ev_prep);
     dev_free(h->d_ct);
     dev_free(h->d_ct_n);
-    dev_free(h->d_ctl);
-    dev_free(h->d_ctl_n);
-    dev_free(h->d_nrst);
-    dev_free(h->d_rst);
-    dev_free(h->d_res);
-    dev_free(h->d_ucount);
-    dev_free(h->d_ulist);
-    dev_free(h->d_ct_nc);
-    if (h->s_units) {
-        (void)hipStreamSynchronize(h->s_units);
-        (void)hipStreamDestroy(h->s_units);
-    }
-    if (h->ev_entry)
-        (void)hipEventDestroy(h->ev_entry);
-    for (int k = 0; k < 2; k++) {
-        if (h->ev_units[k])
-            (void)hipEventDestroy(h->ev_units[k]);
-        if (h->ev_join[k])
-            (void)hipEventDestroy(h->ev_join[k]);
-    }
-    for (int k = 0; k < 2; k++) {
-        dev_free(h->d_stage[k]);
-        dev_free(h->d_pieces[k]);
-        dev_free(h->d_npieces[k]);
-    }
+    msk_tp_free(h);
     dev_free(h->d_nread);
     for (int k = 0; k < 2; k++) {
         dev_free(h->d_carry[k]);
@@ -667,6 +681,16 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
         fresh = true;
     }
     if (!h->d_rst) {
+        // (all or nothing: a failed allocation half way must not leave a handle that looks set up)
+        struct Undo {
+            aisx_msk* h;
+            bool armed = true;
+            ~Undo()
+            {
+                if (armed)
+                    msk_tp_free(h);
+            }
+        } undo{ h };
         const size_t nc = (size_t)h->nchan;
         h->stage_stride = mskp_stage_stride(h->max_items + aisx_msk::carry_cap, h->d_sps, h->gain, h->limit);
         if ((rc = dev_alloc(&h->d_ctl_n, 2 * nc)) != AISX_OK || (rc = dev_alloc(&h->d_nrst, 2 * nc)) != AISX_OK ||
@@ -684,6 +708,7 @@ static int msk_tp_buffers(aisx_msk* h, int tag_cap, hipStream_t st)
             if ((rc = dev_alloc(&h->d_stage[k], nc * (size_t)h->stage_stride)) != AISX_OK ||
                 (rc = dev_alloc(&h->d_pieces[k], nc * MSKP_SMAX)) != AISX_OK || (rc = dev_alloc(&h->d_npieces[k], nc)) != AISX_OK)
                 return rc;
+        undo.armed = false;
         fresh = true;
     }
     if (fresh) // dev_alloc's zero fill runs on the null stream: it must not trail into the kernels on `st`
