@@ -432,6 +432,10 @@ class feedforward_agc_cc:
         """initial max_env of the window search: 1e-4 (GNU Radio 3.7/3.8, the default) or 1e-12."""
         check(_lib.lib().aisx_agc_set_floor(self._h, float(floor_env)), "set_floor")
 
+    def set_streaming(self, on):
+        """on = False: the tile kernels for every call (the streaming kernel serves the stock window otherwise)."""
+        check(_lib.lib().aisx_agc_set_streaming(self._h, 1 if on else 0), "set_streaming")
+
     def work(self, x, out=None, stream=None):
         x = _dev_c64(x, self.nchan)
         if out is None:

@@ -227,6 +227,12 @@ extern "C" int aisx_chain_step(aisx_chain* h, const aisx_cf32* d_in, long in_str
         set_err("aisx_chain_step: bad argument (n = %d, max_items = %d)", n, h ? h->max_items : -1);
         return AISX_ERR_INVALID;
     }
+    // (what only the last stage would notice: checked here, before the first stage is issued, so that an
+    // argument error leaves the chain and the stages' histories as they were)
+    if (out_stride < 1 || out_stride >= (1L << 23)) {
+        set_err("aisx_chain_step: out_stride %ld outside 1 .. 2^23 - 1", out_stride);
+        return AISX_ERR_INVALID;
+    }
     if (h->failed) {
         set_err("aisx_chain_step: an earlier step failed half way (its stages had been issued in part): the stage handles' "
                 "streams and histories no longer match; aisx_*_reset the stages and create a new chain");

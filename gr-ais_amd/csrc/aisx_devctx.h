@@ -110,6 +110,38 @@ struct DevCtx {
     // v of lane - 1 / lane + 1, 0 at the ends of the wave: one DPP move each (wave_shr:1 / wave_shl:1)
     __device__ __forceinline__ unsigned lane_prev_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
     __device__ __forceinline__ unsigned lane_next_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+    // Wave scans of non-negative integers (k_agcw.h: bit patterns of envelopes), 0 the identity.
+    // excl_prefix: max over the lanes below this one; excl_suffix: over the lanes above it.
+    // DPP row shifts fill with 0 where a lane has no source (bound_ctrl), which is the identity here.
+    template <int CTRL, int ROWMASK>
+    static __device__ __forceinline__ int dpp_max_nn(int v)
+    {
+        return max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, true));
+    }
+    __device__ __forceinline__ int wave_excl_prefix_max_nn(int v) const
+    {
+        v = dpp_max_nn<0x111, 0xf>(v); // row_shr:1
+        v = dpp_max_nn<0x112, 0xf>(v); // row_shr:2
+        v = dpp_max_nn<0x114, 0xf>(v); // row_shr:4
+        v = dpp_max_nn<0x118, 0xf>(v); // row_shr:8   -> inclusive inside each row of 16
+        v = dpp_max_nn<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+        v = dpp_max_nn<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
+        return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); // wave_shr:1, lane 0 gets 0
+    }
+    __device__ __forceinline__ int wave_excl_suffix_max_nn(int v) const
+    {
+        v = dpp_max_nn<0x101, 0xf>(v); // row_shl:1
+        v = dpp_max_nn<0x102, 0xf>(v); // row_shl:2
+        v = dpp_max_nn<0x104, 0xf>(v); // row_shl:4
+        v = dpp_max_nn<0x108, 0xf>(v); // row_shl:8   -> inclusive inside each row; lane 16 r holds row r's maximum
+        // (no broadcast runs towards lower rows: the three row maxima go through scalar registers)
+        const int t1 = __builtin_amdgcn_readlane(v, 16), t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
+        const int T2 = max(t2, t3), T1 = max(t1, T2);
+        const int row = (int)(threadIdx.x & 63u) >> 4;
+        const int above = row == 0 ? T1 : row == 1 ? T2 : row == 2 ? t3 : 0;
+        v = max(v, above);
+        return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); // wave_shl:1, lane 63 gets 0
+    }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // two complex items to byte offset `off` (< 4 GiB) of `base`: one 16-byte store

@@ -1005,6 +1005,11 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         if (d_syms || !d_bits || !h->tail_on) { // the caller's own symbol rows are complete when `stream` is
             hipLaunchKernelGGL(k_mskp_gather, dim3(MSKP_GATHER_X, h->nchan), dim3(256), 0, st, g);
             AISX_HIPCHK(hipGetLastError());
+            // this gather reads d_stage[par] / d_res[par], which the units of the call after next overwrite on
+            // their own stream: they wait for ev_join[par], so it has to stand BEHIND the gather (without a
+            // bit tail on another stream nothing else orders the two)
+            if (h->ev_join_set[par])
+                AISX_HIPCHK(hipEventRecord(h->ev_join[par], st));
         }
     }
     if (d_bits) {

@@ -10,6 +10,7 @@
 #include "aisx_host.h"
 #include "aisx_tables.h"
 #include "k_agc.h"
+#include "k_agcw.h"
 #include "k_freqsync.h"
 
 using namespace aisx;
@@ -49,6 +50,15 @@ __global__ __launch_bounds__(AGC8_T) void k_agc8(AgcParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevCtx cx{ smem };
     agc8_body(cx, p);
+}
+
+// the streaming form for the stock window (k_agcw.h): four independent waves per workgroup
+template <bool MIXED>
+__global__ __launch_bounds__(AGW_T) void k_agcw(AgcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    agcw_body<MIXED>(cx, p);
 }
 
 __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
@@ -428,6 +438,7 @@ struct aisx_agc {
     float reference = 0, floor_env = AGC_FLOOR_DEFAULT;
     cf* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
+    bool tiles_only = false; // aisx_agc_set_streaming(h, 0): the tile kernels for every call
 };
 
 extern "C" int aisx_agc_geometry(const aisx_agc* h, int* nchan, int* max_items, int* nsamples, int* fused_ok)
@@ -466,6 +477,8 @@ extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, in
     h->W = nsamples;
     h->max_items = max_items;
     h->reference = reference;
+    if (const char* e = getenv("AISX_AGC_STREAMING")) // (experiments; the API is aisx_agc_set_streaming)
+        h->tiles_only = atoi(e) == 0;
     if ((rc = dev_alloc(&h->d_hist[0], (size_t)nchan * nsamples)) != AISX_OK ||
         (rc = dev_alloc(&h->d_hist[1], (size_t)nchan * nsamples)) != AISX_OK) {
         aisx_agc_destroy(h);
@@ -489,6 +502,14 @@ extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
         return AISX_ERR_INVALID;
     }
     h->floor_env = floor_env;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_set_streaming(aisx_agc* h, int on)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    h->tiles_only = !on;
     return AISX_OK;
 }
 
@@ -542,7 +563,9 @@ extern "C" int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stri
     p.pend_out = nullptr;
     p.npend = 0;
     p.n_raw = 0;
-    if (agc8_applies(p.W))
+    if (agcw_applies(p.W, n) && !h->tiles_only)
+        hipLaunchKernelGGL(k_agcw<false>, dim3(agcw_grid(n), h->nchan), dim3(AGW_T), 0, (hipStream_t)stream, p);
+    else if (agc8_applies(p.W))
         hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_agc, dim3(p.ntiles, h->nchan), dim3(AGC_T), AGC_LDS_BYTES, (hipStream_t)stream, p);
@@ -570,10 +593,11 @@ static int fs_fused_prepare(aisx_freqsync* h)
             return rc;
         if (!s.d_fhat && (rc = dev_alloc(&s.d_fhat, (size_t)h->nchan * h->max_vec)) != AISX_OK)
             return rc;
+        // (each allocation under its own test: a call that failed half way is finished by the next one)
+        if (!s.d_dvec && (rc = dev_alloc(&s.d_dvec, (size_t)h->nchan * h->max_vec)) != AISX_OK)
+            return rc;
         if (!s.d_phases) {
             h->phases_stride = ((long)h->max_vec * (h->fftlen / FSW_CK) + 3) & ~3L;
-            if ((rc = dev_alloc(&s.d_dvec, (size_t)h->nchan * h->max_vec)) != AISX_OK)
-                return rc;
             if ((rc = dev_alloc(&s.d_phases, (size_t)h->nchan * (size_t)h->phases_stride, false)) != AISX_OK)
                 return rc;
         }
@@ -748,7 +772,10 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.pend_out = h->d_pend[h->cur ^ 1];
     p.npend = h->npend;
     p.n_raw = n;
-    hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES_MIXED, st, p);
+    if (agcw_applies(p.W, total) && !a->tiles_only)
+        hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), AGW_LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES_MIXED, st, p);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipEventRecord(s.ev_read, st));
     s.read_pending = true;

@@ -100,11 +100,16 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
 
     // per-thread constants of the transform, in registers for the whole kernel: first / last pass
     // twiddles W_4096^{k t}, second / third pass twiddles W_256^{k2 n3}, the thread's 16 positions of H
+    // (the run-time-length build, NC = 0, has sixteen slice predicates live as lane masks on top of this and
+    // does not fit 256 VGPRs with the first / last pass twiddles resident: it reads them from the 32 KB
+    // table -- L1 / L2 hits -- where it uses them; the folded builds keep them)
+    constexpr bool W_REGS = NC != 0;
     cf w[16], H[16];
     w[0] = mk(1.f, 0.f);
 #pragma unroll
     for (int k = 1; k < 16; k++)
-        w[k] = p.wtab[(k * t) & (CF4_F - 1)];
+        w[k] = W_REGS ? p.wtab[(k * t) & (CF4_F - 1)] : mk(0.f, 0.f);
+    auto tw1 = [&](int k) -> cf { return W_REGS ? w[k] : p.wtab[(k * t) & (CF4_F - 1)]; };
 #if CD_W2_REGS
     cf w2[16];
     w2[0] = mk(1.f, 0.f);
@@ -257,7 +262,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
         dft16<false>(cx, x);
 #pragma unroll
         for (int k1 = 1; k1 < 16; k1++)
-            x[k1] = cmul_fma(x[k1], w[k1]);
+            x[k1] = cmul_fma(x[k1], tw1(k1));
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++)
             st8(A + cf4_pos(k1, t), x[k1]);
@@ -328,7 +333,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) {
             cf a = ld8(A + cf4_pos(k1, t));
-            x[k1] = (k1 == 0) ? a : cmul_conj_fma(a, w[k1]);
+            x[k1] = (k1 == 0) ? a : cmul_conj_fma(a, tw1(k1));
         }
         dft16<true>(cx, x);
         // y[i] = corr[k0 + i - N]; A4 mag^2 (:191) and the threshold test (:197).  Value n1 of a

@@ -215,7 +215,7 @@ int aisx_msk_set_time_parallel(aisx_msk* h, int restart_points_per_channel, int 
 int aisx_msk_get_max_noutput_items(const aisx_msk* h);
 int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
 /* Diagnostics of the time-parallel recovery (k_mskp.h) for the last aisx_msk_process_stream call,
- * summed over the channels: out6 = { restart points chosen, units whose run was taken over,
+ * summed over the channels: out10 (ten entries) = { restart points chosen, units whose run was taken over,
  * symbols that came from units, units that ended at the next restart point, units that ended
  * elsewhere (stale tag, end of the row), calls that took the time-parallel path, units whose end
  * state equals what the next unit assumed, out of this many, items of the longest unit, items of all
@@ -315,6 +315,12 @@ int aisx_agc_reset(aisx_agc* h);
  * "float max_env = 1e-4; // avoid divide by zero, indirectly set max gain") or the 1e-12 of the
  * line upstream has commented out.  Not part of the GNU Radio API. */
 int aisx_agc_set_floor(aisx_agc* h, float floor_env);
+/* Which kernel serves a call is an implementation detail with one switch: calls with the stock
+ * window (512) and a whole number of 512-item blocks run the streaming kernel (k_agcw.h: every
+ * wave walks its own run of blocks, nothing but registers between loads and stores), all others
+ * the tile kernels (k_agc.h).  Same results bit for bit; on = 0 keeps the tile kernels for every
+ * call (A/B measurements, twin tests).  Default on.  Not part of the GNU Radio API. */
+int aisx_agc_set_streaming(aisx_agc* h, int on);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
 /* square_and_fft_sync_cc -> feedforward_agc_cc, the first two blocks of python/ais_demod.py:56, in

@@ -24,6 +24,7 @@ namespace aisx { long msk_stats[8]; }
 #include "../../gr-ais_amd/csrc/k_pfb.h"
 #if __has_include("../../gr-ais_amd/csrc/k_agc.h")
 #include "../../gr-ais_amd/csrc/k_agc.h"
+#include "../../gr-ais_amd/csrc/k_agcw.h"
 #define HAVE_AGC 1
 #endif
 #if __has_include("../../gr-ais_amd/csrc/k_freqsync.h")
@@ -134,6 +135,27 @@ struct EmuCtx {
         const int ln = tid_ & 63;
         memcpy(&lo, &b[wave_base() + (ln & ~W)], sizeof(cf));
         memcpy(&hi, &b[wave_base() + (ln | W)], sizeof(cf));
+    }
+    // wave scans of non-negative integers (DevCtx: DPP), 0 the identity
+    int wave_excl_prefix_max_nn(int v) const
+    {
+        unsigned long long* b = bank();
+        b[tid_] = (unsigned long long)(unsigned)v;
+        wsync();
+        int r = 0;
+        for (int i = 0; i < (tid_ & 63); i++)
+            r = std::max(r, (int)(unsigned)b[wave_base() + i]);
+        return r;
+    }
+    int wave_excl_suffix_max_nn(int v) const
+    {
+        unsigned long long* b = bank();
+        b[tid_] = (unsigned long long)(unsigned)v;
+        wsync();
+        int r = 0;
+        for (int i = (tid_ & 63) + 1; i < 64 && wave_base() + i < sh->nthreads; i++)
+            r = std::max(r, (int)(unsigned)b[wave_base() + i]);
+        return r;
     }
     unsigned lane_prev_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l > 0 ? l - 1 : l); return l > 0 ? r : 0u; }
     unsigned lane_next_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l < 63 ? l + 1 : l); return l < 63 ? r : 0u; }
@@ -659,6 +681,11 @@ void emu_fxpt_float_to_fixed_n(const float* x, int* out, long n)
 {
     for (long i = 0; i < n; i++) out[i] = fxpt_float_to_fixed(x[i]);
 }
+// k_agcw.h's float_to_fixed of an NCO phase against the general statement
+void emu_nco_phase_to_fixed_n(const float* x, int* out, long n)
+{
+    for (long i = 0; i < n; i++) out[i] = nco_phase_to_fixed(x[i]);
+}
 const float* emu_mmse_table() { return &aisx_mmse_taps[0][0]; }
 const float* emu_atan_table() { return aisx_atan_table; }
 
@@ -668,7 +695,9 @@ struct EmuAgc {
     float ref;
     std::vector<cf> hist[2];
     int cur = 0;
+    bool no_stream = false; // tile kernels only (agc8_body / agc_body), as for windows agcw_body does not serve
 };
+void emu_agc_set_streaming(void* hv, int on) { ((struct EmuAgc*)hv)->no_stream = !on; }
 void* emu_agc_create(int nsamples, float reference, int nchan)
 {
     EmuAgc* h = new EmuAgc();
@@ -686,7 +715,9 @@ void emu_agc_process(void* hv, const cf* in, long in_stride, cf* out, long out_s
     p.hist_in = h->hist[h->cur].data(); p.hist_out = h->hist[h->cur ^ 1].data();
     p.n = n; p.W = h->W; p.reference = h->ref; p.floor_env = AGC_FLOOR_DEFAULT; p.ntiles = agc8_applies(h->W) ? (n + AGC8_TL - 1) / AGC8_TL : (n + AGC_TL - 1) / AGC_TL;
     p.phases = nullptr; p.phases_stride = 0; p.dvec = nullptr; p.dvec_stride = 0; p.sintab = nullptr; p.pend_in = nullptr; p.pend_out = nullptr; p.npend = 0; p.n_raw = 0;
-    if (agc8_applies(p.W))
+    if (agcw_applies(p.W, n) && !h->no_stream) // (the product's dispatch: aisx_agc_process)
+        run_grid(agcw_grid(n), h->nchan, AGW_T, AGW_LDS_BYTES, [&](EmuCtx& cx) { agcw_body<false>(cx, p); });
+    else if (agc8_applies(p.W))
         run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES, [&](EmuCtx& cx) { agc8_body(cx, p); });
     else
         run_grid(p.ntiles, h->nchan, AGC_T, AGC_LDS_BYTES, [&](EmuCtx& cx) { agc_body(cx, p); });
@@ -771,7 +802,10 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
     p.ntiles = total > 0 ? (total + AGC8_TL - 1) / AGC8_TL : 1;
     p.phases = phases.data(); p.phases_stride = pstride; p.dvec = dvec.data(); p.dvec_stride = h->max_vec; p.sintab = &aisx_sine_table[0][0]; p.pend_in = h->pend[h->cur].data(); p.pend_out = h->pend[h->cur ^ 1].data();
     p.npend = h->npend; p.n_raw = n;
-    run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
+    if (agcw_applies(p.W, total) && !a->no_stream) // (the product's dispatch: aisx_freqsync_agc_process)
+        run_grid(agcw_grid(total), h->nchan, AGW_T, AGW_LDS_BYTES, [&](EmuCtx& cx) { agcw_body<true>(cx, p); });
+    else
+        run_grid(p.ntiles, h->nchan, AGC8_T, AGC8_LDS_BYTES_MIXED, [&](EmuCtx& cx) { agc8_body(cx, p); });
     h->npend = h->npend + n - total;
     h->cur ^= 1;
     a->cur ^= 1;

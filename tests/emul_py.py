@@ -52,6 +52,7 @@ def lib():
         L.emu_agc_create.argtypes = [i32, f32, i32]
         L.emu_agc_destroy.argtypes = [vp]
         L.emu_agc_process.argtypes = [vp, vp, lng, vp, lng, i32]
+        L.emu_agc_set_streaming.argtypes = [vp, i32]
         L.emu_fs_agc_process.restype = i32
         L.emu_fs_agc_process.argtypes = [vp, vp, vp, lng, i32, vp, lng, vp, lng]
         L.emu_fs_create.restype = vp

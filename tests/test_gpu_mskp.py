@@ -203,3 +203,70 @@ def test_time_parallel_at_the_benchmark_size_equals_the_serial_kernel(ais):
         idx = torch.arange(w, device="cuda").view(1, -1) < qa["produced"].view(-1, 1)
         assert torch.equal(qa["bits"][:, :w][idx], qb["bits"][:, :w][idx])
     assert a.preamble_detect.tags().tobytes() == b.preamble_detect.tags().tobytes()
+
+
+def test_time_parallel_pipelined_symbols_only(ais):
+    """aisx_msk_process_stream_after with a ready event and NO bit tail (d_bits NULL: the gather of the units'
+    symbols runs on the caller's stream): six calls queued back to back.  The units of call k + 2 reuse the
+    staging rows call k's gather reads, and run on the handle's own stream -- they must wait for that gather
+    (the event they wait for is recorded behind it).  Symbols and counts equal to the serial kernel's."""
+    import ctypes as C
+    import torch
+    from ais_amd import _lib, synth
+
+    nchan, L, ncalls, sps, Q = 512, 32768, 6, 4.0, 256
+    rng = np.random.default_rng(11)
+    total = L * ncalls
+    base = np.stack([synth.make_channel(4000 + c, total, "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(8)])
+    xs = np.concatenate([np.roll(base, 1000 * r, axis=1) for r in range(nchan // 8)], axis=0)
+    tags8 = [_tags_with_pairs(rng, total, c, sps, 700, 0.2, 6, None) for c in range(8)]
+    cap = max(len(t) for t in tags8) + 1
+    d_x = _dev(xs)
+    calls = []
+    for k in range(ncalls):
+        tg = np.zeros((nchan, cap), dtype=ais.TAG_DTYPE)
+        cnt = np.zeros(nchan, np.int32)
+        for c in range(nchan):
+            t = tags8[c % 8]
+            sel = t[(t["offset"] >= k * L) & (t["offset"] < (k + 1) * L)]
+            for f in ("offset", "value", "key"):
+                tg[f][c, : len(sel)] = sel[f]
+            tg["chan"][c, : len(sel)] = c
+            cnt[c] = len(sel)
+        calls.append((torch.as_tensor(tg.view(np.uint8).reshape(nchan, -1).copy()).cuda(), torch.as_tensor(cnt).cuda()))
+
+    def run(time_parallel):
+        blk = ais.msk_timing_recovery_cc(sps, 0.04, 0.01, 1, nchan=nchan, max_items=L)
+        blk.set_max_noutput_items(Q)
+        if time_parallel:
+            blk.set_time_parallel(64, join_kernel=1, max_unit_items=16384)
+        ocap = blk.out_capacity
+        st = torch.cuda.Stream()
+        outs = []
+        with torch.cuda.stream(st):
+            for k in range(ncalls):
+                syms = torch.zeros((nchan, ocap), dtype=torch.complex64, device="cuda")
+                prod = torch.zeros(nchan, dtype=torch.int32, device="cuda")
+                ev = torch.cuda.Event()
+                ev.record(st)
+                x = d_x[:, k * L:(k + 1) * L]
+                rc = _lib.lib().aisx_msk_process_stream_after(
+                    blk._h, x.data_ptr(), x.stride(0), L, calls[k][0].data_ptr(), calls[k][1].data_ptr(), cap,
+                    syms.data_ptr(), None, None, None, ocap, prod.data_ptr(), C.c_void_p(st.cuda_stream),
+                    C.c_void_p(ev.cuda_event))
+                _lib.check(rc, "process_stream_after")
+                outs.append((syms, prod, ev))
+        st.synchronize()
+        assert blk.last_status() == 0
+        stats = blk.restart_stats() if time_parallel else None
+        return [(s.cpu().numpy(), p.cpu().numpy()) for s, p, _ in outs], stats
+
+    want, _ = run(False)
+    for trial in range(2):
+        got, stats = run(True)
+        assert stats["units_taken"] > 0
+        for k in range(ncalls):
+            assert np.array_equal(got[k][1], want[k][1]), (trial, k)
+            p = want[k][1]
+            for c in range(nchan):
+                assert np.array_equal(got[k][0][c, :p[c]].view(np.uint32), want[k][0][c, :p[c]].view(np.uint32)), (trial, k, c)

@@ -465,3 +465,49 @@ def test_two_block_and_fused_calls_mixed_across_streams(ais):
         for c in range(4):
             want, _ = o[c].process(xs[c, sum(lens[:i]):sum(lens[:i + 1])])
             assert np.array_equal(yh[c].view(np.uint32), want.view(np.uint32)), (i, c)
+
+
+@pytest.mark.gpu
+def test_streaming_front_end_equals_tile_kernels_at_full_size(ais):
+    # The stock window's calls run k_agcw.h (every wave walks its own run of 512-item blocks); the tile
+    # kernels (k_agc.h) stay for every other window and length.  Same stream through both, fused
+    # front end and the AGC alone: carriers at offsets of either sign (phases below -pi for whole
+    # calls), silence (the floor), a NaN, calls that leave pending items, 65536-sample calls
+    # (eight runs per channel), 300 channels; a few channels against the oracle.
+    nchan = 300
+    lens = [65536, 1000, 65536 + 24, 3 * 1024 - 1000, 512 * 33]
+    total = sum(lens)
+    rng = np.random.default_rng(9)
+    n = np.arange(total)
+    xs = (0.05 * (rng.normal(size=(nchan, total)) + 1j * rng.normal(size=(nchan, total)))).astype(np.complex64)
+    offs = rng.uniform(-9000.0, 9000.0, nchan)
+    for c in range(nchan):
+        xs[c] += (0.5 * np.exp(1j * (2 * np.pi * offs[c] / 38400.0 * n + c))).astype(np.complex64)
+    xs[3, 5000:70000] = 0
+    xs[4, 777] = np.nan
+    mk = lambda: (ais.square_and_fft_sync_cc(38400.0, 9600.0, 1024, nchan=nchan, max_items=max(lens)),
+                  ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens) + 1024))
+    fs1, ag1 = mk()
+    fs2, ag2 = mk()
+    ag2.set_streaming(False)
+    pa1 = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens))
+    pa2 = ais.feedforward_agc_cc(512, 2.0, nchan=nchan, max_items=max(lens))
+    pa2.set_streaming(False)
+    nor = 6
+    ofs = [orc.FreqSync(38400.0, 9600.0, 1024) for _ in range(nor)]
+    oag = [orc.Agc(512, 2.0) for _ in range(nor)]
+    k = 0
+    for L in lens:
+        x = _dev(xs[:, k:k + L])
+        a, fa = ais.freq_sync_agc(fs1, ag1, x, want_fhat=True)
+        b, fb = ais.freq_sync_agc(fs2, ag2, x, want_fhat=True)
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), L
+        assert np.array_equal(fa.cpu().numpy(), fb.cpu().numpy())
+        p, q = pa1.work(x).cpu().numpy(), pa2.work(x).cpu().numpy()
+        assert np.array_equal(p.view(np.uint32), q.view(np.uint32)), L
+        for c in range(nor):
+            yo, _ = ofs[c].process(xs[c, k:k + L])
+            want = oag[c].work(yo) if yo.size else yo
+            assert np.array_equal(a[c].view(np.uint32), want.view(np.uint32)), (L, c)
+        k += L
