@@ -126,6 +126,111 @@ def pmc_traffic(nchan, T, N):
     return None, None
 
 
+MSK_BYTES_PER_SAMPLE = 10.25  # 8 read + 8 / sps symbol + 1 / sps bit written, sps = 4
+
+
+def probe_gnuradio():
+    """Is the reference's own CPU path (GNU Radio 3.8 + VOLK) present on THIS host?  Looks for the
+    things its build needs (CMakeLists.txt:71 find_package(Gnuradio "3.8")): the Python package, the config tool,
+    VOLK's profiler / pkg-config entry, the CMake package files.  Says what it found; never builds anything."""
+    import importlib.util
+    import shutil
+
+    found = []
+    try:
+        # (gnuradio.gr, not gnuradio: this repository's own gr-ais_amd/gnuradio/ directory -- the wrapper sources --
+        # is on sys.path and would pass for a namespace package of that name)
+        if importlib.util.find_spec("gnuradio.gr") is not None:
+            found.append("python package gnuradio.gr")
+    except (ImportError, ValueError, AttributeError):
+        pass
+    for tool in ("gnuradio-config-info", "volk_profile", "volk-config-info"):
+        w = shutil.which(tool)
+        if w:
+            found.append(w)
+    for d in ("/usr/lib/x86_64-linux-gnu/cmake/gnuradio", "/usr/lib/cmake/gnuradio", "/usr/local/lib/cmake/gnuradio",
+              "/usr/lib/x86_64-linux-gnu/cmake/volk", "/usr/local/lib/cmake/volk", "/usr/include/volk", "/usr/local/include/volk",
+              "/usr/include/gnuradio", "/usr/local/include/gnuradio"):
+        if os.path.isdir(d):
+            found.append(d)
+    try:
+        pc = subprocess.run(["pkg-config", "--modversion", "gnuradio-runtime", "volk"], capture_output=True, text=True, timeout=10)
+        if pc.returncode == 0:
+            found.append("pkg-config: " + pc.stdout.strip().replace("\n", " / "))
+    except (OSError, subprocess.SubprocessError):
+        pass
+    if not found:
+        return ("unavailable: probed this host for the gnuradio Python package, gnuradio-config-info, volk_profile, "
+                "volk-config-info, the gnuradio / volk CMake and include directories and pkg-config entries -- none present, "
+                "so /root/reference (find_package(Gnuradio \"3.8\")) can not be built or timed here")
+    return "found on this host, not timed (the reference still needs its own build): " + "; ".join(found)
+
+
+def measure_h2d(torch, device):
+    """Host-to-device rate of a pinned 1 GiB buffer (hipMemcpyAsync through torch, best of three): a caller that hands
+    over HOST buffers of IQ is bound by it -- 8 bytes per complex sample in; the decoded bits coming back are 1 / 32 of that."""
+    try:
+        n = 1 << 30
+        h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        d = torch.empty(n, dtype=torch.uint8, device=device)
+        best = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d.copy_(h, non_blocking=True)
+            torch.cuda.synchronize()
+            best = max(best, n / (time.perf_counter() - t0) / 1e9)
+        del h, d
+        return {"h2d_GBs": best, "h2d_bound_MSs": best * 1e9 / 8.0 / 1e6,
+                "note": "pinned host memory -> HBM, 1 GiB; the headline value has its input resident in HBM -- a host-buffer "
+                        "hand-over is bound by h2d_bound_MSs per GPU"}
+    except RuntimeError as e:
+        return {"h2d_GBs": None, "h2d_bound_MSs": None, "note": "not measured: %s" % e}
+
+
+def hbm_ceilings():
+    """tools/ubench/hbm_ceiling (built by __graft_entry__.build()): read-only, write-only and copy rates by access shape."""
+    exe = os.path.join(ROOT, "tools", "ubench", "hbm_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "json"], capture_output=True, text=True, timeout=120)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        return None
+    return {"best_copy_GBs": d.get("best_copy_GBs"), "best_read_GBs": d.get("best_read_GBs"), "best_write_GBs": d.get("best_write_GBs"),
+            "copy_128MiB_GBs": next((r["GBs"] for r in d.get("rows", []) if r["GiB"] < 0.2), None),
+            "source": "tools/ubench/hbm_ceiling.hip: 2 GiB buffers (beyond the 256 MiB Infinity Cache), hipEvents over 10 launches, "
+                      "best of the shapes swept; copy_128MiB_GBs is what a cache-resident size reads (the guide's 6.29 TB/s class)"}
+
+
+def config1_host_path():
+    """BASELINE config 1 (one 48 kS/s channel) through the gr::ais block classes' work() / general_work() with HOST buffers
+    -- the GNU Radio drop-in path -- as a throughput: tests/abi_cpp/gr_blocks_harness.cpp (the compiled scheduler stand-in
+    of tests/test_gr_wrappers.py) run over tests/golden/config1_sched.bin, warm (second of two runs)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gr_wrappers as tw
+
+        exe = tw._build()
+        best = None
+        for _ in range(2):
+            out = subprocess.run([exe, tw.FIXTURE], capture_output=True, text=True, timeout=300)
+            for ln in out.stdout.splitlines():
+                if ln.startswith("HOST_PATH"):
+                    kv = dict(w.split("=") for w in ln.split()[1:])
+                    best = dict(samples=int(kv["samples"]), seconds=float(kv["seconds"]), MSs=float(kv["MSs"]),
+                                passed="PASS" in out.stdout)
+        if best is None:
+            return None
+        best["what"] = ("one channel, freq_sync -> agc -> corr_est -> msk through make() / work() / general_work() with host pointers "
+                        "(every call: copy in, launch, copy out, synchronous); the stock application needs 2 x 0.05 MS/s "
+                        "(python/radio.py:88-89,120); one CPU thread of the port runs cpu_baseline.single_thread_value")
+        return best
+    except Exception as e:  # noqa: BLE001  (a side measurement must not take the line with it)
+        return {"MSs": None, "note": "not measured: %s" % e}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -197,7 +302,7 @@ def cpu_baseline(chain, family, sps, T, budget_s=6.0):
                 native_build=native is not None, native_results_equal_portable=same,
                 portable_O2_build={"single_thread_value": p1, "value": p2},
                 scaling_note=note, cpu_model=cpu_model(), nproc=os.cpu_count(),
-                reference_volk_path="unavailable (no GNU Radio / VOLK in the image)")
+                reference_volk_path=probe_gnuradio())
 
 
 def oracle_replay(chain, tmpl, sps, xk, nsteps, max_noutput=0):
@@ -422,7 +527,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(chain, want_parity, lookahead=True, msk_tp=False, msk_Q=0):
+    def measure(chain, want_parity, lookahead=True, msk_tp=False, msk_Q=0, nch=None):
         """K timed steps of `chain` on this rank's channel shard; returns the wall time (max over
         ranks), the correlator kernel's per-launch times inside the timed region and (rank 0) the
         parity gates of the last step.  The step is the product's pipelined chain
@@ -431,6 +536,7 @@ def main():
         phase walk of step k + 2 on two more.  This benchmark feeds the same samples every step, so
         the next step's input is always at hand (x_next = x); a live source runs one block ahead."""
         stock = chain == "stock"
+        nchan = nch or args.channels_per_gpu
         x = make_input(nchan, T, args.template, sps, device, rank, stock)
         # (the buffers of the alone-on-the-chip measurement at the end are allocated now: a 2 GB buffer
         # allocated late comes out of what the allocator has left over, and the same kernel reads
@@ -461,6 +567,8 @@ def main():
             step()
         barrier()
         corr.set_profiling(True)  # restart the event ring: the timed steps only
+        if chain != "corr" and not msk_tp:
+            dem.clockrec.set_profiling(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -470,7 +578,8 @@ def main():
         # per-launch duration of the dominant kernel over the timed region: hipEvents
         # recorded around it on its launch stream in every step, read back only now
         kern_ms = corr.kernel_ms_history()[-args.steps:]
-        res = dict(kern_ms=kern_ms, st=0, ndet=0, parity=None, tag_overflow=False)
+        res = dict(kern_ms=kern_ms, st=0, ndet=0, parity=None, tag_overflow=False, nchan=nchan)
+        res["msk_ms"] = dem.clockrec.kernel_ms_history()[-args.steps:] if (chain != "corr" and not msk_tp) else None
         if rank == 0:
             # the last step's results, before anything else touches the handles
             res["st"] = dem.clockrec.last_status() if chain != "corr" else 0
@@ -554,6 +663,11 @@ def main():
     if side and world == 1:
         corr_only = [measure_corr_only(c, f) for c in (256, 4096) for f in ("S", "P")]
 
+    # BASELINE config 4's per-GPU shape (8192 channels) as a side measurement of the default run: there the
+    # timing recovery hides behind the sample passes, and every millisecond taken off those shows one to one
+    c4 = measure("stock", False, nch=8192) if (args.chain == "stock" and side and world == 1 and nchan != 8192) else None
+    h2d = measure_h2d(torch, device) if (rank == 0 and side) else None
+    ceil = hbm_ceilings() if (rank == 0 and side) else None
     copy_gbs = None
     if rank == 0 and side:
         # what a plain 16-byte-per-lane copy sustains on this chip, no profiler attached (2 GiB each way)
@@ -603,6 +717,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_static": True,  # (read from the committed PMC summary of this workload, not collected in this run)
                 "traffic_source": traffic_src,
                 "kernel_ms": kms,
                 "kernel_ms_alone": float(np.mean(iso)),
@@ -617,6 +732,40 @@ def main():
             "tag_overflow": r["tag_overflow"],
             "msk_status": int(st),
         }
+        if ceil is not None:
+            # what this box's HBM sustains by access shape (tools/ubench/hbm_ceiling.hip, 2 GiB buffers, hipEvents): the
+            # correlator moves 8 B in + 8 B out per sample, so the copy figure is its practical ceiling
+            line["roofline"]["achievable_GBs"] = ceil
+            if ceil.get("best_copy_GBs"):
+                line["roofline"]["frac_of_best_copy"] = achieved / ceil["best_copy_GBs"]
+                line["roofline"]["frac_alone_of_best_copy"] = line["roofline"]["frac_alone"] * HBM_PEAK_GBS / ceil["best_copy_GBs"]
+        if r.get("msk_ms"):
+            mms = float(np.mean(r["msk_ms"]))
+            mbytes = MSK_BYTES_PER_SAMPLE * float(nchan) * T
+            line["roofline_msk"] = {
+                "kernel": "k_msk", "bound": "latency (a recurrence per channel: 16384 dependent iteration pairs per step)",
+                "bytes_per_sample": MSK_BYTES_PER_SAMPLE, "algorithmic_bytes_per_launch": mbytes, "kernel_ms": mms,
+                "achieved": mbytes / (mms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": mbytes / (mms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "step_floor_ms": 4.75,
+                "note": "the kernel that bounds the step at 4096 channels: ~290 ns per iteration pair whatever the channel "
+                        "count (4.75 ms per 65536 samples alone on the chip: value can not exceed channels x 65536 / 4.75 ms)",
+            }
+        if h2d is not None:
+            line["h2d"] = h2d
+        if side and world == 1:
+            line["config1_host_path"] = config1_host_path()
+        if c4 is not None:
+            k4 = float(np.mean(c4["kern_ms"]))
+            a4 = CORR_BYTES_PER_SAMPLE * 8192.0 * T / (k4 * 1e-3) / 1e9
+            line["config4_per_gpu"] = {
+                "what": "the same steps at BASELINE config 4's per-GPU shape, 8192 channels x %d samples (side measurement on this GPU)" % T,
+                "ms_per_step": c4["el"] / args.steps * 1e3,
+                "value": 8192.0 * T * args.steps / c4["el"] / 1e6, "unit": "complex MS/s",
+                "corr_kernel_ms": k4, "corr_frac": a4 / HBM_PEAK_GBS,
+                "msk_kernel_ms": float(np.mean(c4["msk_ms"])) if c4.get("msk_ms") else None,
+                "msk_status": int(c4["st"]),
+            }
         if extra is not None:
             line["corr_est_to_msk_only"] = {
                 "chain": CHAIN_TEXT["core"],

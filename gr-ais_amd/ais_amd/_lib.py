@@ -78,6 +78,7 @@ def lib(device=True):
     sig("aisx_device_count", i32, [pi32])
     sig("aisx_set_device", i32, [i32])
     sig("aisx_util_copy_GBs", i32, [C.c_size_t, i32, C.POINTER(C.c_float)])
+    sig("aisx_util_agc_rcp_mismatches", i32, [f32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)])
     sig("aisx_corr_create", i32, [pvp, vp, i32, f32, u32, f32, i32, i32, i32])
     sig("aisx_corr_destroy", i32, [vp])
     sig("aisx_corr_symbols", i32, [vp, vp, i32])
@@ -113,6 +114,8 @@ def lib(device=True):
     sig("aisx_msk_process_stream_after", i32, [vp, vp, lng, i32, vp, vp, i32, vp, vp, vp, vp, lng, vp, vp, vp])
     sig("aisx_msk_last_status", i32, [vp, pi32, vp])
     sig("aisx_msk_restart_stats", i32, [vp, vp, vp])
+    sig("aisx_msk_set_profiling", i32, [vp, i32])
+    sig("aisx_msk_kernel_ms_history", i32, [vp, C.POINTER(C.c_float), i32, pi32])
     sig("aisx_msk_set_max_noutput_items", i32, [vp, i32])
     sig("aisx_msk_set_time_parallel", i32, [vp, i32, i32, i32])
     sig("aisx_msk_get_max_noutput_items", i32, [vp])
@@ -141,6 +144,7 @@ def lib(device=True):
     sig("aisx_agc_reset", i32, [vp])
     sig("aisx_agc_set_floor", i32, [vp, f32])
     sig("aisx_agc_set_streaming", i32, [vp, i32])
+    sig("aisx_agc_set_lds_claim", i32, [vp, i32])
     sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
     sig("aisx_chain_create", i32, [pvp, vp, vp, vp, vp, i32, i32, i32])
     sig("aisx_chain_destroy", i32, [vp])

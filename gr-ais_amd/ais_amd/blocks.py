@@ -279,6 +279,15 @@ class msk_timing_recovery_cc:
     def max_noutput_items(self):
         return _lib.lib().aisx_msk_get_max_noutput_items(self._h)
 
+    def set_profiling(self, on=True):
+        check(_lib.lib().aisx_msk_set_profiling(self._h, 1 if on else 0), "set_profiling")
+
+    def kernel_ms_history(self):
+        buf = (C.c_float * 64)()
+        n = C.c_int(0)
+        check(_lib.lib().aisx_msk_kernel_ms_history(self._h, buf, 64, C.byref(n)), "kernel_ms_history")
+        return [float(buf[i]) for i in range(n.value)]
+
     def restart_stats(self, stream=None):
         """What the time-parallel recovery made of the last call (sums over the channels)."""
         a = (C.c_longlong * 10)()

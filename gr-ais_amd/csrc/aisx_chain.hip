@@ -190,6 +190,13 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             chain_free(h);
             return rc;
         }
+    if (!h->serial && agc) {
+        // one front-end workgroup beside each recovery workgroup, two on the other CUs (aisx_agc_set_lds_claim)
+        if ((rc = aisx_agc_set_lds_claim(agc, 48 * 1024)) != AISX_OK) {
+            chain_free(h);
+            return rc;
+        }
+    }
     if (!h->serial) {
         // the bit tail of step k beside the recovery of step k + 1; the next step's sample passes
         // behind this step's tag prepass (aisx_msk_wait_prepass: the first call arms the event)

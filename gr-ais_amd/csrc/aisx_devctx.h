@@ -128,20 +128,29 @@ struct DevCtx {
         v = dpp_max_nn<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
         return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); // wave_shr:1, lane 0 gets 0
     }
-    __device__ __forceinline__ int wave_excl_suffix_max_nn(int v) const
+    // (`all`: the maximum over the whole wave, wave-uniform)
+    __device__ __forceinline__ int wave_excl_suffix_max_nn(int v, int& all) const
     {
         v = dpp_max_nn<0x101, 0xf>(v); // row_shl:1
         v = dpp_max_nn<0x102, 0xf>(v); // row_shl:2
         v = dpp_max_nn<0x104, 0xf>(v); // row_shl:4
         v = dpp_max_nn<0x108, 0xf>(v); // row_shl:8   -> inclusive inside each row; lane 16 r holds row r's maximum
-        // (no broadcast runs towards lower rows: the three row maxima go through scalar registers)
-        const int t1 = __builtin_amdgcn_readlane(v, 16), t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
+        // (no broadcast runs towards lower rows: the row maxima go through scalar registers)
+        const int t0 = __builtin_amdgcn_readlane(v, 0), t1 = __builtin_amdgcn_readlane(v, 16);
+        const int t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
         const int T2 = max(t2, t3), T1 = max(t1, T2);
+        all = max(t0, T1);
         const int row = (int)(threadIdx.x & 63u) >> 4;
         const int above = row == 0 ? T1 : row == 1 ? T2 : row == 2 ? t3 : 0;
         v = max(v, above);
         return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); // wave_shl:1, lane 63 gets 0
     }
+    // v_rcp_f32: the reciprocal to 1 ulp (callers refine it, k_agcw.h: agcw_gain_fast)
+    __device__ __forceinline__ float rcp_approx(float x) const { return __builtin_amdgcn_rcpf(x); }
+    // v_sqrt_f32: the square root to 1 ulp (k_freqsync.h: scores that only select what is evaluated exactly)
+    __device__ __forceinline__ float sqrt_approx(float x) const { return __builtin_amdgcn_sqrtf(x); }
+    // entry `idx` of a table of 8-byte pairs in LDS (k_agcw.h: the NCO's sine table)
+    __device__ __forceinline__ cf lds_cf(const float* tab, unsigned idx) const { return ld8(reinterpret_cast<const cf*>(tab) + idx); }
     // x - floorf(x) for x >= 0 (v_fract_f32 is exact there)
     __device__ __forceinline__ float fract(float x) const { return __builtin_amdgcn_fractf(x); }
     // two complex items to byte offset `off` (< 4 GiB) of `base`: one 16-byte store

@@ -561,11 +561,14 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
     } else if (dma) {
         void (*kern)(CorrParams) = corr4d_pick(h->N);
+        // (experiments: LDS a workgroup claims beyond what it uses decides how many of them fit beside the timing
+        // recovery's 92 160 bytes on a CU -- one at 71 680, none above 71 680)
+        static const int lds_pad = getenv("AISX_CORR_LDS_PAD") ? atoi(getenv("AISX_CORR_LDS_PAD")) : 0;
         if (h->dma_attr_set != (const void*)kern) {
-            AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES));
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES + lds_pad));
             h->dma_attr_set = (const void*)kern;
         }
-        hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(CF4_T), CD_LDS_BYTES, st, p);
+        hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(CF4_T), CD_LDS_BYTES + lds_pad, st, p);
     } else {
         hipLaunchKernelGGL(k_corr4_main, dim3(nseg, h->nchan), dim3(CF4_T), CF4_LDS_BYTES, st, p);
     }

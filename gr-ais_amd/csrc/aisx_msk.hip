@@ -138,6 +138,11 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
 // ---------------------------------------------------------------------------
 struct aisx_msk {
     int nchan = 0, max_items = 0, out_cap = 0, osps = 1;
+    // measurement hook (aisx_msk_set_profiling): hipEvents around the recovery kernel of every stream call
+    int prof = 0;
+    static constexpr int NEV = 64;
+    hipEvent_t pev0[NEV] = {}, pev1[NEV] = {};
+    long ncalls_prof = 0;
     int lpw = 64; // channels per wave of the timing-recovery kernel
     int inline_tags = 1; // (AISX_MSK_INLINE_TAGS=0: every tag reset through the general steps, for A/B runs)
     float d_sps = 0, gain = 0, gain_omega = 0, limit = 0;
@@ -438,6 +443,12 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
             (void)hipEventDestroy(h->ev_tail[k]);
     if (h->ev_prep)
         (void)hipEventDestroy(h->ev_prep);
+    for (int k = 0; k < aisx_msk::NEV; k++) {
+        if (h->pev0[k])
+            (void)hipEventDestroy(h->pev0[k]);
+        if (h->pev1[k])
+            (void)hipEventDestroy(h->pev1[k]);
+    }
     dev_free(h->d_ct);
     dev_free(h->d_ct_n);
     msk_tp_free(h);
@@ -988,8 +999,15 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         p.sym_al16 = ((uintptr_t)syms % 16 == 0) && (out_stride % 2 == 0);
         p.out_cap = out_cap;
         p.produced = produced;
+        const int evi = (int)(h->ncalls_prof % aisx_msk::NEV);
+        if (h->prof)
+            AISX_HIPCHK(hipEventRecord(h->pev0[evi], st));
         if ((rc = msk_launch(p, (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw), st)) != AISX_OK)
             return rc;
+        if (h->prof) {
+            AISX_HIPCHK(hipEventRecord(h->pev1[evi], st));
+            h->ncalls_prof++;
+        }
     }
     h->cur ^= 1;
     h->total_in += (unsigned long long)n;
@@ -1133,6 +1151,37 @@ extern "C" int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items)
 }
 
 // what the time-parallel path made of the last call (diagnostics; waits for `stream`)
+extern "C" int aisx_msk_set_profiling(aisx_msk* h, int on)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (on && !h->pev0[0]) {
+        for (int k = 0; k < aisx_msk::NEV; k++) {
+            AISX_HIPCHK(hipEventCreate(&h->pev0[k]));
+            AISX_HIPCHK(hipEventCreate(&h->pev1[k]));
+        }
+    }
+    h->prof = on ? 1 : 0;
+    h->ncalls_prof = 0;
+    return AISX_OK;
+}
+
+extern "C" int aisx_msk_kernel_ms_history(aisx_msk* h, float* ms, int cap, int* n)
+{
+    if (!h || !ms || !n || !h->pev0[0])
+        return AISX_ERR_INVALID;
+    const long have = h->ncalls_prof < aisx_msk::NEV ? h->ncalls_prof : aisx_msk::NEV;
+    int w = 0;
+    for (long k = h->ncalls_prof - have; k < h->ncalls_prof && w < cap; k++) {
+        const int evi = (int)(k % aisx_msk::NEV);
+        AISX_HIPCHK(hipEventSynchronize(h->pev1[evi]));
+        AISX_HIPCHK(hipEventElapsedTime(&ms[w], h->pev0[evi], h->pev1[evi]));
+        w++;
+    }
+    *n = w;
+    return AISX_OK;
+}
+
 extern "C" int aisx_msk_restart_stats(aisx_msk* h, long long* out10, void* stream)
 {
     if (!h || !out10)

@@ -3,6 +3,7 @@
 // (python/gmsk_sync.py, lib/freqest_impl.cc) and analog.feedforward_agc_cc.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -61,6 +62,64 @@ __global__ __launch_bounds__(AGW_T) void k_agcw(AgcParams p)
     agcw_body<MIXED>(cx, p);
 }
 
+// exhaustive check of agcw_gain_fast against the float division (k_agcw.h): every float m in
+// [AGW_RCP_LO, AGW_RCP_HI], one per lane and grid-stride step
+__global__ __launch_bounds__(256) void k_agc_rcp_sweep(float reference, unsigned lo_bits, unsigned hi_bits,
+                                                      unsigned long long* count, unsigned* example)
+{
+    DevCtx cx{ nullptr };
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)lo_bits + (unsigned long long)blockIdx.x * 256 + threadIdx.x; b <= hi_bits;
+         b += (unsigned long long)gridDim.x * 256) {
+        const float m = __uint_as_float((unsigned)b);
+        const float fast = agcw_gain_fast(cx, reference, m), exact = fdiv_rn(reference, m);
+        if (__float_as_uint(fast) != __float_as_uint(exact)) {
+            bad++;
+            atomicMax(example, (unsigned)b);
+        }
+    }
+    if (bad)
+        atomicAdd(count, bad);
+}
+
+extern "C" int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example)
+{
+    if (!count)
+        return AISX_ERR_INVALID;
+    int rc = require_device();
+    if (rc != AISX_OK)
+        return rc;
+    if (!agcw_fast_reference(reference)) {
+        set_err("aisx_util_agc_rcp_mismatches: %g is not a reference the reciprocal form serves", reference);
+        return AISX_ERR_INVALID;
+    }
+    unsigned long long* d_count = nullptr;
+    unsigned* d_ex = nullptr;
+    if ((rc = dev_alloc(&d_count, 1)) != AISX_OK || (rc = dev_alloc(&d_ex, 1)) != AISX_OK) {
+        dev_free(d_count);
+        return rc;
+    }
+    unsigned lo, hi, ex = 0;
+    const float flo = AGW_RCP_LO, fhi = AGW_RCP_HI;
+    memcpy(&lo, &flo, 4);
+    memcpy(&hi, &fhi, 4);
+    hipLaunchKernelGGL(k_agc_rcp_sweep, dim3(256 * 32), dim3(256), 0, 0, reference, lo, hi, d_count, d_ex);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy(count, d_count, sizeof(*count), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(&ex, d_ex, sizeof(ex), hipMemcpyDeviceToHost);
+    dev_free(d_count);
+    dev_free(d_ex);
+    if (e != hipSuccess) {
+        set_err("aisx_util_agc_rcp_mismatches: %s", hipGetErrorString(e));
+        return AISX_ERR_HIP;
+    }
+    if (example)
+        memcpy(example, &ex, 4);
+    return AISX_OK;
+}
+
 __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,7 +128,26 @@ __global__ __launch_bounds__(AGC_T) void k_agc(AgcParams p)
 }
 
 // ---------------------------------------------------------------------------
+// GNU Radio path staging: device buffers the *_work_host calls copy through, kept between calls and only ever
+// grown (a scheduler calls work() thousands of times a second with similar sizes)
+template <class T>
+static int stage_grow(T** buf, size_t* cap, size_t need)
+{
+    if (need <= *cap)
+        return AISX_OK;
+    dev_free(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    const int rc = dev_alloc(buf, need, false);
+    if (rc == AISX_OK)
+        *cap = need;
+    return rc;
+}
+
 struct aisx_freqsync {
+    cf *d_hst_in = nullptr, *d_hst_out = nullptr; // aisx_freqsync_work_host
+    float* d_hst_fh = nullptr;
+    size_t hst_in_cap = 0, hst_out_cap = 0, hst_fh_cap = 0;
     int nchan = 0, fftlen = 0, max_items = 0, offset = 0, max_vec = 0;
     float binsize = 0, sensitivity = 0;
     cf* d_pend[2] = { nullptr, nullptr };
@@ -248,6 +326,9 @@ extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
             (void)hipEventDestroy(e);
     dev_free(h->d_st_vec);
     dev_free(h->d_st_out);
+    dev_free(h->d_hst_in);
+    dev_free(h->d_hst_out);
+    dev_free(h->d_hst_fh);
     dev_free(h->d_sintab);
     delete h;
     return AISX_OK;
@@ -375,13 +456,13 @@ extern "C" int aisx_freqsync_work_host(aisx_freqsync* h, const aisx_cf32* in, in
         set_err("aisx_freqsync_work_host: output buffer too small for %d vectors", nvec);
         return AISX_ERR_INVALID;
     }
-    cf *d_in = nullptr, *d_out = nullptr;
-    float* d_fh = nullptr;
-    int rc = dev_alloc(&d_in, n, false);
+    int rc = stage_grow(&h->d_hst_in, &h->hst_in_cap, (size_t)n);
     if (rc == AISX_OK)
-        rc = dev_alloc(&d_out, (size_t)nvec * h->fftlen + 1, false);
+        rc = stage_grow(&h->d_hst_out, &h->hst_out_cap, (size_t)nvec * h->fftlen + 1);
     if (rc == AISX_OK && fhat)
-        rc = dev_alloc(&d_fh, nvec + 1, false);
+        rc = stage_grow(&h->d_hst_fh, &h->hst_fh_cap, (size_t)nvec + 1);
+    cf *d_in = h->d_hst_in, *d_out = h->d_hst_out;
+    float* d_fh = fhat ? h->d_hst_fh : nullptr;
     int nout = 0;
     if (rc == AISX_OK && hipMemcpy(d_in, in, sizeof(cf) * n, hipMemcpyHostToDevice) != hipSuccess)
         rc = AISX_ERR_HIP;
@@ -394,9 +475,6 @@ extern "C" int aisx_freqsync_work_host(aisx_freqsync* h, const aisx_cf32* in, in
         rc = AISX_ERR_HIP;
     if (rc == AISX_OK && hipDeviceSynchronize() != hipSuccess)
         rc = AISX_ERR_HIP;
-    dev_free(d_in);
-    dev_free(d_out);
-    dev_free(d_fh);
     return rc == AISX_OK ? nout : rc;
 }
 
@@ -439,6 +517,9 @@ struct aisx_agc {
     cf* d_hist[2] = { nullptr, nullptr };
     int cur = 0;
     bool tiles_only = false; // aisx_agc_set_streaming(h, 0): the tile kernels for every call
+    int lds_claim = 0; // aisx_agc_set_lds_claim: LDS a streaming workgroup claims beyond the 8 KB it uses
+    cf *d_hst_in = nullptr, *d_hst_out = nullptr; // aisx_agc_work_host's staging (grown, never shrunk)
+    size_t hst_in_cap = 0, hst_out_cap = 0;
 };
 
 extern "C" int aisx_agc_geometry(const aisx_agc* h, int* nchan, int* max_items, int* nsamples, int* fused_ok)
@@ -505,6 +586,16 @@ extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
     return AISX_OK;
 }
 
+extern "C" int aisx_agc_set_lds_claim(aisx_agc* h, int bytes)
+{
+    if (!h || bytes < 0 || bytes > 56 * 1024) { // (8 KB + the claim stays within the 64 KB a launch may ask for unraised)
+        set_err("aisx_agc_set_lds_claim: 0 .. 57344 bytes");
+        return AISX_ERR_INVALID;
+    }
+    h->lds_claim = bytes;
+    return AISX_OK;
+}
+
 extern "C" int aisx_agc_set_streaming(aisx_agc* h, int on)
 {
     if (!h)
@@ -519,6 +610,8 @@ extern "C" int aisx_agc_destroy(aisx_agc* h)
         return AISX_OK;
     dev_free(h->d_hist[0]);
     dev_free(h->d_hist[1]);
+    dev_free(h->d_hst_in);
+    dev_free(h->d_hst_out);
     delete h;
     return AISX_OK;
 }
@@ -633,7 +726,8 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.maxpos_stride = h->max_vec;
     e.nvec = nvec;
     e.offset = h->offset;
-    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+    static const int est_pad = getenv("AISX_EST_LDS_PAD") ? atoi(getenv("AISX_EST_LDS_PAD")) : 0; // (experiments: placement)
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES + est_pad, st, e);
     AISX_HIPCHK(hipGetLastError());
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
         AISX_HIPCHK(hipEventRecord(h->ev_est, st));
@@ -772,8 +866,9 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.pend_out = h->d_pend[h->cur ^ 1];
     p.npend = h->npend;
     p.n_raw = n;
+    static const int agcw_pad = getenv("AISX_AGCW_LDS_PAD") ? atoi(getenv("AISX_AGCW_LDS_PAD")) : -1; // (experiments: overrides the handle's claim)
     if (agcw_applies(p.W, total) && !a->tiles_only)
-        hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), AGW_LDS_BYTES, st, p);
+        hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), AGW_LDS_BYTES + (agcw_pad >= 0 ? agcw_pad : a->lds_claim), st, p);
     else
         hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES_MIXED, st, p);
     AISX_HIPCHK(hipGetLastError());
@@ -801,10 +896,10 @@ extern "C" int aisx_agc_work_host(aisx_agc* h, int noutput_items, const aisx_cf3
         return AISX_ERR_INVALID;
     }
     const int H = h->W - 1, n = noutput_items;
-    cf *d_in = nullptr, *d_out = nullptr;
-    int rc = dev_alloc(&d_in, n, false);
+    int rc = stage_grow(&h->d_hst_in, &h->hst_in_cap, (size_t)n);
     if (rc == AISX_OK)
-        rc = dev_alloc(&d_out, n, false);
+        rc = stage_grow(&h->d_hst_out, &h->hst_out_cap, (size_t)n);
+    cf *d_in = h->d_hst_in, *d_out = h->d_hst_out;
     // the block's history comes from the scheduler's buffer, not from the handle
     if (rc == AISX_OK && H > 0 && hipMemcpy(h->d_hist[h->cur], in, sizeof(cf) * H, hipMemcpyHostToDevice) != hipSuccess)
         rc = AISX_ERR_HIP;
@@ -814,8 +909,6 @@ extern "C" int aisx_agc_work_host(aisx_agc* h, int noutput_items, const aisx_cf3
         rc = aisx_agc_process(h, (const aisx_cf32*)d_in, n, (aisx_cf32*)d_out, n, n, nullptr);
     if (rc == AISX_OK && hipMemcpy(out, d_out, sizeof(cf) * n, hipMemcpyDeviceToHost) != hipSuccess)
         rc = AISX_ERR_HIP;
-    dev_free(d_in);
-    dev_free(d_out);
     return rc == AISX_OK ? n : rc;
 }
 

@@ -29,6 +29,7 @@
 // the one item i = n - 1 that opens block NB-1 (its window is that whole block).  A wave takes
 // AGW_RUN consecutive output blocks and reads one block more (1 / AGW_RUN of halo).
 #pragma once
+#include <type_traits>
 #include "k_agc.h"
 
 namespace aisx {
@@ -102,6 +103,39 @@ AISX_HD int nco_folded_to_fixed(float x)
 }
 AISX_HD int nco_phase_to_fixed(float x) { return nco_folded_to_fixed(nco_fold_ok(x) ? nco_fold_fast(x) : nco_fold_general(x)); }
 
+// the gain reference / max_env.  With a power-of-two reference (the stock 2.0) it is the correctly
+// rounded reciprocal scaled exactly: v_rcp_f32 (1 ulp) and one Newton step give that reciprocal for
+// every max_env in [2^-100, 2^100] -- settled exhaustively on the device (round 3; the sweep is
+// aisx_util_agc_rcp_mismatches, tests/test_gpu_stages.py runs it again) -- four instructions where
+// the division sequence takes eleven.  Anything else divides.
+constexpr float AGW_RCP_LO = 7.888609052210118e-31f, AGW_RCP_HI = 1.2676506002282294e30f; // 2^-100, 2^100
+template <class Ctx>
+AISX_DI float agcw_gain_fast(const Ctx& cx, float reference, float max_env)
+{
+    const float r0 = cx.rcp_approx(max_env);
+    const float e = fmaf(-max_env, r0, 1.0f);
+    const float r1 = fmaf(e, r0, r0);
+    return r1 * reference; // (an exact scaling)
+}
+// is `reference` a power of two whose scaling of a reciprocal in [2^-100, 2^100] can neither overflow nor go subnormal?
+AISX_HD bool agcw_fast_reference(float reference)
+{
+    int ex = 0;
+    const float m = frexpf(reference, &ex);
+    return m == 0.5f && ex > -20 && ex < 20;
+}
+
+// envelope(x) of feedforward_agc_cc with a NaN mapped to 0 (std::max never selects it; 0 is below any
+// positive floor): the IEEE maximum of (e, 0) is that in one instruction (e >= 0 otherwise)
+AISX_HD float agcw_envelope(cf x)
+{
+    const float r_abs = fabsf(x.re), i_abs = fabsf(x.im);
+    const bool rg = r_abs > i_abs;
+    const float big = rg ? r_abs : i_abs, small = rg ? i_abs : r_abs;
+    const float e = (float)((double)big + 0.4 * (double)small);
+    return fmaxf(e, 0.0f);
+}
+
 template <bool MIXED, class Ctx>
 AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
 {
@@ -124,6 +158,7 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
         return;
     const int ob1 = (ob0 + AGW_RUN < NB) ? ob0 + AGW_RUN : NB;
     const bool last_run = ob1 == NB;
+    const int B0 = ob0 - 1, Bend = ob1 - 1; // blocks B0 .. Bend are read, B0 .. Bend - 1 give outputs
 
     constexpr int H = AGW_W - 1;
     const cf* xin = p.in + (long)c * p.in_stride;
@@ -134,6 +169,9 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
     const float* phi = MIXED ? p.phases + (long)c * p.phases_stride : nullptr;
     const float* dv = MIXED ? p.dvec + (long)c * p.dvec_stride : nullptr;
     const int floor_i = f2i(p.floor_env);
+    // (wave-uniform) the reciprocal form of the gain serves this call: reference and floor in its range
+    const bool fast_ref = agcw_fast_reference(p.reference) && p.floor_env >= AGW_RCP_LO;
+    const int rcp_hi_i = f2i(AGW_RCP_HI);
 
     // what a block's lane loads: its 8 raw items (history: already mixed), the NCO checkpoint that
     // opens the group and the increment of the group's vector (a block lies in one 1024-vector)
@@ -141,10 +179,12 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
         cf v[AGW_G];
         float ck, d;
     };
-    auto load = [&](int B, Raw& R) {
+    // INTERIOR: the block lies wholly in the new samples (16-byte loads); otherwise any block
+    auto load = [&](auto INTERIOR, int B, Raw& R) {
+        constexpr bool interior = decltype(INTERIOR)::value;
         R.ck = 0.f;
         R.d = 0.f;
-        if (B < 0) { // the history: j = 8 l + k - 1
+        if (!interior && B < 0) { // the history: j = 8 l + k - 1
 #pragma unroll
             for (int k = 0; k < AGW_G; k++) {
                 const int j = AGW_G * l + k - 1;
@@ -153,7 +193,7 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
             return;
         }
         const int m0 = AGW_W * B + AGW_G * l;
-        if (AGW_W * B >= npend) { // (wave-uniform) wholly inside the new samples: 16-byte loads
+        if (interior || AGW_W * B >= npend) { // (wave-uniform)
             const cf_pair_agc* src = (const cf_pair_agc*)(xin + (m0 - npend));
 #pragma unroll
             for (int k = 0; k < AGW_G / 2; k++) {
@@ -175,15 +215,16 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
     };
 
     // a block with its items mixed, their envelopes' prefix / suffix maxima inside the lane (bit
-    // patterns), and the maxima over all lanes before / behind this one
+    // patterns), the maxima over all lanes before / behind this one and over the whole wave
     struct Blk {
         cf v[AGW_G];
         int pfx[AGW_G], sfx[AGW_G];
-        int xp, xs;
+        int xp, xs, all;
     };
-    auto finish = [&](int B, const Raw& R, Blk& K) {
+    auto finish = [&](auto INTERIOR, int B, const Raw& R, Blk& K) {
+        constexpr bool interior = decltype(INTERIOR)::value;
         float e[AGW_G];
-        if (MIXED && B >= 0) {
+        if (MIXED && (interior || B >= 0)) {
             // phases of the group: the checkpoint is item 0's (m0 is a multiple of NCO_CK = 8), the others are
             // walked again with the walk's own statement (fs_walk_body)
             static_assert(NCO_CK == AGW_G, "one checkpoint opens each lane's group");
@@ -214,13 +255,12 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
                 for (int k = 0; k < AGW_G; k++)
                     f[k] = nco_fold_general(f[k]);
             }
-            const cf* T = reinterpret_cast<const cf*>(ST);
 #pragma unroll
             for (int k = 0; k < AGW_G; k++) {
                 // [GR] frequency_modulator_fc: gr::fxpt::sincos(float_to_fixed(d_phase)); multiply_cc
                 const unsigned x = (unsigned)nco_folded_to_fixed(f[k]);
                 const unsigned xc = x + 0x40000000u;
-                const cf es = ld8(T + (x >> 22)), ec = ld8(T + (xc >> 22));
+                const cf es = cx.lds_cf(ST, x >> 22), ec = cx.lds_cf(ST, xc >> 22);
                 const float sn = es.re * (float)(x >> 1) + es.im;
                 const float cs = ec.re * (float)(xc >> 1) + ec.im;
                 K.v[k] = cmul_exact(R.v[k], mk(cs, sn));
@@ -232,8 +272,8 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
         }
 #pragma unroll
         for (int k = 0; k < AGW_G; k++)
-            e[k] = agc_envelope(K.v[k]);
-        if (B < 0 && l == 0)
+            e[k] = agcw_envelope(K.v[k]);
+        if (!interior && B < 0 && l == 0)
             e[0] = 0.f; // j = -1: before the stream (0 never wins: the floor is positive)
         K.pfx[0] = f2i(e[0]);
 #pragma unroll
@@ -244,26 +284,36 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
         for (int k = AGW_G - 2; k >= 0; k--)
             K.sfx[k] = imax(K.sfx[k + 1], f2i(e[k]));
         K.xp = cx.wave_excl_prefix_max_nn(K.pfx[AGW_G - 1]);
-        K.xs = cx.wave_excl_suffix_max_nn(K.pfx[AGW_G - 1]);
-    };
-    auto gain_of = [&](int mx) -> float {
-        mx = imax(mx, floor_i);
-        return fdiv_rn(p.reference, i2f(mx));
+        K.xs = cx.wave_excl_suffix_max_nn(K.pfx[AGW_G - 1], K.all);
     };
     // outputs of block B (all of its items) given the block behind it
-    auto emit = [&](int B, const Blk& K, const Blk& Nx) {
+    auto emit = [&](auto INTERIOR, int B, const Blk& K, const Blk& Nx) {
+        constexpr bool interior = decltype(INTERIOR)::value;
         const int a = imax(K.xs, Nx.xp); // the 63 whole groups between the item's own and the window's last
-        cf o[AGW_G];
+        int mx[AGW_G];
 #pragma unroll
         for (int k = 0; k < AGW_G; k++) {
-            int mx = imax(K.sfx[k], a);
+            mx[k] = imax(K.sfx[k], a);
             if (k > 0)
-                mx = imax(mx, Nx.pfx[k - 1]);
-            const float g = gain_of(mx);
-            o[k] = mk(g * K.v[k].re, g * K.v[k].im);
+                mx[k] = imax(mx[k], Nx.pfx[k - 1]);
+            mx[k] = imax(mx[k], floor_i);
+        }
+        cf o[AGW_G];
+        if (fast_ref && imax(K.all, Nx.all) <= rcp_hi_i) { // (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < AGW_G; k++) {
+                const float g = agcw_gain_fast(cx, p.reference, i2f(mx[k]));
+                o[k] = mk(g * K.v[k].re, g * K.v[k].im);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < AGW_G; k++) {
+                const float g = fdiv_rn(p.reference, i2f(mx[k]));
+                o[k] = mk(g * K.v[k].re, g * K.v[k].im);
+            }
         }
         const int i0 = AGW_W * B + H + AGW_G * l;
-        if (B >= 0) {
+        if (interior || B >= 0) {
             cf_pair_agc* dst = (cf_pair_agc*)(xout + i0);
 #pragma unroll
             for (int k = 0; k < AGW_G / 2; k++) {
@@ -279,28 +329,48 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
                     xout[i0 + k] = o[k];
         }
     };
+    // One step at block X: load block X + 1, finish block X, emit block X - 1.  `mine` raw / block belong to X,
+    // `other` to X - 1 before the step and to X + 1 (raw) after it.
+    auto step = [&](auto INTERIOR, int X, Raw& r_mine, Raw& r_other, Blk& k_mine, const Blk& k_other) {
+        if (X + 1 <= Bend)
+            load(INTERIOR, X + 1, r_other);
+        finish(INTERIOR, X, r_mine, k_mine);
+        if (X > B0)
+            emit(INTERIOR, X - 1, k_other, k_mine);
+    };
+    std::integral_constant<bool, false> ANY;
+    std::integral_constant<bool, true> INNER;
 
-    Raw r1, r2;
-    Blk cur, nxt;
-    {
-        Raw r0;
-        load(ob0 - 1, r0);
-        load(ob0, r1);
-        finish(ob0 - 1, r0, cur);
+    Raw rA, rB;
+    Blk kA, kB;
+    int X = B0;
+    load(ANY, X, rA);
+    // steps that touch the history, the pending items or the run's first block: one copy of the code, blocks
+    // handed on by assignment (a wave takes one, the first run of a channel two to four)
+    while (X <= Bend && !(X > B0 && X >= 1 && AGW_W * (X + 1) >= npend)) {
+        step(ANY, X, rA, rB, kA, kB);
+        rA = rB;
+        kB = kA;
+        X++;
     }
-    for (int B = ob0 - 1; B < ob1 - 1; B++) {
-        if (B + 2 < ob1) // (the block behind the next one, while that one is computed)
-            load(B + 2, r2);
-        finish(B + 1, r1, nxt);
-        emit(B, cur, nxt);
-        cur = nxt;
-        r1 = r2;
+    // (kB = block X - 1, rA = raw of block X)  interior steps in pairs: the two sets of registers swap roles
+    bool final_in_A = false; // where the block finished last stands: kB after the loop above
+    while (X <= Bend) {
+        step(INNER, X, rA, rB, kA, kB);
+        X++;
+        final_in_A = true;
+        if (X > Bend)
+            break;
+        step(INNER, X, rB, rA, kB, kA);
+        X++;
+        final_in_A = false;
     }
-    if (last_run) {
-        // `cur` is block NB - 1: its first item is output n - 1 (window = the whole block), the
-        // others are the history the next call starts from (set_history(nsamples))
+    // the block finished last is NB - 1: its first item is output n - 1 (window = the whole block), the
+    // others are the history the next call starts from (set_history(nsamples))
+    auto epilogue = [&](const Blk& cur) {
         if (l == 0) {
-            const float g = gain_of(imax(cur.sfx[0], cur.xs));
+            const int mx = imax(imax(cur.sfx[0], cur.xs), floor_i);
+            const float g = fdiv_rn(p.reference, i2f(mx));
             xout[n - 1] = mk(g * cur.v[0].re, g * cur.v[0].im);
         }
         cf* ho = p.hist_out + (long)c * H;
@@ -318,6 +388,12 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
                 po[i] = (m < npend) ? pend[m] : xin[m - npend];
             }
         }
+    };
+    if (last_run) { // (two calls, not a choice of block: the blocks are registers)
+        if (final_in_A)
+            epilogue(kA);
+        else
+            epilogue(kB);
     }
 }
 

@@ -60,6 +60,12 @@ constexpr int CD_IMG = 16 * CF4_ROW;               // complex slots per window i
 //                     wave (the inverse direction mirrors it).  Only the exchanges between the pass
 //                     over n1 and the pass over n2 cross waves: three workgroup barriers per tile
 //                     instead of five.  0 = a workgroup barrier at all four exchanges (round 2).
+//   CD_GENERIC_W_REGS 1 = the run-time-length build (NC = 0) keeps the first / last pass twiddles in registers like the
+//                     folded builds: 9 VGPRs spilled to scratch (40 B per lane) + 222 SGPR spills (round 4's build).
+//                     0 = it reads them where it uses them: no scratch (round 5; A/B in DESIGN.md section 8).
+#ifndef CD_GENERIC_W_REGS
+#define CD_GENERIC_W_REGS 0
+#endif
 #ifndef CD_WAVE_EXCHANGE
 #define CD_WAVE_EXCHANGE 1
 #endif
@@ -103,7 +109,7 @@ AISX_DI void corr4d_main_body(Ctx& cx, const CorrParams& p)
     // (the run-time-length build, NC = 0, has sixteen slice predicates live as lane masks on top of this and
     // does not fit 256 VGPRs with the first / last pass twiddles resident: it reads them from the 32 KB
     // table -- L1 / L2 hits -- where it uses them; the folded builds keep them)
-    constexpr bool W_REGS = NC != 0;
+    constexpr bool W_REGS = NC != 0 || CD_GENERIC_W_REGS;
     cf w[16], H[16];
     w[0] = mk(1.f, 0.f);
 #pragma unroll

@@ -99,7 +99,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
             X[k1 * FS_ROW + k2 * 4 + n3] = x[k2];
     }
     cx.wave_lds_sync();
-    float a[16];
+    cf y[16];
     int kk[16];
 #pragma unroll
     for (int h = 0; h < 4; h++) {
@@ -108,31 +108,74 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
         cf y2 = X[k1 * FS_ROW + k2 * 4 + 2], y3 = X[k1 * FS_ROW + k2 * 4 + 3];
         dft4<false>(cx, y0, y1, y2, y3);
         const int kb = k1 + 16 * k2; // frequency index k = kb + 256*k3
-        a[4 * h + 0] = cabs_f(y0);
-        a[4 * h + 1] = cabs_f(y1);
-        a[4 * h + 2] = cabs_f(y2);
-        a[4 * h + 3] = cabs_f(y3);
+        y[4 * h + 0] = y0;
+        y[4 * h + 1] = y1;
+        y[4 * h + 2] = y2;
+        y[4 * h + 3] = y3;
         kk[4 * h + 0] = kb;
         kk[4 * h + 1] = kb + 256;
         kk[4 * h + 2] = kb + 512;
         kk[4 * h + 3] = kb + 768;
     }
     cx.wave_lds_sync();
-    // |X| in fft-shifted order: out[j] = X[(j + F/2) mod F]  <=>  j = (k + F/2) mod F
-    float* A = (float*)X;
+    // the spectrum in fft-shifted order: S(j) = X[(j + F/2) mod F]  <=>  j = (k + F/2) mod F.  Item j lives in
+    // slot j + (j >> 4): neighbouring lanes write j's that differ by 16 (k = k1 + 16 k2 + 256 k3 with k2 = l & 15),
+    // which in a dense array is one bank pair for all of them; with one slot skipped per 16 the stride is 17.
+    // The readers (consecutive j) lose nothing.  1024 + 64 slots = FS_WAVE_ELEMS exactly.
+    static_assert(FS_F + FS_F / 16 <= FS_WAVE_ELEMS, "the padded spectrum fits the wave's LDS");
+    cf* S = X;
+    auto sl = [](int j) { return j + (j >> 4); };
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        A[(kk[e] + FS_F / 2) & (FS_F - 1)] = a[e];
+        S[sl((kk[e] + FS_F / 2) & (FS_F - 1))] = y[e];
     cx.wave_lds_sync();
-    // freqest search (lib/freqest_impl.cc:74-83)
+    // freqest search (lib/freqest_impl.cc:74-83): the first strict maximum of e[j] = |S[j]| + |S[j + offset]|,
+    // each magnitude glibc's hypotf (cabs_f: double products, a double square root -- ~45 issue slots).
+    // Round 5: that exact form is evaluated only where it can matter.  Pass 1 scores every j in single
+    // precision (two products, a sum, v_sqrt_f32: within 3e-7 of the exact e[j]) and takes the wave's
+    // maximum E; pass 2 evaluates the exact e[j] for the j whose score is within 4e-6 of E -- every other
+    // j is below the exact maximum by more than both errors together and can neither be it nor tie it.
+    // The result is the exact search's, bit for bit.  Scores the bound does not cover (E below 1e-10:
+    // squares that underflow; above 1e18: squares that overflow; all-zero vectors) take pass 2 for every j.
+    const int span = FS_F - p.offset;
+    constexpr int NJ = FS_F / 64;
+    float sc[NJ];
+    float emax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+        const int j = l + 64 * i;
+        sc[i] = -1.f;
+        if (j < span) {
+            const cf a0 = S[sl(j)], a1 = S[sl(j + p.offset)];
+            sc[i] = cx.sqrt_approx(a0.re * a0.re + a0.im * a0.im) + cx.sqrt_approx(a1.re * a1.re + a1.im * a1.im);
+            emax = fmaxf(emax, sc[i]); // (a NaN score is skipped here as the exact search skips a NaN sum)
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        emax = fmaxf(emax, cx.shfl_xor_f32(emax, o));
+    const bool covered = emax >= 1e-10f && emax <= 1e18f;
+    const float thr = covered ? emax * (1.0f - 4e-6f) : -1.f;
+    unsigned cand = 0; // slots of this lane that pass 2 evaluates
+#pragma unroll
+    for (int i = 0; i < NJ; i++)
+        if (l + 64 * i < span && (sc[i] >= thr || !covered))
+            cand |= 1u << i;
     float best = 0.f;
     int bestj = -1;
-    const int span = FS_F - p.offset;
-    for (int j = l; j < span; j += 64) {
-        const float e = A[j] + A[j + p.offset];
-        if (e > best) {
-            best = e;
-            bestj = j;
+    // (one copy of the exact form, run as often as the busiest lane has candidates: once or twice as a rule;
+    // slots are taken in rising order, so a lane meets its j in the sequential loop's order)
+#pragma nounroll
+    while (cx.ballot(cand != 0u) != 0ull) {
+        if (cand != 0u) {
+            const int i = __builtin_ctz(cand);
+            cand &= cand - 1u;
+            const int j = l + 64 * i;
+            const float e = cabs_f(S[sl(j)]) + cabs_f(S[sl(j + p.offset)]);
+            if (e > best) {
+                best = e;
+                bestj = j;
+            }
         }
     }
 #pragma unroll

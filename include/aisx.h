@@ -69,6 +69,11 @@ int aisx_set_device(int device);
  * with hipEvents and no profiler attached: what "HBM-bound" can mean on this chip next to the
  * 8 TB/s spec peak */
 int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs);
+/* test hook: the streaming AGC kernel (k_agcw.h) forms the gain reference / max_env as a refined
+ * hardware reciprocal when the reference is a power of two (the stock 2): this sweeps EVERY float
+ * max_env in [2^-100, 2^100] on the device and counts those for which that differs from the
+ * correctly rounded float division (*count must come back 0; *example = the largest such value) */
+int aisx_util_agc_rcp_mismatches(float reference, unsigned long long* count, float* example);
 /* ------------------------------------------------------------------------ */
 /* corr_est_cc  (include/ais/corr_est_cc.h:85-106, lib/corr_est_cc_impl.cc)  */
 /* ------------------------------------------------------------------------ */
@@ -221,6 +226,11 @@ int aisx_msk_last_status(aisx_msk* h, int* status, void* stream);
  * state equals what the next unit assumed, out of this many, items of the longest unit, items of all
  * units }.  Waits for `stream`. */
 int aisx_msk_restart_stats(aisx_msk* h, long long* out10, void* stream);
+/* measurement hook, as aisx_corr_set_profiling: when on, every aisx_msk_process_stream call (serial
+ * kernel) brackets the recovery kernel with hipEvents on its stream; aisx_msk_kernel_ms_history returns
+ * the durations of the calls made since it was switched on (the most recent 64 at most), oldest first */
+int aisx_msk_set_profiling(aisx_msk* h, int on);
+int aisx_msk_kernel_ms_history(aisx_msk* h, float* ms, int cap, int* n);
 /* The NRZI bit tail (quadrature demod .. invert, python/ais_demod.py:48-52) has no part in
  * the timing recurrence.  With a tail stream set (enable != 0) aisx_msk_process_stream
  * launches it there, ordered after the call's recovery kernel, so that the next call need
@@ -321,6 +331,15 @@ int aisx_agc_set_floor(aisx_agc* h, float floor_env);
  * the tile kernels (k_agc.h).  Same results bit for bit; on = 0 keeps the tile kernels for every
  * call (A/B measurements, twin tests).  Default on.  Not part of the GNU Radio API. */
 int aisx_agc_set_streaming(aisx_agc* h, int on);
+/* Placement of the streaming kernel's workgroups when it runs BESIDE the timing recovery (the pipelined
+ * chain): a workgroup uses 8 KB of LDS; claiming `bytes` more decides how many of them the dispatcher
+ * puts on the 128 CUs that hold a recovery workgroup (92 160 of 163 840 B taken) without touching the
+ * other CUs.  The recovery is a recurrence that every co-resident wave delays; this kernel is the densest
+ * arithmetic of the chain.  Measured (round 5, 4096 channels, three interleaved runs each): one
+ * workgroup beside the recovery instead of three shortens the step by 4.6 % (5.49 against 5.76 ms).
+ * aisx_chain_create sets 30 720 (one beside the recovery, four elsewhere); default 0.  Results do
+ * not depend on it.  Environment AISX_AGCW_LDS_PAD overrides (experiments). */
+int aisx_agc_set_lds_claim(aisx_agc* h, int bytes);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
 /* square_and_fft_sync_cc -> feedforward_agc_cc, the first two blocks of python/ais_demod.py:56, in

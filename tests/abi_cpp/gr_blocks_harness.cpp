@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <stdexcept>
 #include <vector>
 
@@ -152,6 +153,7 @@ static int run(const char* path)
     size_t si = 0, cj = 0, mki = 0, ncalls = 0;
     std::vector<cf> y1(1 << 17), y2, yc;
 
+    const auto t_start = std::chrono::steady_clock::now();
     for (int pos = 0; pos < T;) {
         const int piece = std::min(src_pieces[si++ % src_pieces.size()], T - pos);
         const int n1 = aisx_freqsync_work_host(fs, reinterpret_cast<const aisx_cf32*>(x.data() + pos), piece, reinterpret_cast<aisx_cf32*>(y1.data()),
@@ -235,6 +237,11 @@ static int run(const char* path)
             }
         }
     }
+
+    const double host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    // (one channel through work() / general_work() with host buffers, every call copying in, launching and
+    // copying out synchronously: what the drop-in costs at nchan = 1 -- bench.py quotes it beside the CPU's)
+    printf("HOST_PATH samples=%d seconds=%.6f MSs=%.4f\n", T, host_seconds, (double)T / host_seconds / 1e6);
 
     // ---- gates: those of sched_harness.cpp
     if ((int)store.size() != ntags_want) {

@@ -147,7 +147,7 @@ struct EmuCtx {
             r = std::max(r, (int)(unsigned)b[wave_base() + i]);
         return r;
     }
-    int wave_excl_suffix_max_nn(int v) const
+    int wave_excl_suffix_max_nn(int v, int& all) const
     {
         unsigned long long* b = bank();
         b[tid_] = (unsigned long long)(unsigned)v;
@@ -155,8 +155,14 @@ struct EmuCtx {
         int r = 0;
         for (int i = (tid_ & 63) + 1; i < 64 && wave_base() + i < sh->nthreads; i++)
             r = std::max(r, (int)(unsigned)b[wave_base() + i]);
+        all = r;
+        for (int i = 0; i <= (tid_ & 63); i++)
+            all = std::max(all, (int)(unsigned)b[wave_base() + i]);
         return r;
     }
+    float rcp_approx(float x) const { return 1.0f / x; } // (the lane model's is correctly rounded; the device's is within 1 ulp)
+    float sqrt_approx(float x) const { return sqrtf(x); }
+    cf lds_cf(const float* tab, unsigned idx) const { return ld8(reinterpret_cast<const cf*>(tab) + idx); }
     unsigned lane_prev_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l > 0 ? l - 1 : l); return l > 0 ? r : 0u; }
     unsigned lane_next_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l < 63 ? l + 1 : l); return l < 63 ? r : 0u; }
     unsigned long long shfl_u64(unsigned long long v, int src) const { return xchg(v, src); }

@@ -30,7 +30,32 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        _LIB = _bind(C.CDLL(build()))
+    return _LIB
+
+
+class use_library:
+    """with use_library(path): every oracle_py object created AND used inside talks to the oracle built
+    at `path` instead (tests/test_table_sensitivity.py: the same C file compiled against perturbed tables)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _LIB
+        lib()
+        self.saved = _LIB
+        _LIB = _bind(C.CDLL(self.path))
+        return _LIB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.saved
+        return False
+
+
+def _bind(L):
+    if True:
         vp, i32, u32, f32, f64, u64 = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_uint64
         pi32 = C.POINTER(C.c_int)
         L.orc_fast_atan2f.restype = f32
@@ -105,8 +130,7 @@ def lib():
         L.orc_freq_xlating_fir.argtypes = [vp, i32, i32, f64, f64, vp, C.c_long, C.c_long, i32, vp]
         L.orc_firdes_low_pass.restype = i32
         L.orc_firdes_low_pass.argtypes = [f64, f64, f64, f64, vp, i32]
-        _LIB = L
-    return _LIB
+    return L
 
 
 def _c64(a):

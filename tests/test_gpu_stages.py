@@ -511,3 +511,38 @@ def test_streaming_front_end_equals_tile_kernels_at_full_size(ais):
             want = oag[c].work(yo) if yo.size else yo
             assert np.array_equal(a[c].view(np.uint32), want.view(np.uint32)), (L, c)
         k += L
+
+
+def test_streaming_agc_reciprocal_is_the_division(ais):
+    # k_agcw.h: agcw_gain_fast -- with a power-of-two reference (the stock 2) the gain is one Newton step
+    # from v_rcp_f32, scaled exactly, instead of the IEEE division sequence.  The hook sweeps EVERY float
+    # max_env in [2^-100, 2^100] (1.68e9 values) on the device: it must agree with the division in
+    # every bit, for the stock reference and two other powers of two.  Other references and maxima
+    # beyond the range divide: checked against the oracle on the kernel itself.
+    import ctypes as C
+    from ais_amd import _lib
+
+    for ref in (2.0, 1.0, 0.25):
+        cnt, ex = C.c_ulonglong(123), C.c_float(0)
+        _lib.check(_lib.lib().aisx_util_agc_rcp_mismatches(ref, C.byref(cnt), C.byref(ex)), "sweep")
+        assert cnt.value == 0, (ref, cnt.value, ex.value)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().aisx_util_agc_rcp_mismatches(3.0, C.byref(cnt), C.byref(ex)), "sweep")
+    rng = np.random.default_rng(12)
+    x = (rng.normal(size=(3, 8192)) + 1j * rng.normal(size=(3, 8192))).astype(np.complex64)
+    out = ais.feedforward_agc_cc(512, 1.7, nchan=3, max_items=8192).work(_dev(x)).cpu().numpy()
+    for c in range(3):
+        assert np.array_equal(out[c].view(np.uint32), orc.Agc(512, 1.7).work(x[c]).view(np.uint32))
+    y = x.copy()
+    y[:, 3000:3600] *= np.float32(1e33)  # maxima beyond 2^100 in some blocks, not in others
+    y[1, 5000] = complex(3e38, 0)
+    out = ais.feedforward_agc_cc(512, 2.0, nchan=3, max_items=8192).work(_dev(y)).cpu().numpy()
+    for c in range(3):
+        assert np.array_equal(out[c].view(np.uint32), orc.Agc(512, 2.0).work(y[c]).view(np.uint32))
+    a = ais.feedforward_agc_cc(512, 2.0, nchan=3, max_items=8192)
+    a.set_floor(1e-12)
+    z = x.copy()
+    z[0, 1000:4000] = 0
+    out = a.work(_dev(z)).cpu().numpy()
+    for c in range(3):
+        assert np.array_equal(out[c].view(np.uint32), orc.Agc(512, 2.0, floor=1e-12).work(z[c]).view(np.uint32))

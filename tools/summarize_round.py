@@ -128,10 +128,10 @@ for k, v in ker.items():
         continue
     rows[k] = {"launches": len(v.get("fetch", [])), "fetch_GB": statistics.median(v.get("fetch", [0.0])) * 2 * 1024 / 1e9,
                "write_GB": statistics.median(v.get("write", [0.0])) * 1024 / 1e9}
-stream = [k for k in rows if k.startswith(("k_fs_est", "k_fs_walk", "k_agc8", "k_corr4d_main", "k_corr_resolve"))]
+stream = [k for k in rows if k.startswith(("k_fs_est", "k_fs_walk", "k_agc8", "k_agcw", "k_corr4d_main", "k_corr_resolve"))]
 prev = None
 try:
-    prev = json.load(open("profiles/r03_chain_traffic.json"))
+    prev = json.load(open("profiles/r04_chain_traffic.json"))
 except OSError:
     pass
 chain = {
@@ -144,11 +144,11 @@ chain = {
     "kernels": rows,
     "streaming_side_GB_per_step": sum(rows[k]["fetch_GB"] + rows[k]["write_GB"] for k in stream),
     "whole_step_GB": sum(v["fetch_GB"] + v["write_GB"] for v in rows.values()),
-    "round_3": None if prev is None else {"streaming_side_GB_per_step": prev["streaming_side_GB_per_step"], "whole_step_GB": prev["whole_step_GB"]},
-    "notes": "round 4: the NCO phase walk leaves every 8th phase (0.5 B per sample instead of 4) and each vector's increment; the AGC's "
-             "load stage walks the seven phases in between again (k_agc.h).  What is left to remove: the AGC folded into the correlator's "
-             "window load (-4.3 GB), the delayed pass-through read by the timing recovery as a shifted view of the correlator's input "
-             "(-2.15 GB) -- DESIGN.md.",
+    "round_4": None if prev is None else {"streaming_side_GB_per_step": prev["streaming_side_GB_per_step"], "whole_step_GB": prev["whole_step_GB"]},
+    "notes": "round 5: the front-end pass is the streaming kernel k_agcw (k_agcw.h) -- the same bytes as the tile kernel it replaced "
+             "(input 8 B + checkpoints 0.5 B read, 8 B written per sample; a run of sixteen 512-item blocks re-reads one block: 6 %) in "
+             "1.2-1.3 ms instead of 2.3.  What is left to remove is unchanged: the AGC folded into the correlator's window load (-4.3 GB), "
+             "the delayed pass-through as a view (-2.15 GB, measured in round 4: no gain) -- DESIGN.md.",
 }
 json.dump(chain, open("profiles/%s_chain_traffic.json" % tag, "w"), indent=1)
 print("streaming side %.2f GB, whole step %.2f GB" % (chain["streaming_side_GB_per_step"], chain["whole_step_GB"]))
@@ -202,3 +202,42 @@ if tp:
     json.dump(doc, open("profiles/%s_msk_time_parallel.json" % tag, "w"), indent=1)
     print("time-parallel: %.2f ms/step against %.2f (serial kernel, same Q) and %.2f (default)" % (
         tp["ms_per_step"], tp["ms_per_step_serial_kernel_same_max_noutput_items"], plain["ms_per_step"]))
+
+
+# ---- round 5: the front-end kernels alone (streaming kernel against the tile kernel it replaced)
+try:
+    fr = {}
+    for name, path in (("k_agcw", "agcw_pmc_table.json"), ("k_fs_est", "est_pmc_table.json"), ("k_agc8", "agc8_pmc_table.json")):
+        t = json.load(open(os.path.join(src, path)))
+        for k, c in t.items():
+            if not k.startswith(name):
+                continue
+            waves = c.get("SQ_WAVES", 0.0)
+            fr[k] = {"per_launch": c,
+                     "per_wave": {m: c[m] / waves for m in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if m in c and waves},
+                     "wave_active_fraction": c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                     "wave_waiting_fraction": c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None}
+    alone = {}
+    for label, d in (("streaming", "front_stats"), ("tile", "front_tile_stats")):
+        for f in glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Name"].split("(")[0].replace("void ", "")
+                if k.startswith(("k_agcw", "k_agc8", "k_fs_est", "k_fs_walk")):
+                    alone.setdefault(label, {})[k] = float(r["AverageNs"]) / 1e6
+    doc = {"what": "the front-end kernels of the stock chain with the chip to themselves (tools/front_alone.py: 4096 channels x 65536 samples, "
+                   "eight calls of aisx_freqsync_agc_process): SQ counters of the streaming kernel k_agcw<true> (round 5) and of the tile "
+                   "kernel k_agc8 it replaced (AISX_AGC_STREAMING=0), and of k_fs_est with the single-precision prefilter of its peak search",
+           "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex <k> --output-format csv -- python tools/front_alone.py "
+                      "(two passes: SQ cycles | SQ instructions); durations from rocprofv3 --kernel-trace --stats of the same script",
+           "kernels": fr, "avg_ms_alone": alone,
+           "notes": "k_agcw: a wave = one run of sixteen 512-item blocks (+ one read ahead), four waves per workgroup, no barrier after the "
+                    "sine table is staged; k_agc8: 1024-thread tiles of 8192 items, eight barriers.  SQ cycle counters are quad-cycles per wave."}
+    json.dump(doc, open("profiles/%s_front_end_kernels.json" % tag, "w"), indent=1)
+    print("front end alone (ms):", alone)
+except (OSError, KeyError, ValueError) as e:
+    print("front-end kernel summary skipped:", e)
+try:
+    hc = json.load(open(os.path.join(src, "hbm_ceiling.json")))
+    json.dump(hc, open("profiles/%s_hbm_ceilings.json" % tag, "w"), indent=1)
+except (OSError, ValueError) as e:
+    print("hbm ceilings skipped:", e)
