@@ -88,13 +88,17 @@ __global__ __launch_bounds__(CF4_T, 2) void k_corr4d_main(CorrParams p)
     corr4d_main_body<DevCtx, NC>(cx, p);
 }
 // builds with the template length folded in: the stock template at 4 and at 5 samples per symbol
-// (224 symbols, python/ais_demod.py:36-38); every other length runs the <0> build
+// (224 symbols, python/ais_demod.py:36-38) and config 5's two lengths; every other length runs the <0> build
 static void (*corr4d_pick(int N))(CorrParams)
 {
     switch (N) {
     case 896: return k_corr4d_main<896>;
     case 1120: return k_corr4d_main<1120>;
-    default: return k_corr4d_main<0>;
+    // the lengths BASELINE config 5 runs at: the wideband benchmark's template cut to 1024 items (bench.py --chain
+    // wideband) and the 224-symbol template at the channelizer's 48 828.125 Hz lane rate (1139 items, tests/test_gpu_configs.py)
+    case 1024: return k_corr4d_main<1024>;
+    case 1139: return k_corr4d_main<1139>;
+    default: return k_corr4d_main<0>; // any other length: the run-time-length build (no scratch either, k_corr4d.h)
     }
 }
 

@@ -378,7 +378,7 @@ extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, lo
         e.maxpos_stride = h->max_vec;
         e.nvec = nvec;
         e.offset = h->offset;
-        hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
+        hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_VEC_PER_WG - 1) / FS_VEC_PER_WG, h->nchan), dim3(FS_T), FS_LDS_BYTES, st, e);
         AISX_HIPCHK(hipGetLastError());
     }
     FsMixParams m;
@@ -588,8 +588,8 @@ extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
 
 extern "C" int aisx_agc_set_lds_claim(aisx_agc* h, int bytes)
 {
-    if (!h || bytes < 0 || bytes > 56 * 1024) { // (8 KB + the claim stays within the 64 KB a launch may ask for unraised)
-        set_err("aisx_agc_set_lds_claim: 0 .. 57344 bytes");
+    if (!h || bytes < 0 || bytes > 144 * 1024) {
+        set_err("aisx_agc_set_lds_claim: 0 .. 147456 bytes");
         return AISX_ERR_INVALID;
     }
     h->lds_claim = bytes;
@@ -727,7 +727,7 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.nvec = nvec;
     e.offset = h->offset;
     static const int est_pad = getenv("AISX_EST_LDS_PAD") ? atoi(getenv("AISX_EST_LDS_PAD")) : 0; // (experiments: placement)
-    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan), dim3(FS_T), FS_LDS_BYTES + est_pad, st, e);
+    hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_VEC_PER_WG - 1) / FS_VEC_PER_WG, h->nchan), dim3(FS_T), FS_LDS_BYTES + est_pad, st, e);
     AISX_HIPCHK(hipGetLastError());
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
         AISX_HIPCHK(hipEventRecord(h->ev_est, st));
@@ -867,8 +867,15 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.npend = h->npend;
     p.n_raw = n;
     static const int agcw_pad = getenv("AISX_AGCW_LDS_PAD") ? atoi(getenv("AISX_AGCW_LDS_PAD")) : -1; // (experiments: overrides the handle's claim)
-    if (agcw_applies(p.W, total) && !a->tiles_only)
-        hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), AGW_LDS_BYTES + (agcw_pad >= 0 ? agcw_pad : a->lds_claim), st, p);
+    if (agcw_applies(p.W, total) && !a->tiles_only) {
+        const int lds = AGW_LDS_BYTES + (agcw_pad >= 0 ? agcw_pad : a->lds_claim);
+        static int lds_limit = 64 * 1024; // (what a launch may ask for before the kernel's limit is raised)
+        if (lds > lds_limit) {
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)k_agcw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            lds_limit = lds;
+        }
+        hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), lds, st, p);
+    }
     else
         hipLaunchKernelGGL(k_agc8, dim3(p.ntiles, h->nchan), dim3(AGC8_T), AGC8_LDS_BYTES_MIXED, st, p);
     AISX_HIPCHK(hipGetLastError());

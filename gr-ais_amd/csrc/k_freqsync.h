@@ -32,7 +32,18 @@ constexpr int FS_F = 1024;
 #ifndef FS_WAVES_PER_WG
 #define FS_WAVES_PER_WG 4
 #endif
-constexpr int FS_WAVES = FS_WAVES_PER_WG; // one 1024-vector per wave
+constexpr int FS_WAVES = FS_WAVES_PER_WG; // waves per workgroup, each on its own vectors
+// consecutive 1024-vectors a wave takes, one after the other: the first-pass twiddles (fifteen 8-byte gathers per lane,
+// as many bytes from L2 as the vector itself) are loaded once for all of them, and the samples of the next vector
+// are in flight while this one is transformed
+#ifndef FS_VPW
+#define FS_VPW 4
+#endif
+constexpr int FS_VEC_PER_WG = FS_WAVES * FS_VPW;
+// 1 = the next vector's samples are requested before this one's transform (32 more VGPRs live), 0 = behind its search
+#ifndef FS_PREFETCH
+#define FS_PREFETCH 1
+#endif
 constexpr int FS_T = 64 * FS_WAVES;
 constexpr int FS_ROW = 68;            // LDS row pitch (complex) per k1 row
 constexpr int FS_WAVE_ELEMS = 16 * FS_ROW; // complex slots per wave
@@ -50,33 +61,70 @@ template <class Ctx>
 AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
 {
     const int t = cx.tid();
-    const int wave = t >> 6, l = t & 63;
+    const int wave = t >> 6, l = t & 63, lane0 = l;
     const int c = cx.by();
-    const int v = cx.bx() * FS_WAVES + wave;
+    const int v0 = (cx.bx() * FS_WAVES + wave) * FS_VPW; // this wave's vectors: v0 .. v0 + FS_VPW - 1
     cf* lds = (cf*)cx.lds();
     cf* X = lds + wave * FS_WAVE_ELEMS;
     cf* T2 = lds + FS_WAVES * FS_WAVE_ELEMS; // W_64^{k2*n3}, index k2*4+n3
     if (t < 64)
         T2[t] = p.wtab[(16 * (t >> 2) * (t & 3)) & (FS_F - 1)];
-    const bool live = v < p.nvec;
     const cf* xin = p.in + (long)c * p.in_stride;
     const cf* pend = p.pend + (long)c * FS_F;
-    cf x[16];
     cf tw1[16];
     tw1[0] = mk(1.f, 0.f);
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++)
         tw1[k1] = p.wtab[(k1 * l) & (FS_F - 1)];
-    // P1: lane l = column (n2,n3); x[n1] = s[l + 64 n1]^2
+    // lane l = column (n2,n3) of vector v: s[l + 64 n1], n1 = 0 .. 15
+    auto fetch = [&](int v, cf (&s)[16]) {
+        const long i0 = (long)v * FS_F; // index of the vector's first item in pending ++ new
+        // (all three tests are wave-uniform; one base pointer and constant offsets per case -- sixteen per-item
+        // selects between two rows would keep thirty-two addresses alive across the loop)
+        if (v >= p.nvec) {
 #pragma unroll
-    for (int n1 = 0; n1 < 16; n1++) {
-        cf s = mk(0.f, 0.f);
-        if (live) {
-            const long idx = (long)v * FS_F + l + 64 * n1; // index into pending ++ new
-            s = (idx < p.npend) ? pend[idx] : xin[idx - p.npend];
+            for (int n1 = 0; n1 < 16; n1++)
+                s[n1] = mk(0.f, 0.f);
+        } else if (i0 >= p.npend) {
+            const cf* b = xin + (i0 - p.npend) + l;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++)
+                s[n1] = b[64 * n1];
+        } else if (i0 + FS_F <= p.npend) {
+            const cf* b = pend + i0 + l;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++)
+                s[n1] = b[64 * n1];
+        } else { // the vector the pending items end in
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const long idx = i0 + l + 64 * n1;
+                s[n1] = (idx < p.npend) ? pend[idx] : xin[idx - p.npend];
+            }
         }
-        x[n1] = cmul_exact(s, s); // multiply_cc of the stream with itself
-    }
+    };
+    cf nxt[16];
+    fetch(v0, nxt);
+    cx.sync(); // (the W_64 table wave 0 wrote is in place for every wave; from here on a wave only meets its own rows)
+#pragma nounroll
+    for (int it = 0; it < FS_VPW; it++) {
+    const int v = v0 + it;
+    if (v >= p.nvec)
+        break; // (the whole wave: v is wave-uniform)
+    const bool live = true;
+    // (the lane index of the body, opaque to the optimiser: otherwise every LDS address and index below -- a hundred
+    // of them, all functions of the lane alone -- is hoisted out of this loop and kept in registers across it: 230 VGPRs)
+    int l = lane0;
+    cx.pin(l);
+    cf x[16];
+    // P1: x[n1] = s[l + 64 n1]^2
+#pragma unroll
+    for (int n1 = 0; n1 < 16; n1++)
+        x[n1] = cmul_exact(nxt[n1], nxt[n1]); // multiply_cc of the stream with itself
+#if FS_PREFETCH
+    if (it + 1 < FS_VPW)
+        fetch(v + 1, nxt); // (in flight while this vector is transformed)
+#endif
     dft16<false>(cx, x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; k1++)
@@ -84,7 +132,7 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++)
         X[k1 * FS_ROW + l] = x[k1];
-    cx.sync(); // (the W_64 table wave 0 wrote is now in place for every wave; from here on a wave only meets its own rows)
+    cx.wave_lds_sync();
     {
         const int k1 = l >> 2, n3 = l & 3;
 #pragma unroll
@@ -100,22 +148,16 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
     }
     cx.wave_lds_sync();
     cf y[16];
-    int kk[16];
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         const int q = l + 64 * h, k1 = q >> 4, k2 = q & 15;
         cf y0 = X[k1 * FS_ROW + k2 * 4 + 0], y1 = X[k1 * FS_ROW + k2 * 4 + 1];
         cf y2 = X[k1 * FS_ROW + k2 * 4 + 2], y3 = X[k1 * FS_ROW + k2 * 4 + 3];
         dft4<false>(cx, y0, y1, y2, y3);
-        const int kb = k1 + 16 * k2; // frequency index k = kb + 256*k3
         y[4 * h + 0] = y0;
         y[4 * h + 1] = y1;
         y[4 * h + 2] = y2;
         y[4 * h + 3] = y3;
-        kk[4 * h + 0] = kb;
-        kk[4 * h + 1] = kb + 256;
-        kk[4 * h + 2] = kb + 512;
-        kk[4 * h + 3] = kb + 768;
     }
     cx.wave_lds_sync();
     // the spectrum in fft-shifted order: S(j) = X[(j + F/2) mod F]  <=>  j = (k + F/2) mod F.  Item j lives in
@@ -125,9 +167,18 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
     static_assert(FS_F + FS_F / 16 <= FS_WAVE_ELEMS, "the padded spectrum fits the wave's LDS");
     cf* S = X;
     auto sl = [](int j) { return j + (j >> 4); };
+    {
+        // value 4 h + k3 of this lane is frequency k = kb + 256 k3, kb = k1 + 16 k2 with k1 = (l >> 4) + 4 h, k2 = l & 15;
+        // j = (k + 512) mod 1024 = kb + 256 ((k3 + 2) mod 4), and kb < 256 keeps j >> 4 = (kb >> 4) + 16 ((k3 + 2) mod 4):
+        // slot = slot0 + 4 h (+ carry-free: k1 < 16) + 272 ((k3 + 2) mod 4)
+        const int kb0 = (l >> 4) + 16 * (l & 15);
+        const int slot0 = kb0 + (kb0 >> 4);
 #pragma unroll
-    for (int e = 0; e < 16; e++)
-        S[sl((kk[e] + FS_F / 2) & (FS_F - 1))] = y[e];
+        for (int h = 0; h < 4; h++)
+#pragma unroll
+            for (int k3 = 0; k3 < 4; k3++)
+                S[slot0 + 4 * h + 272 * ((k3 + 2) & 3)] = y[4 * h + k3];
+    }
     cx.wave_lds_sync();
     // freqest search (lib/freqest_impl.cc:74-83): the first strict maximum of e[j] = |S[j]| + |S[j + offset]|,
     // each magnitude glibc's hypotf (cabs_f: double products, a double square root -- ~45 issue slots).
@@ -190,6 +241,12 @@ AISX_DI void fs_est_body(Ctx& cx, const FsEstParams& p)
     }
     if (live && l == 0)
         p.maxpos[(long)c * p.maxpos_stride + v] = (bestj >= 0) ? bestj + p.offset / 2 : -1;
+    cx.wave_lds_sync(); // (the next vector's first pass overwrites the rows the search has just read)
+#if !FS_PREFETCH
+    if (it + 1 < FS_VPW)
+        fetch(v + 1, nxt);
+#endif
+    } // vectors of this wave
 }
 
 // freqest::work on spectra the caller already transformed (lib/freqest_impl.cc:57-88):

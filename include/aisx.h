@@ -333,12 +333,14 @@ int aisx_agc_set_floor(aisx_agc* h, float floor_env);
 int aisx_agc_set_streaming(aisx_agc* h, int on);
 /* Placement of the streaming kernel's workgroups when it runs BESIDE the timing recovery (the pipelined
  * chain): a workgroup uses 8 KB of LDS; claiming `bytes` more decides how many of them the dispatcher
- * puts on the 128 CUs that hold a recovery workgroup (92 160 of 163 840 B taken) without touching the
- * other CUs.  The recovery is a recurrence that every co-resident wave delays; this kernel is the densest
- * arithmetic of the chain.  Measured (round 5, 4096 channels, three interleaved runs each): one
- * workgroup beside the recovery instead of three shortens the step by 4.6 % (5.49 against 5.76 ms).
- * aisx_chain_create sets 30 720 (one beside the recovery, four elsewhere); default 0.  Results do
- * not depend on it.  Environment AISX_AGCW_LDS_PAD overrides (experiments). */
+ * puts on the 128 CUs that hold a recovery workgroup (92 160 of 163 840 B taken, 71 680 left) and on the
+ * other CUs.  The recovery is a recurrence that every co-resident wave delays, and this kernel is the
+ * densest arithmetic of the chain.  Measured (round 5, 4096 channels x 65536 samples, interleaved runs on
+ * one box): no claim 5.65-5.86 ms per step with the recovery kernel at 5.45-5.66 ms and the correlator at
+ * 2.50-2.59; 72 KB (none beside the recovery, two per free CU) 5.44-5.49 with the recovery at 5.05-5.09 and
+ * the correlator at 1.89-1.94; 100 KB (one per free CU) 5.71-5.74.  aisx_chain_create sets 73 728 while the
+ * recovery's workgroups (32 channels each) leave at least half of the CUs free, 0 otherwise; default 0.
+ * Results do not depend on it.  Environment AISX_AGCW_LDS_PAD overrides (experiments). */
 int aisx_agc_set_lds_claim(aisx_agc* h, int bytes);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);

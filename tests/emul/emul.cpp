@@ -771,7 +771,7 @@ int emu_fs_process(void* hv, const cf* in, long in_stride, int n, cf* out, long 
         FsEstParams e;
         e.in = in; e.in_stride = in_stride; e.pend = h->pend[h->cur].data(); e.npend = h->npend; e.wtab = h->wtab.data();
         e.maxpos = h->maxpos.data(); e.maxpos_stride = h->max_vec; e.nvec = nvec; e.offset = h->offset;
-        run_grid((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
+        run_grid((nvec + FS_VEC_PER_WG - 1) / FS_VEC_PER_WG, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
     }
     FsMixParams m;
     m.nchan = h->nchan; m.in = in; m.in_stride = in_stride; m.pend_in = h->pend[h->cur].data(); m.pend_out = h->pend[h->cur ^ 1].data();
@@ -794,7 +794,7 @@ int emu_fs_agc_process(void* fv, void* av, const cf* in, long in_stride, int n, 
         FsEstParams e;
         e.in = in; e.in_stride = in_stride; e.pend = h->pend[h->cur].data(); e.npend = h->npend; e.wtab = h->wtab.data();
         e.maxpos = h->maxpos.data(); e.maxpos_stride = h->max_vec; e.nvec = nvec; e.offset = h->offset;
-        run_grid((nvec + FS_WAVES - 1) / FS_WAVES, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
+        run_grid((nvec + FS_VEC_PER_WG - 1) / FS_VEC_PER_WG, h->nchan, FS_T, FS_LDS_BYTES, [&](EmuCtx& cx) { fs_est_body(cx, e); });
         FsWalkParams w;
         w.nchan = h->nchan; w.maxpos = h->maxpos.data(); w.maxpos_stride = h->max_vec; w.fhat = fhat; w.fhat_stride = fhat_stride;
         w.phase_in = h->phase.data(); w.phase_out = h->phase.data(); w.phases = phases.data(); w.phases_stride = pstride; w.dvec = dvec.data(); w.dvec_stride = h->max_vec; w.nvec = nvec; w.binsize = h->binsize;
