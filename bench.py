@@ -64,7 +64,8 @@ CHAIN_TEXT = {"core": "corr_est->msk_timing+NRZI tail (no freq_sync / agc in fro
 
 
 def make_template(family, sps):
-    from ais_amd import gmsk_mod, modulate_vector_bc, synth
+    import synth
+    from ais_amd import gmsk_mod, modulate_vector_bc
 
     if family == "S":
         return modulate_vector_bc(gmsk_mod(sps, 0.4), [1, 1, 0, 0] * 7, [1])
@@ -81,7 +82,7 @@ def make_input(nchan, T, family, sps, device, rank, stock):
     (seeded) replicated with a per-channel carrier phase, plus
     per-sample device-generated noise so that no two channels are equal."""
     import torch
-    from ais_amd import synth
+    import synth
 
     ip = input_params(family, stock)
     amp = ip["amp"]
@@ -102,7 +103,7 @@ def make_input(nchan, T, family, sps, device, rank, stock):
 
 def burst_infos(c, T, family, sps, rank, stock):
     """What was transmitted in device channel c (= base channel c % NUNIQ)."""
-    from ais_amd import synth
+    import synth
 
     ip = input_params(family, stock)
     return synth.make_channel(synth.SEED0 + 1000 * rank + (c % NUNIQ), T, family, sps, amp=ip["amp"], cfo_max=ip["cfo_max"],
@@ -256,7 +257,7 @@ def cpu_baseline(chain, family, sps, T, budget_s=6.0):
     import tempfile
 
     import oracle_py as orc
-    from ais_amd import synth
+    import synth
 
     tmpl = make_template(family, sps)
     stock = chain == "stock"

@@ -27,7 +27,7 @@ from .modulate import gmsk_mod, modulate_vector_bc  # noqa: F401
 
 def __getattr__(name):
     # blocks need torch + libaisx.so; load them on first use so that the host-only
-    # helpers (synth, modulate) stay importable anywhere
+    # helpers (modulate, framing) stay importable anywhere
     if name in ("corr_est_cc", "msk_timing_recovery_cc", "square_and_fft_sync_cc", "freqest", "feedforward_agc_cc",
                 "ais_demod", "TAG_DTYPE", "pfb_channelizer_ccf", "firdes_low_pass", "freq_sync_agc"):
         from . import blocks

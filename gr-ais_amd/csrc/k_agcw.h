@@ -36,7 +36,10 @@ namespace aisx {
 
 constexpr int AGW_W = 512;          // the window this kernel serves: 64 lanes x 8 items
 constexpr int AGW_G = 8;            // items per lane
-constexpr int AGW_WAVES = 4;        // waves per workgroup (they share nothing but the sine table)
+#ifndef AGW_WAVES_PER_WG
+#define AGW_WAVES_PER_WG 4
+#endif
+constexpr int AGW_WAVES = AGW_WAVES_PER_WG; // waves per workgroup (they share nothing but the sine table)
 constexpr int AGW_T = 64 * AGW_WAVES;
 #ifndef AGW_RUN
 #define AGW_RUN 16                  // output blocks per wave

@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "gr-ais_amd"))
 
 import sched_policy as sp  # noqa: E402
-from ais_amd import gmsk_mod, modulate_vector_bc, synth  # noqa: E402
+from ais_amd import gmsk_mod, modulate_vector_bc  # noqa: E402
+import synth  # noqa: E402  (tests/synth.py)
 
 
 def main():

@@ -16,7 +16,7 @@ purposes:
     the oracle library in the loop.
 
 Only data is stored (inputs, expected outputs, the transmitted payload bits);
-the inputs come from ais_amd.synth, this repository's own signal generator.
+the inputs come from tests/synth.py, this repository's own signal generator.
 """
 import os
 import sys
@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "gr-ais_amd"))
 
 import oracle_py as orc  # noqa: E402
-from ais_amd import synth  # noqa: E402
+import synth  # noqa: E402  (tests/synth.py)
 
 SPS = 4
 

@@ -73,7 +73,7 @@ def assert_decoded_bursts_identical(got_bits, want_bits, infos, min_frac_equal=0
     time_est that differs in its last place (FFT rounding) legitimately flips a
     few of them; only their overall agreement is bounded.  Returns
     (bursts compared, bursts transmitted)."""
-    from ais_amd import synth
+    import synth
 
     got_bits = np.asarray(got_bits, dtype=np.uint8)
     want_bits = np.asarray(want_bits, dtype=np.uint8)
@@ -147,7 +147,7 @@ def compare_bursts(got_bits, want_bits, infos, slack=4):
     `want_bits`) is looked up in `got_bits`: bit for bit at the same position, or within +-slack
     positions (a detection seen by one chain only re-times the loop and can move the symbol count
     by one in the noise before the burst).  Returns (compared, identical_in_place, identical_within_slack)."""
-    from ais_amd import synth
+    import synth
 
     got_bits = np.asarray(got_bits, dtype=np.uint8)
     want_bits = np.asarray(want_bits, dtype=np.uint8)

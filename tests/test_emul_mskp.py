@@ -7,7 +7,7 @@ import pytest
 
 import emul_py as emu
 import oracle_py as orc
-from ais_amd import synth
+import synth
 
 
 def _tags_with_pairs(rng, total, chan, sps, pair_every, neg_frac, extra_random, nan_at=None):

@@ -5,7 +5,7 @@ import pytest
 
 import emul_py as emu
 import oracle_py as orc
-from ais_amd import synth
+import synth
 
 
 def test_emul_agc_bit_exact():

@@ -5,7 +5,7 @@ import numpy as np
 
 import ais_amd
 import oracle_py as orc
-from ais_amd import synth
+import synth
 
 
 def _frame_bits(payload_bits):

@@ -105,7 +105,7 @@ def test_oracle_reproduces_chain_fixtures(name, stages):
 def test_chain_fixtures_contain_the_transmitted_payloads():
     # the stored bit streams are worth comparing against: most of the bursts that were sent
     # come out of them bit for bit
-    from ais_amd import synth
+    import synth
 
     for name in ("chain_core", "chain_stock"):
         g = _load(name)
@@ -202,7 +202,7 @@ def test_gpu_agc_and_freqsync_against_fixtures(ais):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,stages", [("chain_core", "core"), ("chain_stock", "stock")])
 def test_gpu_chain_against_fixtures(ais, name, stages):
-    from ais_amd import synth
+    import synth
 
     g = _load(name)
     nchan, T, steps = int(g["nchan"]), int(g["T"]), int(g["steps"])

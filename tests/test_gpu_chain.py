@@ -77,7 +77,7 @@ def test_pipelined_step_equals_the_serial_chain_ragged(ais):
     # ragged calls: lengths that are not whole vectors (estimates prepared BEHIND the pass), a first
     # call shorter than one vector (nothing reaches the correlator), whole vectors in a row
     # (estimates two calls ahead), next input known for some steps only
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [600, 4096, 2048, 1000, 24, 5000, 3 * 1024 + 7, 8192, 8192, 1024, 2041]
@@ -88,7 +88,7 @@ def test_pipelined_step_equals_the_serial_chain_ragged(ais):
 
 def test_pipelined_core_chain(ais):
     # corr_est -> msk only (fs = agc = NULL): the chain BASELINE.json's metric names
-    from ais_amd import synth
+    import synth
 
     nchan = 33
     lens = [8192, 5000, 12288, 100, 4096]
@@ -104,7 +104,8 @@ def test_two_alternating_input_buffers_against_the_oracle(ais):
     # were prepared for even though the POINTER repeats every other step: checked
     # against the oracle's chain, which knows nothing of buffers.
     import torch
-    from ais_amd import _lib, synth
+    import synth
+    from ais_amd import _lib
     import ctypes as C
 
     nchan, K, T, steps = 24, 6, 16384, 6
@@ -149,7 +150,7 @@ def test_two_alternating_input_buffers_against_the_oracle(ais):
 
 
 def test_chain_argument_checks(ais):
-    from ais_amd import synth
+    import synth
 
     nchan, T = 4, 4096
     dem = ais.ais_demod(OPTS, nchan=nchan, max_items=T, stages="stock")

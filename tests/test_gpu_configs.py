@@ -39,7 +39,7 @@ def _dev(x):
 
 
 def _template(ais, family, sps=SPS):
-    from ais_amd import synth
+    import synth
 
     if family == "S":
         return ais.modulate_vector_bc(ais.gmsk_mod(sps, 0.4), [1, 1, 0, 0] * 7, [1])
@@ -63,7 +63,7 @@ def _replicated(base, nchan):
 @pytest.mark.parametrize("family", ["S", "P"])
 def test_config2_256_channels_corr_est_only(ais, family):
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, T, nu = 256, 65536, 16
     tmpl = _template(ais, family)
@@ -109,7 +109,7 @@ def _stock_chain_against_oracle(ais, nchan, K, steps, seed0):
     checked against the oracle with the gates of test_gpu_stages.py::test_stock_chain_full_length_steps;
     the others are replicas of them."""
     import torch
-    from ais_amd import synth
+    import synth
 
     T = 65536
     assert steps <= 3  # (results of the last AISX_CHAIN_DEPTH steps stay readable)
@@ -232,7 +232,7 @@ def test_config5_wideband_channelizer_to_nmea(ais):
     import concurrent.futures as cf
 
     import torch
-    from ais_amd import synth
+    import synth
 
     fs, M, D, nfr = 25e6, 1024, 512, 8192
     sps = fs / D / 9600.0
@@ -311,7 +311,7 @@ def test_config4_rows_do_not_depend_on_their_position(ais):
     # 8192 channels whose upper half repeats the lower half: the same input row gives the same
     # bits and tags wherever it sits in the batch (workgroup, wave, lane)
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, T, nu = 8192, 65536, 8
     tmpl = _template(ais, "S")
@@ -341,7 +341,7 @@ def test_config4_rows_do_not_depend_on_their_position(ais):
 def test_corr_est_other_samples_per_symbol(ais, sps_block, sps_signal):
     # isps = (int)(sps + 0.5) steps the peak search (lib/corr_est_cc_impl.cc:193,270); the stock
     # receiver runs the block at 5.2083 sps against a 5 sps template (python/radio.py:49-57)
-    from ais_amd import synth
+    import synth
 
     tmpl = _template(ais, "S", sps_signal)
     nchan, T = 12, 40000

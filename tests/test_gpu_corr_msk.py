@@ -35,7 +35,7 @@ def _per_chan(tags, nchan):
 
 
 def _p_template(sps=4):
-    from ais_amd import synth
+    import synth
 
     lv = [1 if b else -1 for b in synth.sync_bits("P")]
     return synth.gmsk_waveform(np.array(lv, float), sps)[: len(lv) * sps].astype(np.complex64)
@@ -191,7 +191,7 @@ def test_corr_work_host_gnuradio_path(ais):
 
 @pytest.mark.parametrize("sps,osps", [(4.0, 1), (4.0, 2), (5.2083, 1)])
 def test_msk_stream_bit_exact(ais, sps, osps):
-    from ais_amd import synth
+    import synth
 
     nchan, lens = 70, [6000, 37, 4000, 1, 9000]
     total = sum(lens)
@@ -247,7 +247,7 @@ def test_msk_api_and_errors(ais):
 
 
 def test_msk_general_work_host_gnuradio_path(ais):
-    from ais_amd import synth
+    import synth
 
     rng = np.random.default_rng(3)
     x, _ = synth.make_channel(77, 30000, "P", 4, amp=1.0, cfo_max=50.0)
@@ -277,7 +277,7 @@ def test_msk_general_work_host_gnuradio_path(ais):
 def test_msk_interp_range_raises_like_upstream(ais):
     # a time_est tag whose value puts mu outside the interpolator's table: upstream throws
     # std::runtime_error("mmse_fir_interpolator_cc: imu out of bounds.")
-    from ais_amd import synth
+    import synth
 
     x, _ = synth.make_channel(5, 4000, "P", 4, amp=1.0, cfo_max=50.0)
     buf = np.concatenate([np.zeros(1, np.complex64), x])
@@ -290,7 +290,7 @@ def test_msk_interp_range_raises_like_upstream(ais):
 
 def test_msk_many_tags_per_call(ais):
     # more time_est tags in one call than the kernel's LDS tag queue holds: refilled in instalments
-    from ais_amd import synth
+    import synth
 
     rng = np.random.default_rng(12)
     nchan, total = 66, 7000
@@ -327,7 +327,7 @@ def test_msk_many_tags_per_call(ais):
 def test_msk_channels_per_wave_builds(ais, lpw, monkeypatch):
     # the three builds of the timing-recovery kernel (16 / 32 / 64 channels per wave) give the
     # same bits and symbols as the oracle; the library picks 16, AISX_MSK_LPW overrides it
-    from ais_amd import synth
+    import synth
 
     monkeypatch.setenv("AISX_MSK_LPW", str(lpw))
     rng = np.random.default_rng(40 + lpw)
@@ -420,7 +420,7 @@ def test_msk_bursts_of_tags_symbol_stage(ais, sps):
 def test_msk_bit_tail_on_its_own_stream(ais):
     # aisx_msk_set_tail_stream: same bits, computed on a second stream while the next call runs
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, lens = 20, [4000, 3000, 5000, 2000]
     xs = np.stack([synth.make_channel(700 + c, sum(lens), "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
@@ -458,7 +458,7 @@ def test_msk_wait_prepass_orders_another_stream(ais):
     # recovery's large workgroups are placed before that stream's small ones); the first call only
     # arms the event, results are untouched
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, lens = 12, [3000, 2500, 4000]
     xs = np.stack([synth.make_channel(760 + c, sum(lens), "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
@@ -488,7 +488,7 @@ def test_msk_wait_prepass_orders_another_stream(ais):
 def test_core_chain_corr_to_msk_bits_identical(ais, family):
     # corr_est -> msk -> NRZI bits with the tags handed over on the device, vs
     # the oracle chain (stages=0), several steps with carried state
-    from ais_amd import synth
+    import synth
 
     sps = 4
     if family == "S":
@@ -538,7 +538,7 @@ def test_full_size_properties(ais):
     # BASELINE config scale (4096 channels x 65536 samples): size-independent
     # properties + oracle comparison on a subset of channels
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, T, nuniq, sps = 4096, 65536, 16, 4
     tmpl = _p_template(sps)

@@ -32,7 +32,7 @@ def _dev(x):
 
 def _stream(ais, nchan, lens, seed, join, Q, neg_frac, pair_every, nan_at=None, every=1, sps=4.0):
     import torch
-    from ais_amd import synth
+    import synth
 
     rng = np.random.default_rng(seed)
     total = sum(lens)
@@ -101,7 +101,7 @@ def test_time_parallel_with_failing_junctions(ais, join):
 def test_max_noutput_items_serial_kernel(ais, Q):
     # set_max_noutput_items() with the serial kernel alone (restart points off)
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan, lens = 40, [20000, 37, 9000]
     total = sum(lens)
@@ -212,7 +212,8 @@ def test_time_parallel_pipelined_symbols_only(ais):
     (the event they wait for is recorded behind it).  Symbols and counts equal to the serial kernel's."""
     import ctypes as C
     import torch
-    from ais_amd import _lib, synth
+    import synth
+    from ais_amd import _lib
 
     nchan, L, ncalls, sps, Q = 512, 32768, 6, 4.0, 256
     rng = np.random.default_rng(11)

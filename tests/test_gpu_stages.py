@@ -62,7 +62,7 @@ def test_agc_other_references_and_huge_inputs(ais):
 
 
 def test_freqsync_matches_oracle(ais):
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [4096, 1000, 24, 5000, 30 * 1024 + 7]
@@ -109,7 +109,7 @@ def test_freqest_work_kat(ais):
 def test_stock_chain_bits_identical(ais, family, nchan, T, steps):
     # freq_sync -> agc -> corr_est -> msk -> NRZI bits, the connect order of
     # python/ais_demod.py:56, vs the oracle chain with the same step contract
-    from ais_amd import synth
+    import synth
 
     sps = 4
     if family == "S":
@@ -195,7 +195,7 @@ def test_stock_chain_full_length_steps(ais):
     #  (3) every burst the oracle's chain decodes is in the GPU's bit stream within +-2 bits of
     #      the same place -- except, at most, one per detection that only one side saw (such a
     #      tag resets the timing loop in one chain and not in the other).
-    from ais_amd import synth
+    import synth
 
     sps, nchan, T, steps = 4, 70, 65536, 2
     tmpl = ais.modulate_vector_bc(ais.gmsk_mod(sps, 0.4), [1, 1, 0, 0] * 7, [1])
@@ -266,7 +266,7 @@ def test_fused_front_end_equals_the_two_blocks(ais):
     # aisx_freqsync_agc_process (estimates, NCO phase walk on its own, mixing inside the AGC's load
     # stage) against aisx_freqsync_process + aisx_agc_process on the GPU and against the oracle:
     # bit for bit, ragged calls, 70 channels (two walk waves, the second one ragged)
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [4096, 1000, 24, 5000, 30 * 1024 + 7, 10]
@@ -304,7 +304,7 @@ def test_estimate_ahead_gives_the_same_results(ais):
     # stream while call k's sample pass runs; ragged calls (pending items written by the pass the
     # next estimate has to wait for), a prepared estimate that is dropped (other arguments)
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [4096, 1000, 24, 5000, 9 * 1024 + 7, 10, 2048]
@@ -341,7 +341,7 @@ def test_estimate_two_calls_ahead(ais):
     # preparations wait at a time (two slots, three copies of the NCO phase); allowed behind calls
     # that leave no pending items; a call with other arguments drops both
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [4096, 2048, 1024, 8192, 3072, 1000, 24, 2048]
@@ -384,7 +384,7 @@ def test_estimate_two_calls_ahead(ais):
 def test_ais_demod_fused_front_end_gives_the_same_bits(ais):
     # ais_demod(..., fused_front_end=True): the whole python/ais_demod.py:56 chain with freq_sync and
     # the AGC as one pass -- bits, symbol counts and tags equal to the chain with the two blocks
-    from ais_amd import synth
+    import synth
 
     nchan, lens = 24, [8192, 5000, 12288]
     opts = dict(samples_per_symbol=4, bits_per_sec=9600.0, clockrec_gain=0.04, omega_relative_limit=0.01, fftlen=1024)
@@ -414,7 +414,7 @@ def test_two_block_and_fused_calls_mixed_across_streams(ais):
     # alternating between the two forms and between two streams, no host synchronisation in between;
     # the output must be the oracle's chain of freq_sync -> agc, bit for bit.
     import torch
-    from ais_amd import synth
+    import synth
 
     nchan = 70
     lens = [4096, 3000, 2048, 5000, 1024, 8192, 1000, 4096]

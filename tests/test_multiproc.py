@@ -39,7 +39,7 @@ def _worker(rank, world, port, total, q):
     import torch.distributed as dist
 
     import oracle_py as orc
-    from ais_amd import synth
+    import synth
     from ais_amd.shard import gather_counts, max_over_ranks, shard_channels
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,7 +64,7 @@ def test_two_rank_gloo_shards_cover_all_channels():
     import torch.multiprocessing as mp
 
     import oracle_py as orc
-    from ais_amd import synth
+    import synth
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

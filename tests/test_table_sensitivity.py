@@ -99,7 +99,7 @@ def _run_chain(g):
 
 def _compare(g, base, var):
     """(payloads decoded by both at the same place, payloads decoded by the base, bits equal in place, bits)"""
-    from ais_amd import synth
+    import synth
 
     both = had = same = total = 0
     for c, ((b0, t0), (b1, t1)) in enumerate(zip(base, var)):

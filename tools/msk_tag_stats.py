@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def main():
     import oracle_py as orc
     import bench
-    from ais_amd import synth
+    import synth
 
     nchan = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 2

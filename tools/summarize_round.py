@@ -33,8 +33,16 @@ prof = bench_line(os.path.join(src, "bench_profiled.log"))
 json.dump(plain, open("profiles/%s_default_bench_line.json" % tag, "w"), indent=1)
 
 # ---- kernel stats of the profiled default run
-trace = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))[0]
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+# (rocprofv3 follows the child processes bench.py starts -- the HBM-ceiling micro-benchmark, the GNU Radio harness -- and
+# writes a trace per process: the benchmark's own is the one that holds the timing-recovery kernel)
+def _pick(pattern):
+    cands = glob.glob(os.path.join(src, "stats", "*", pattern))
+    best = max(cands, key=lambda f: open(f).read().count("k_msk<"))
+    return best
+
+
+trace = _pick("*kernel_trace.csv")
+stats = trace.replace("kernel_trace.csv", "kernel_stats.csv")
 st = {k: v for k, v in sp.timed_stats(trace, prof["steps"], prof["warmup"]).items()
       if not k.startswith(("k_mskp", "k_msk_ff"))}  # (kernels of the time-parallel side run only)
 open("profiles/%s_default_bench_kernel_stats.csv" % tag, "w").write(open(stats).read())
