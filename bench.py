@@ -667,8 +667,8 @@ def main():
     # BASELINE config 4's per-GPU shape (8192 channels) as a side measurement of the default run: there the
     # timing recovery hides behind the sample passes, and every millisecond taken off those shows one to one
     c4 = measure("stock", False, nch=8192) if (args.chain == "stock" and side and world == 1 and nchan != 8192) else None
-    h2d = measure_h2d(torch, device) if (rank == 0 and side) else None
-    ceil = hbm_ceilings() if (rank == 0 and side) else None
+    h2d = measure_h2d(torch, device) if (rank == 0 and side and world == 1) else None
+    ceil = hbm_ceilings() if (rank == 0 and side and world == 1) else None
     copy_gbs = None
     if rank == 0 and side:
         # what a plain 16-byte-per-lane copy sustains on this chip, no profiler attached (2 GiB each way)
@@ -792,7 +792,7 @@ def main():
             }
         if corr_only is not None:
             line["corr_only"] = corr_only
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the CPU path is timed beside the one-GPU run only)
             line["cpu_baseline"] = cpu_baseline(args.chain if args.chain != "corr" else "core", args.template, sps, T)
         print(json.dumps(line))
     if use_dist:

@@ -194,14 +194,16 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         // The front-end kernel's workgroups stay off the CUs that hold a recovery workgroup (aisx_agc_set_lds_claim):
         // 8 KB used + 72 KB claimed is more than the 71 680 B the recovery leaves, and two of them fit a free CU.
         // Only while the recovery leaves half of the chip free (one workgroup of 32 channels per CU: up to 4096
-        // channels on 256 CUs): with a recovery workgroup on every CU the claim would make the front end wait
-        // for them to finish (8192 channels: 10.9 against 9.4 ms per step).
+        // channels on 256 CUs): with a recovery workgroup on every CU that claim would make the front end wait
+        // for them to finish (8192 channels: 10.9 against 9.5 ms per step).  There 48 KB -- ONE front-end
+        // workgroup beside each recovery workgroup instead of three -- is what measures best (9.40-9.42 against
+        // 9.47-9.60 ms, the correlator 2.56 instead of 3.4-3.6 ms).
         int dev = 0, ncu = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             ncu = prop.multiProcessorCount;
         const int msk_wgs = (nchan + 31) / 32;
-        int claim = (ncu > 0 && 2 * msk_wgs <= ncu) ? 72 * 1024 : 0;
+        int claim = (ncu > 0 && 2 * msk_wgs <= ncu) ? 72 * 1024 : 48 * 1024;
         if (const char* e = getenv("AISX_CHAIN_AGC_CLAIM"))
             claim = atoi(e);
         if ((rc = aisx_agc_set_lds_claim(agc, claim)) != AISX_OK) {

@@ -339,7 +339,8 @@ int aisx_agc_set_streaming(aisx_agc* h, int on);
  * one box): no claim 5.65-5.86 ms per step with the recovery kernel at 5.45-5.66 ms and the correlator at
  * 2.50-2.59; 72 KB (none beside the recovery, two per free CU) 5.44-5.49 with the recovery at 5.05-5.09 and
  * the correlator at 1.89-1.94; 100 KB (one per free CU) 5.71-5.74.  aisx_chain_create sets 73 728 while the
- * recovery's workgroups (32 channels each) leave at least half of the CUs free, 0 otherwise; default 0.
+ * recovery's workgroups (32 channels each) leave at least half of the CUs free, 49 152 otherwise (one front-end
+ * workgroup beside each recovery workgroup: 8192 channels 9.40-9.42 against 9.47-9.60 ms); default 0.
  * Results do not depend on it.  Environment AISX_AGCW_LDS_PAD overrides (experiments). */
 int aisx_agc_set_lds_claim(aisx_agc* h, int bytes);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
