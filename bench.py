@@ -369,7 +369,7 @@ def parity_gates(chain, tmpl, sps, T, family, rank, xk, nsteps, gpu_tags, gpu_bi
     return out
 
 
-def bench_wideband(args, torch, device):
+def bench_wideband(args, torch, device, as_dict=False, steps=None):
     """BASELINE config 5 (one GPU): 25 MS/s wideband IQ -> 1024-lane polyphase channelizer
     (2x oversampled: 48.83 kS/s per lane = 5.086 samples/symbol) -> corr_est -> msk chain
     on the 1024 lanes with the sps = 5 template (the stock app runs 5.2083 sps against a
@@ -394,26 +394,32 @@ def bench_wideband(args, torch, device):
         lanes = pfb.work(x)
         dem.work(lanes)
 
+    nsteps = steps or args.steps
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(nsteps):
         step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ev[0].record(); lanes = pfb.work(x); ev[1].record(); dem.work(lanes); ev[2].record()
     torch.cuda.synchronize()
-    print(json.dumps({
+    line = {
         "metric": "wideband complex MS/s through polyphase channelizer -> 1024 demod lanes",
-        "value": n * args.steps / el / 1e6, "unit": "complex MS/s (wideband input)", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": n * nsteps / el / 1e6, "unit": "complex MS/s (wideband input)", "n_gpus": 1, "steps": nsteps,
+        "warmup": args.warmup, "ms_per_step": el / nsteps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "1 x %d wideband samples/step at 25 MS/s -> 1024 lanes x %d items (decim 512, 60227-tap "
                                "prototype) -> corr_est(N=1024)->msk" % (n, nfr)},
         "pfb_ms": ev[0].elapsed_time(ev[1]), "demod_ms": ev[1].elapsed_time(ev[2]),
-        "realtime_factor": n * args.steps / el / 25e6}))
+        "realtime_factor": n * nsteps / el / 25e6}
+    del pfb, dem, x
+    torch.cuda.empty_cache()
+    if as_dict:
+        return line
+    print(json.dumps(line))
 
 
 def parse_args(argv=None):
@@ -756,6 +762,11 @@ def main():
             line["h2d"] = h2d
         if side and world == 1:
             line["config1_host_path"] = config1_host_path()
+            if args.chain == "stock":
+                # BASELINE config 5 as a side measurement (bench.py --chain wideband is the run of its own)
+                w = bench_wideband(args, torch, device, as_dict=True, steps=20)
+                line["config5_wideband"] = {k: w[k] for k in ("value", "unit", "ms_per_step", "steps", "pfb_ms", "demod_ms", "realtime_factor")}
+                line["config5_wideband"]["workload"] = w["config"]["workload"]
         if c4 is not None:
             k4 = float(np.mean(c4["kern_ms"]))
             a4 = CORR_BYTES_PER_SAMPLE * 8192.0 * T / (k4 * 1e-3) / 1e9

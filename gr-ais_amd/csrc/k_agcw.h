@@ -17,7 +17,7 @@
 // A block is one wave: lane l owns the 8 consecutive items 8l .. 8l+7.  Prefix / suffix maxima
 // inside a lane are register chains; across lanes two wave scans of the 64 group maxima (DPP);
 // block b's items wait in registers until block b + 1's prefix maxima exist.  Envelopes are
-// non-negative and never NaN (agc_envelope), so every maximum is taken on the bit patterns as
+// non-negative and never NaN (agcw_envelope), so every maximum is taken on the bit patterns as
 // integers (same order, one v_max_i32 / v_max3_i32 each, no NaN canonicalisation).
 //
 // Block grid.  With H = W - 1 = 511 items of history the block's combined input is
