@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/../gr-ais_amd"
 make -s
 name=$1; tu=$2; flags=$3
+if [ "$tu" = aisx_stages ]; then flags="-fno-slp-vectorize $flags"; fi  # (as gr-ais_amd/Makefile builds that unit)
 mkdir -p ../tools/scratch/obj
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $flags -c -o ../tools/scratch/obj/${tu}_${name}.o csrc/${tu}.hip
 objs=""
