@@ -790,6 +790,10 @@ def main():
             }
         if nola is not None:
             line["no_lookahead_ms_per_step"] = nola["el"] / args.steps * 1e3
+            # (there the phase walk runs in front of the pass on the same stream, not beside the correlator)
+            line["no_lookahead_corr_kernel_ms"] = float(np.mean(nola["kern_ms"]))
+            if nola.get("msk_ms"):
+                line["no_lookahead_msk_kernel_ms"] = float(np.mean(nola["msk_ms"]))
         if tpm is not None:
             line["msk_time_parallel"] = {
                 "what": "the same steps with aisx_msk_set_time_parallel(64 restart points, serial kernel as join, units <= 16384 items) "

@@ -207,7 +207,9 @@ struct aisx_msk {
     int* d_npieces[2] = { nullptr, nullptr };
     long tp_calls = 0;
     // GNU Radio path staging
-    cf *d_st_in = nullptr, *d_st_sym = nullptr;
+    cf *d_st_in = nullptr, *d_st_sym = nullptr; // (d_st_sym = d_st_blk + 2: the symbols behind their 16-byte header)
+    cf* d_st_blk = nullptr;
+    std::vector<cf> st_host; // where header + symbols land on the host
     float *d_st_err = nullptr, *d_st_mu = nullptr;
     unsigned char* d_st_bits = nullptr;
     tag_rec* d_st_tags = nullptr;
@@ -465,7 +467,7 @@ extern "C" int aisx_msk_destroy(aisx_msk* h)
     dev_free(h->d_mmse);
     dev_free(h->d_atan);
     dev_free(h->d_st_in);
-    dev_free(h->d_st_sym);
+    dev_free(h->d_st_blk);
     dev_free(h->d_st_err);
     dev_free(h->d_st_mu);
     dev_free(h->d_st_bits);
@@ -1244,6 +1246,23 @@ extern "C" int aisx_msk_last_status(aisx_msk* h, int* status, void* stream)
     return AISX_OK;
 }
 
+// GNU Radio path: the call's control words set, and its three result words gathered behind the symbols' header,
+// by one-thread kernels -- a blocking hipMemcpy of four bytes costs as much as a launch, and a call had eight of them
+__global__ void k_msk_host_setup(int* tagn, int ntags, unsigned long long* nread, unsigned long long R, int* carry_len, int* ctag_n)
+{
+    *tagn = ntags;
+    *nread = R;
+    *carry_len = 0;
+    *ctag_n = 0;
+}
+__global__ void k_msk_host_pack(int* hdr, const int* produced, const int* consumed, const int* status)
+{
+    hdr[0] = *produced;
+    hdr[1] = *consumed;
+    hdr[2] = *status;
+    hdr[3] = 0;
+}
+
 extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ninput_items, const aisx_cf32* in,
                                           aisx_cf32* out, float* out_err, float* out_mu, uint8_t* out_bits,
                                           const aisx_tag* tags, int ntags, uint64_t nitems_read,
@@ -1269,14 +1288,19 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
         h->st_in_cap = nin;
     }
     if (noutput_items > h->st_out_cap) {
-        dev_free(h->d_st_sym);
+        dev_free(h->d_st_blk);
+        h->d_st_blk = nullptr;
+        h->d_st_sym = nullptr;
         dev_free(h->d_st_err);
         dev_free(h->d_st_mu);
         dev_free(h->d_st_bits);
-        if ((rc = dev_alloc(&h->d_st_sym, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_err, noutput_items)) != AISX_OK ||
+        // (symbols behind a 16-byte header {produced, consumed, status, 0}: one copy brings back both)
+        if ((rc = dev_alloc(&h->d_st_blk, (size_t)noutput_items + 2)) != AISX_OK || (rc = dev_alloc(&h->d_st_err, noutput_items)) != AISX_OK ||
             (rc = dev_alloc(&h->d_st_mu, noutput_items)) != AISX_OK || (rc = dev_alloc(&h->d_st_bits, noutput_items)) != AISX_OK)
             return rc;
+        h->d_st_sym = h->d_st_blk + 2;
         h->st_out_cap = noutput_items;
+        h->st_host.resize((size_t)noutput_items + 2);
     }
     if (ntags + 1 > h->st_tag_cap) {
         dev_free(h->d_st_tags);
@@ -1290,12 +1314,9 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
         AISX_HIPCHK(hipMemset(h->d_st_in + ninput_items, 0, sizeof(cf)));
     if (ntags > 0)
         AISX_HIPCHK(hipMemcpy(h->d_st_tags, tags, sizeof(tag_rec) * ntags, hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemcpy(h->d_st_tagn, &ntags, sizeof(int), hipMemcpyHostToDevice));
-    unsigned long long R = nitems_read;
-    AISX_HIPCHK(hipMemcpy(h->d_nread, &R, sizeof(R), hipMemcpyHostToDevice));
-    const int zero = 0;
-    AISX_HIPCHK(hipMemcpy(h->d_carry_len[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
-    AISX_HIPCHK(hipMemcpy(h->d_ctag_n[h->cur], &zero, sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_msk_host_setup, dim3(1), dim3(1), 0, 0, h->d_st_tagn, ntags, h->d_nread, (unsigned long long)nitems_read,
+                       h->d_carry_len[h->cur], h->d_ctag_n[h->cur]);
+    AISX_HIPCHK(hipGetLastError());
     if ((rc = msk_launch_tagprep(h, h->d_st_tags, h->d_st_tagn, ntags + 1, 0)) != AISX_OK)
         return rc;
     MskParams p;
@@ -1316,16 +1337,22 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     if ((rc = msk_launch(p, 1, 0)) != AISX_OK)
         return rc;
     h->cur ^= 1;
-    if ((rc = msk_launch_bittail(h, h->d_st_sym, noutput_items, h->d_produced, h->d_st_bits, noutput_items,
-                                 noutput_items, 0)) != AISX_OK)
+    // (the NRZI bit tail only for a caller that takes its output -- the gr::ais block does not, python/ais_demod.py:48-52
+    // are blocks of their own there: its state then carries on from the last call that did)
+    if (out_bits && (rc = msk_launch_bittail(h, h->d_st_sym, noutput_items, h->d_produced, h->d_st_bits, noutput_items,
+                                             noutput_items, 0)) != AISX_OK)
         return rc;
-    int st = 0;
-    AISX_HIPCHK(hipMemcpy(produced, h->d_produced, sizeof(int), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(consumed, h->d_consumed, sizeof(int), hipMemcpyDeviceToHost));
-    AISX_HIPCHK(hipMemcpy(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_msk_host_pack, dim3(1), dim3(1), 0, 0, (int*)h->d_st_blk, h->d_produced, h->d_consumed, h->d_status);
+    AISX_HIPCHK(hipGetLastError());
+    // header + every symbol the call may have produced in one copy (at most noutput_items of them: a few KB)
+    AISX_HIPCHK(hipMemcpy(h->st_host.data(), h->d_st_blk, sizeof(cf) * ((size_t)noutput_items + 2), hipMemcpyDeviceToHost));
+    const int* hdr = (const int*)h->st_host.data();
+    *produced = hdr[0];
+    *consumed = hdr[1];
+    const int st = hdr[2];
     const int np = *produced;
     if (np > 0) {
-        AISX_HIPCHK(hipMemcpy(out, h->d_st_sym, sizeof(cf) * np, hipMemcpyDeviceToHost));
+        memcpy(out, h->st_host.data() + 2, sizeof(cf) * (size_t)np);
         if (out_err)
             AISX_HIPCHK(hipMemcpy(out_err, h->d_st_err, sizeof(float) * np, hipMemcpyDeviceToHost));
         if (out_mu)

@@ -262,7 +262,11 @@ int aisx_msk_set_head_start(aisx_msk* h, int microseconds);
  * consume_each(), *produced the return value.  The reference's loop bound
  * (impl :119,:138) lets the 8-tap interpolator read in[ninput_items], one item
  * past what the scheduler announced; in_has_lookahead = 1 says that item is
- * readable (always true inside a GNU Radio circular buffer), 0 substitutes 0. */
+ * readable (always true inside a GNU Radio circular buffer), 0 substitutes 0.
+ * out_err / out_mu / out_bits may be NULL (ports not connected).  The NRZI bit tail runs only in calls
+ * that pass out_bits; its state (previous symbol, previous sliced bit) carries on from the last call
+ * that did, so a caller takes bits in every call or in none (the gr::ais block takes none: the tail
+ * is four GNU Radio blocks of its own there, python/ais_demod.py:48-52). */
 int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ninput_items, const aisx_cf32* in, aisx_cf32* out,
                                float* out_err, float* out_mu, uint8_t* out_bits, const aisx_tag* tags, int ntags,
                                uint64_t nitems_read, int in_has_lookahead, int* consumed, int* produced);
