@@ -47,6 +47,8 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
+    if (h->agc) // (the placement claim is the chain's: the handle goes back as it came)
+        (void)aisx_agc_set_lds_claim(h->agc, 0);
     for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamSynchronize(s);
