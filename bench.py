@@ -114,13 +114,19 @@ def pmc_traffic(nchan, T, N):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     summary (collected in separate --pmc passes, see profiles/), if it was taken on
     this workload; (None, None) otherwise."""
-    for name in ("r04_corr_main_pmc.json", "r04_corr2d_main_pmc.json", "r03_corr_main_pmc.json", "r02_corr_main_pmc.json", "r01_corr_main_pmc.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    import glob
+
+    kern = corr_kernel_name(N)
+    # (the newest round's summary of THIS kernel on THIS workload: rNN_corr*_pmc.json, highest NN first)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_corr*_pmc.json")), reverse=True):
+        name = os.path.basename(path)
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         w = d.get("workload", {})
+        if not str(d.get("kernel", "")).startswith(kern):
+            continue
         if (w.get("channels"), w.get("samples"), w.get("template_len")) == (nchan, T, N):
             return d.get("hbm_bytes_per_launch"), "profiles/%s (kernel %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % (
                 name, d.get("kernel"))
@@ -464,10 +470,97 @@ def spawn_ranks(args):
 
 def corr_kernel_name(n):
     """the correlator kernel aisx_corr_process launches for an n-item template (aisx_lib.hip)"""
-    dma = os.environ.get("AISX_CORR_DMA", "1") != "0"
-    if n <= 512:
-        return "k_corr2d_main" if dma else "k_corr_main"
-    return "k_corr4d_main" if dma else "k_corr4_main"
+    return "k_corr2d_main" if n <= 512 else "k_corr4f_main"
+
+
+class PowerSampler:
+    """Package power and shader clock of one GPU from its hwmon files (power1_average / power1_input in uW, freq1_input in
+    Hz), read every few ms by a thread while a measurement runs.  Why it is in the line: the correlator alone runs the
+    package into its 1400 W limit and the firmware answers with the shader clock (2.0-2.15 GHz instead of 2.4), and the
+    kernel's time follows the clock -- the number next to a roofline fraction that says which limit was met."""
+
+    def __init__(self, index=0, period=0.004):
+        import glob
+
+        self.files = None
+        cards = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = next((os.path.join(h, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+            fq = os.path.join(h, "freq1_input")
+            if pw:
+                pci = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))  # 0000:bb:dd.f
+                cards.append((pw, fq if os.path.exists(fq) else None, pci))
+        # the card of THIS process's device: by PCI address (a box may show more cards in sysfs than the process may use)
+        want = None
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001
+            pass
+        pick = [c for c in cards if want and c[2].lower().startswith(want)]
+        if pick:
+            self.files = pick[0][:2]
+        elif len(cards) == 1:
+            self.files = cards[0][:2]
+        self.period = period
+        self.samples = []
+        self._stop = None
+        self._th = None
+
+    def _read(self, path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        import threading
+
+        if self.files is None:
+            return self
+        self.samples = []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                pw = self._read(self.files[0])
+                fq = self._read(self.files[1]) if self.files[1] else None
+                self.samples.append((pw, fq))
+                self._stop.wait(self.period)
+
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        self._th = None
+        pw = [a / 1e6 for a, _ in self.samples if a]
+        fq = [b / 1e6 for _, b in self.samples if b]
+        if not pw:
+            return None
+        return {"package_W_mean": float(np.mean(pw)), "package_W_max": float(np.max(pw)),
+                "sclk_MHz_mean": float(np.mean(fq)) if fq else None, "sclk_MHz_min": float(np.min(fq)) if fq else None,
+                "samples": len(pw), "source": self.files[0]}
+
+
+def spin_up(torch, device, ms=250.0):
+    """Untimed device work before the warm-up steps: after idle the firmware ramps the shader clock over tens of ms
+    (0.6 -> 2.1 GHz in ~60 ms on this pool), and every kernel of this path is clock-bound -- a 20-step timed region
+    behind five warm-up steps would otherwise start on a chip that is still coming up.  A streaming receiver never idles."""
+    a = torch.empty(64 << 20, dtype=torch.float32, device=device)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            a.mul_(1.0001)
+        torch.cuda.synchronize()
+    del a
 
 
 def main():
@@ -570,22 +663,25 @@ def main():
                 state["last"] = dem.work_pipelined(x, x_next=x if (stock and lookahead) else None)
             state["k"] += 1
 
+        spin_up(torch, device)  # (untimed, not a step: the clocks of an idle chip take tens of ms to come up)
         for _ in range(args.warmup):
             step()
         barrier()
         corr.set_profiling(True)  # restart the event ring: the timed steps only
         if chain != "corr" and not msk_tp:
             dem.clockrec.set_profiling(True)
+        ps = PowerSampler(local_rank).start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        power = ps.stop()
         barrier()
         # per-launch duration of the dominant kernel over the timed region: hipEvents
         # recorded around it on its launch stream in every step, read back only now
         kern_ms = corr.kernel_ms_history()[-args.steps:]
-        res = dict(kern_ms=kern_ms, st=0, ndet=0, parity=None, tag_overflow=False, nchan=nchan)
+        res = dict(kern_ms=kern_ms, st=0, ndet=0, parity=None, tag_overflow=False, nchan=nchan, power=power)
         res["msk_ms"] = dem.clockrec.kernel_ms_history()[-args.steps:] if (chain != "corr" and not msk_tp) else None
         if rank == 0:
             # the last step's results, before anything else touches the handles
@@ -616,13 +712,22 @@ def main():
             del fs2, agc2
         if yout is None:
             yout = torch.empty((nchan, T), dtype=torch.complex64, device=device)
-        # (eight launches back to back, the first two dropped: a launch that follows a host
-        # synchronisation starts on an idle, clocked-down chip and reads 15-20 % longer)
+        # (launches back to back for 0.15 s, then twenty timed ones: a launch that follows a host synchronisation
+        # starts on a clocked-down chip -- the shader clock takes tens of ms to come up -- and the kernel's time follows the clock)
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < 0.15:
+            for _ in range(10):
+                corr.work(yin, out=yout)
+            torch.cuda.synchronize()
+        for _ in range(5):
+            corr.work(yin, out=yout)
         corr.set_profiling(True)
-        for _ in range(8):
+        ps_iso = PowerSampler(local_rank).start()
+        for _ in range(20):
             corr.work(yin, out=yout)
         torch.cuda.synchronize()
-        iso = corr.kernel_ms_history()[-6:]
+        res["power_alone"] = ps_iso.stop()
+        iso = corr.kernel_ms_history()[-20:]
         res["el"] = max_over_ranks(el, device=device)
         res["el_min"] = -max_over_ranks(-el, device=device)
         res["iso"] = iso
@@ -640,18 +745,38 @@ def main():
         for _ in range(3):
             blk.work(x, out=out)
         torch.cuda.synchronize()
+        # (a) as rounds 1-5 measured it: 20 launches behind a host synchronisation -- the shader clock is still coming up
         blk.set_profiling(True)
+        for _ in range(20):
+            blk.work(x, out=out)
+        torch.cuda.synchronize()
+        cold = float(np.mean(blk.kernel_ms_history()[-20:]))
+        # (b) the steady state: launches back to back for 0.25 s (the clock has settled: spin_up), then 40 timed ones
         t0 = time.perf_counter()
-        nrun = 20
+        while time.perf_counter() - t0 < 0.25:
+            for _ in range(20):
+                blk.work(x, out=out)
+            torch.cuda.synchronize()
+        for _ in range(10):
+            blk.work(x, out=out)
+        blk.set_profiling(True)
+        ps = PowerSampler(local_rank).start()
+        t0 = time.perf_counter()
+        nrun = 40
         for _ in range(nrun):
             blk.work(x, out=out)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / nrun
+        power = ps.stop()
         kms = float(np.mean(blk.kernel_ms_history()[-nrun:]))
         nbytes = CORR_BYTES_PER_SAMPLE * float(nch) * T
         r = dict(channels=nch, template_len=int(tm.size), kernel=corr_kernel_name(tm.size),
                  kernel_ms=kms, call_ms=wall * 1e3, achieved_GBs=nbytes / (kms * 1e-3) / 1e9,
-                 frac=nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, complex_MSs=float(nch) * T / wall / 1e6)
+                 frac=nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, complex_MSs=float(nch) * T / wall / 1e6,
+                 kernel_ms_first_20_after_sync=cold, frac_first_20_after_sync=nbytes / (cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 power=power,
+                 how="steady state: 40 launches behind 0.25 s of back-to-back launches (settled clock); *_first_20_after_sync = the "
+                     "20 launches behind a host synchronisation that rounds 1-5 reported (clock still ramping)")
         del blk, x, out
         torch.cuda.empty_cache()
         return r
@@ -704,10 +829,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s%d batched channels/GPU x %d complex samples/step, sps=4, template N=%d (%s), chain=%s"
+                "workload": "%s%d batched channels/GPU x %d complex samples/step, sps=4, template N=%d (%s), chain=%s; "
+                            "device-resident input (the same buffer every step), one-buffer look-ahead (the next step's "
+                            "frequency estimates are prepared during this one: config.side.no_lookahead_ms_per_step is the same "
+                            "work without), clocks spun up by 0.25 s of untimed device work before the warm-up steps"
                 % ("BASELINE config 4 (%d channels on %d GPUs): " % (nchan * world, world) if args.config4 else "",
                    nchan, T, tmpl.size, "stock ais_demod.py" if args.template == "S" else "28-symbol preamble",
                    CHAIN_TEXT[args.chain]),
+                "input": "device-resident", "lookahead_buffers": 1 if args.chain == "stock" else 0, "spin_up_ms": 250,
                 "channels_per_gpu": nchan,
                 "samples_per_step": T,
                 "template_len": int(tmpl.size),
@@ -728,6 +857,10 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms": kms,
                 "kernel_ms_alone": float(np.mean(iso)),
+                "power": {"timed_region": r.get("power"), "kernel_alone": r.get("power_alone"),
+                          "note": "package power (W) and shader clock (MHz) from the GPU's hwmon files while the measurement ran; "
+                                  "the package limit is 1400 W, the clock's ceiling 2400 MHz: the correlator alone sits at the "
+                                  "limit and its time follows the clock (DESIGN.md 4.1)"},
                 "frac_alone": CORR_BYTES_PER_SAMPLE * float(nchan) * T / (float(np.mean(iso)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "kernel_ms is measured over the timed region, where the timing-recovery kernel of the "
                         "previous step shares the chip; *_alone = same launch with nothing else running; copy_ceiling_GBs = "
@@ -809,6 +942,21 @@ def main():
             line["corr_only"] = corr_only
         if not args.no_cpu_baseline and world == 1:  # (the CPU path is timed beside the one-GPU run only)
             line["cpu_baseline"] = cpu_baseline(args.chain if args.chain != "corr" else "core", args.template, sps, T)
+        # the side measurements once more under keys the driver's record keeps whole (it stores `config`, `roofline` and
+        # `cpu_baseline` in full and only the NAMES of other top-level keys)
+        sidek = {k: line[k] for k in ("config4_per_gpu", "corr_est_to_msk_only", "no_lookahead_ms_per_step", "no_lookahead_corr_kernel_ms",
+                                       "no_lookahead_msk_kernel_ms", "config5_wideband", "config1_host_path", "h2d") if k in line}
+        if "msk_time_parallel" in line:
+            sidek["msk_time_parallel"] = {k: line["msk_time_parallel"][k] for k in ("ms_per_step", "ms_per_step_serial_kernel_same_max_noutput_items")}
+        if sidek:
+            line["config"]["side"] = sidek
+        if "roofline_msk" in line:
+            line["roofline"]["msk"] = line["roofline_msk"]
+        if "corr_only" in line:
+            line["roofline"]["corr_only"] = line["corr_only"]
+        line["roofline"]["parity_of_this_run"] = {k: line["parity"][k] for k in ("detections", "detections_matched_within_1", "mag_rtol_max",
+                                                                                  "time_est_abs_max", "bursts_compared", "bursts_in_place",
+                                                                                  "bursts_within_4") if line.get("parity") and k in line["parity"]}
         print(json.dumps(line))
     if use_dist:
         dist.barrier()

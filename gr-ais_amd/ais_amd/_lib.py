@@ -7,7 +7,11 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libaisx.so")
+# The product library reads no environment variable.  lib/libaisx_exp.so is the same code built with -DAISX_EXPERIMENTS
+# (alternative kernels, AISX_* knobs): a process asks for it BEFORE the first call with AISX_LIB_VARIANT=exp (the twin tests
+# under tests/exp_builds/, tools/ab_bench.py) -- a choice of this loader, not of the library.
+LIB_VARIANT = os.environ.get("AISX_LIB_VARIANT", "")
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libaisx_exp.so" if LIB_VARIANT == "exp" else "libaisx.so")
 
 AISX_OK = 0
 AISX_ERR_INVALID = -1
@@ -127,6 +131,8 @@ def lib(device=True):
     sig("aisx_msk_general_work_host", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, i32, pi32, pi32])
     sig("aisx_freqsync_create", i32, [pvp, f64, f64, i32, i32, i32])
     sig("aisx_freqest_create", i32, [pvp, f32, i32, i32, i32])
+    sig("aisx_freqest_create_n", i32, [pvp, f32, i32, i32, i32, i32])
+    sig("aisx_freqsync_is_estimator_only", i32, [vp])
     sig("aisx_freqsync_geometry", i32, [vp, pi32, pi32, pi32])
     sig("aisx_freqsync_drop_ahead", i32, [vp, vp])
     sig("aisx_freqsync_destroy", i32, [vp])

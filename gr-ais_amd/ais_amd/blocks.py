@@ -390,20 +390,22 @@ class freqest:
     fft-shifted spectra, one float estimate per vector."""
 
     def __init__(self, sample_rate, data_rate, fftlen, nchan=1):
-        self._fs = square_and_fft_sync_cc(float(sample_rate), float(data_rate), fftlen, nchan=nchan, max_items=fftlen)
-        self.nchan, self.fftlen = nchan, fftlen
-        if nchan == 1 and float(sample_rate) != int(sample_rate):
-            # the block's own make(): d_offset / d_binsize from the float rate (lib/freqest_impl.cc:46-47)
-            h = C.c_void_p()
-            check(_lib.lib().aisx_freqest_create(C.byref(h), float(sample_rate), int(data_rate), int(fftlen), 64), "freqest")
-            _lib.lib().aisx_freqsync_destroy(self._fs._h)
-            self._fs._h = h
+        # the block's own make(): d_offset / d_binsize from the float rate (lib/freqest_impl.cc:46-47), any fftlen >= 2
+        self.nchan, self.fftlen = int(nchan), int(fftlen)
+        h = C.c_void_p()
+        check(_lib.lib().aisx_freqest_create_n(C.byref(h), float(sample_rate), int(data_rate), self.fftlen, self.nchan, 64), "freqest")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().aisx_freqsync_destroy(self._h)
+            self._h = None
 
     def work(self, vecs, stream=None):
         v = _dev_c64(vecs, self.nchan)
         nvec = v.shape[1] // self.fftlen
         out = torch.empty((self.nchan, max(nvec, 1)), dtype=torch.float32, device=v.device)
-        check(_lib.lib().aisx_freqest_work(self._fs._h, v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0), nvec,
+        check(_lib.lib().aisx_freqest_work(self._h, v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0), nvec,
                                            _stream_ptr(stream)), "freqest.work")
         return out[:, :nvec]
 
@@ -413,7 +415,7 @@ class freqest:
         v = np.ascontiguousarray(vecs, dtype=np.complex64).reshape(-1)
         nvec = v.size // self.fftlen
         out = np.zeros(max(nvec, 1), dtype=np.float32)
-        got = check(_lib.lib().aisx_freqest_work_host(self._fs._h, nvec, v.ctypes.data_as(C.c_void_p),
+        got = check(_lib.lib().aisx_freqest_work_host(self._h, nvec, v.ctypes.data_as(C.c_void_p),
                                                       out.ctypes.data_as(C.c_void_p)), "freqest.work_host")
         return out[:got]
 

@@ -104,7 +104,9 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             bad("msk_timing_recovery", "max_items", mi, need);
         if (fs) {
             aisx_freqsync_geometry(fs, &nc, &mi, &fl);
-            if (nc != nchan)
+            if (aisx_freqsync_is_estimator_only(fs))
+                bad("freq_sync", "made by aisx_freqest_create for the estimator alone, fftlen", fl, 1024);
+            else if (nc != nchan)
                 bad("freq_sync", "nchan", nc, nchan);
             else if (fl != fftlen)
                 bad("freq_sync", "fftlen", fl, fftlen);
@@ -131,7 +133,7 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
     h->nchan = nchan;
     h->max_items = max_items;
     h->fftlen = fs ? fftlen : 0;
-    if (const char* e = getenv("AISX_CHAIN_SERIAL"))
+    if (const char* e = exp_env("AISX_CHAIN_SERIAL"))
         h->serial = atoi(e) != 0;
 #define CKH(e)                                                                                     \
     do {                                                                                           \
@@ -151,11 +153,11 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         CKH(hipGetDevice(&dev));
         CKH(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount;
-        if (const char* e = getenv("AISX_CHAIN_MSK_CUS"))
+        if (const char* e = exp_env("AISX_CHAIN_MSK_CUS"))
             msk_cus = atoi(e);
-        if (const char* e = getenv("AISX_CHAIN_WALK_WITH_MSK"))
+        if (const char* e = exp_env("AISX_CHAIN_WALK_WITH_MSK"))
             walk_with_msk = atoi(e);
-        if (const char* e = getenv("AISX_CHAIN_TAIL_WITH_MSK"))
+        if (const char* e = exp_env("AISX_CHAIN_TAIL_WITH_MSK"))
             tail_with_msk = atoi(e);
         if (h->serial || msk_cus < 0 || msk_cus >= ncu)
             msk_cus = 0;
@@ -206,7 +208,7 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             ncu = prop.multiProcessorCount;
         const int msk_wgs = (nchan + 31) / 32;
         int claim = (ncu > 0 && 2 * msk_wgs <= ncu) ? 72 * 1024 : 48 * 1024;
-        if (const char* e = getenv("AISX_CHAIN_AGC_CLAIM"))
+        if (const char* e = exp_env("AISX_CHAIN_AGC_CLAIM"))
             claim = atoi(e);
         if ((rc = aisx_agc_set_lds_claim(agc, claim)) != AISX_OK) {
             chain_free(h);
@@ -217,7 +219,7 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         // the bit tail of step k beside the recovery of step k + 1; the next step's sample passes
         // behind this step's tag prepass (aisx_msk_wait_prepass: the first call arms the event)
         int us = 20; // AISX_MSK_HEADSTART_US: the recovery kernel's head start at the dispatcher (aisx_msk_set_head_start)
-        if (const char* e = getenv("AISX_MSK_HEADSTART_US"))
+        if (const char* e = exp_env("AISX_MSK_HEADSTART_US"))
             us = atoi(e);
         if ((rc = aisx_msk_set_tail_stream(msk, h->s_tail, 1)) != AISX_OK || (rc = aisx_msk_set_head_start(msk, us < 0 ? 0 : us)) != AISX_OK ||
             (rc = aisx_msk_wait_prepass(msk, h->s_main)) != AISX_OK) {

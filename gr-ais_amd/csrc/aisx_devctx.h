@@ -88,6 +88,28 @@ struct DevCtx {
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(av), "s"(k), "v"(m));
         return tocf(r);
     }
+    // a b and a conj(b), rounded as cmul_fma / cmul_conj_fma (aisx_common.h): two packed instructions, the
+    // cross terms picked by operand-select and negate modifiers.  (Left to the compiler, each product with a
+    // loop-invariant b keeps a swapped and a negated copy of b in registers next to b itself: k_corr4e.h has 29
+    // such constants per thread and 128 VGPRs.)
+    __device__ __forceinline__ cf cmul(cf a, cf b) const
+    {
+        v2f m, r;
+        const v2f av = tov(a), bv = tov(b);
+        // m = (a.re b.re, a.re b.im);  r = (-a.im b.im + m.re, a.im b.re + m.im)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m) : "v"(av), "v"(bv));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(m));
+        return tocf(r);
+    }
+    __device__ __forceinline__ cf cmul_conj(cf a, cf b) const
+    {
+        v2f m, r;
+        const v2f av = tov(a), bv = tov(b);
+        // m = (a.re b.re, -(a.re b.im));  r = (a.im b.im + m.re, a.im b.re + m.im)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(m) : "v"(av), "v"(bv));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(m));
+        return tocf(r);
+    }
     // lo = v of lane (i & ~W), hi = v of lane (i | W), W = 16 or 32: one row swap per 32 bits
     // (v_permlane16_swap / v_permlane32_swap with both operands = v)
     template <int W>
@@ -270,6 +292,14 @@ struct DevCtx {
     // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
     // outstanding global stores or for DMA still in flight
     __device__ __forceinline__ void lds_barrier() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    // one complex item from buffer byte offset voff + soff (range-checked on voff only: zeros beyond the count), streaming
+    // policy; the compiler keeps the count of loads in flight and waits where the value is first used
+    __device__ __forceinline__ cf buf_load64(const Buf& b, unsigned voff, unsigned soff) const
+    {
+        const v2u d = __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)b.base, 0, (int)b.nbytes, 0x00020000),
+                                                           (int)voff, (int)soff, AISX_STORE_AUX);
+        return mk(__uint_as_float(d.x), __uint_as_float(d.y));
+    }
     // one complex item to buffer byte offset voff + soff; range-checked on voff only (the scalar
     // part is added after the check)
     __device__ __forceinline__ void buf_store64(const Buf& b, unsigned voff, unsigned soff, cf v) const
@@ -291,6 +321,8 @@ struct DevCtxC : DevCtx {
     __device__ __forceinline__ cf csub(cf a, cf b) const { return mk(a.re - b.re, a.im - b.im); }
     __device__ __forceinline__ cf add_mj(cf a, cf b) const { return mk(a.re + b.im, a.im - b.re); }
     __device__ __forceinline__ cf add_pj(cf a, cf b) const { return mk(a.re - b.im, a.im + b.re); }
+    __device__ __forceinline__ cf cmul(cf a, cf b) const { return cmul_fma(a, b); }
+    __device__ __forceinline__ cf cmul_conj(cf a, cf b) const { return cmul_conj_fma(a, b); }
     template <int KSEL, int CS, bool CNEG, int SS, bool SNEG>
     __device__ __forceinline__ cf cmul_sel(cf a) const
     {

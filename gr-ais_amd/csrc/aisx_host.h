@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/aisx.h"
@@ -31,6 +32,19 @@ inline void set_err(const char* fmt, ...)
             return AISX_ERR_HIP;                                                               \
         }                                                                                      \
     } while (0)
+
+// Experiment knobs.  The product library reads NO environment variable: its behaviour is what the API was told.
+// A build made with -DAISX_EXPERIMENTS (lib/libaisx_exp.so: tools/ab_*, the profiling scripts, the tests of the
+// alternative kernels) answers these look-ups from the environment; in the product build they fold to "unset".
+inline const char* exp_env(const char* name)
+{
+#ifdef AISX_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 inline int require_device()
 {

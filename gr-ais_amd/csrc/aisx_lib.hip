@@ -50,6 +50,11 @@ __global__ __launch_bounds__(CF_T) void k_corr_inith(CorrInitParams p)
     corr_inith_body(cx, p);
 }
 
+// The product launches two correlators: k_corr2d_main (templates up to 512 samples) and k_corr4f_main (513 .. 2048).
+// Their predecessors -- round 1's k_corr_main / k_corr4_main (plain window loads), k_corr4d_main (256 threads x 16 points,
+// LDS-DMA), k_corr4e_main (512 threads x 8 points, LDS-DMA) -- exist in the experiments build only (AISX_CORR_DMA=0,
+// AISX_CORR_WIDE=0 / 1): A/B partners and the twins of tests/test_gpu_corr_msk.py.
+#ifdef AISX_EXPERIMENTS
 __global__ __launch_bounds__(CF_T, 3) void k_corr_main(CorrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,6 +106,66 @@ static void (*corr4d_pick(int N))(CorrParams)
     default: return k_corr4d_main<0>; // any other length: the run-time-length build (no scratch either, k_corr4d.h)
     }
 }
+
+#ifdef CE_PROF
+namespace aisx {
+__device__ unsigned long long g_ce_prof[16];
+}
+extern "C" int aisx_debug_ce_prof(unsigned long long* out16, int reset)
+{
+    AISX_HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(aisx::g_ce_prof), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {};
+        AISX_HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(aisx::g_ce_prof), z, sizeof(z)));
+    }
+    return AISX_OK;
+}
+#endif
+#endif // AISX_EXPERIMENTS
+// the F = 4096 correlator on 512 threads x 8 points (k_corr4e.h: the plan; k_corr4f.h: the kernel the product runs):
+// two workgroups per CU, at most 128 VGPRs: four waves per SIMD
+__global__ __launch_bounds__(CE_T) void k_corr4e_inith(CorrInitParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4e_inith_body(cx, p);
+}
+#ifdef AISX_EXPERIMENTS
+template <int NC>
+__global__ __launch_bounds__(CE_T, 4) void k_corr4e_main(CorrParams p) // (second argument: waves per SIMD)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4e_main_body<DevCtx, NC>(cx, p);
+}
+#endif
+// ... and with the next window fetched into registers (k_corr4f.h): one image + a small overlap buffer
+template <int NC>
+__global__ __launch_bounds__(CE_T, 4) void k_corr4f_main(CorrParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevCtx cx{ smem };
+    corr4f_main_body<DevCtx, NC>(cx, p);
+}
+static void (*corr4f_pick(int N))(CorrParams)
+{
+    switch (N) {
+    case 896: return k_corr4f_main<896>;
+    case 1120: return k_corr4f_main<1120>;
+    case 1024: return k_corr4f_main<1024>;
+    case 1139: return k_corr4f_main<1139>;
+    default: return k_corr4f_main<0>;
+    }
+}
+#ifdef AISX_EXPERIMENTS
+static void (*corr4e_pick(int N))(CorrParams)
+{
+    switch (N) {
+    case 896: return k_corr4e_main<896>;
+    default: return k_corr4e_main<0>;
+    }
+}
+#endif
 
 // the F = 2048 correlator with the next tile's window prefetched by LDS-DMA (k_corr2d.h): four
 // workgroups of two waves per CU (two 17 KB window images each), up to 256 VGPRs
@@ -228,6 +293,12 @@ struct aisx_corr {
     int nchan = 0, N = 0, max_items = 0, tag_cap = 0, L = 0, isps = 0, out_multiple = 0;
     int F = CF_F; // FFT build serving this template length
     bool dma = true; // F = 4096: the k_corr4d.h build (AISX_CORR_DMA=0 selects k_corr4k.h's)
+#ifndef AISX_CORR_WIDE_DEFAULT
+#define AISX_CORR_WIDE_DEFAULT 2
+#endif
+    // F = 4096 with dma: 0 = k_corr4d.h, 1 = the 512-thread build k_corr4e.h, 2 = k_corr4f.h (1 and 2: the template
+    // spectrum in the order of the 8 x 8 x 8 x 8 plan)
+    int wide = AISX_CORR_WIDE_DEFAULT;
     const void* dma_attr_set = nullptr; // build whose dynamic-LDS limit has been raised
     float sps = 0, thresh = 0;
     unsigned mark_delay = 0;
@@ -269,8 +340,14 @@ static int corr_upload_taps(aisx_corr* h)
     CorrInitParams ip{ h->d_tapspad, h->d_wtab, h->d_Hpos };
     if (h->F == CF_F)
         hipLaunchKernelGGL(k_corr_inith, dim3(1), dim3(CF_T), CF_LDS_BYTES, 0, ip);
-    else
+#ifdef AISX_EXPERIMENTS
+    else if (!(h->dma && h->wide))
         hipLaunchKernelGGL(k_corr4_inith, dim3(1), dim3(CF4_T), CF4_LDS_BYTES, 0, ip);
+#endif
+    else {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)k_corr4e_inith, hipFuncAttributeMaxDynamicSharedMemorySize, CE_LDS_BYTES));
+        hipLaunchKernelGGL(k_corr4e_inith, dim3(1), dim3(CE_T), CE_LDS_BYTES, 0, ip);
+    }
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipDeviceSynchronize());
     return AISX_OK;
@@ -302,8 +379,10 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->sps = sps;
     h->F = corr_pick_fft(nsym);
     h->L = h->F - nsym;
-    if (const char* e = getenv("AISX_CORR_DMA")) // (experiments, and the tests of the other build)
+    if (const char* e = exp_env("AISX_CORR_DMA")) // (experiments, and the tests of the other build)
         h->dma = atoi(e) != 0;
+    if (const char* e = exp_env("AISX_CORR_WIDE"))
+        h->wide = atoi(e);
     // constructor maths of lib/corr_est_cc_impl.cc:58-85 (aisx_plan.h)
     CorrSetup cs = corr_setup((const cf*)symbols, nsym, sps, mark_delay, threshold);
     h->symbols = cs.symbols;
@@ -525,7 +604,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     int nseg, tps;
     corr_grid(h->nchan, n, h->L, h->F, &nseg, &tps, dma ? (h->F == CF4_F ? 2 : 4) : 0);
     static const int force_nseg = [] { // (experiments: segments per channel, AISX_CORR_NSEG)
-        const char* e = getenv("AISX_CORR_NSEG");
+        const char* e = exp_env("AISX_CORR_NSEG");
         return e ? atoi(e) : 0;
     }();
     if (force_nseg > 0) {
@@ -559,23 +638,36 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     const int evi = (int)(h->ncalls_prof % aisx_corr::NEV);
     if (h->prof)
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
-    if (h->F == CF_F && dma) {
-        hipLaunchKernelGGL(corr2d_pick(h->N), dim3(nseg, h->nchan), dim3(CF_T), C2_LDS_BYTES, st, p);
-    } else if (h->F == CF_F) {
-        hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
-    } else if (dma) {
-        void (*kern)(CorrParams) = corr4d_pick(h->N);
-        // (experiments: LDS a workgroup claims beyond what it uses decides how many of them fit beside the timing
-        // recovery's 92 160 bytes on a CU -- one at 71 680, none above 71 680)
-        static const int lds_pad = getenv("AISX_CORR_LDS_PAD") ? atoi(getenv("AISX_CORR_LDS_PAD")) : 0;
-        if (h->dma_attr_set != (const void*)kern) {
-            AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES + lds_pad));
+    int rc_launch = AISX_OK;
+    auto launch_big_lds = [&](void (*kern)(CorrParams), int threads, int lds_bytes) -> int {
+        if (h->dma_attr_set != (const void*)kern) { // (per handle: handles may live on different devices)
+            AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
             h->dma_attr_set = (const void*)kern;
         }
-        hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(CF4_T), CD_LDS_BYTES + lds_pad, st, p);
-    } else {
+        hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(threads), lds_bytes, st, p);
+        return AISX_OK;
+    };
+#ifdef AISX_EXPERIMENTS
+    // (LDS a workgroup claims beyond what it uses decides how many of them fit beside the timing recovery's 92 160 bytes on a CU)
+    static const int lds_pad = exp_env("AISX_CORR_LDS_PAD") ? atoi(exp_env("AISX_CORR_LDS_PAD")) : 0;
+    if (h->F == CF_F && !dma)
+        hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
+    else if (h->F == CF4_F && !dma)
         hipLaunchKernelGGL(k_corr4_main, dim3(nseg, h->nchan), dim3(CF4_T), CF4_LDS_BYTES, st, p);
-    }
+    else if (h->F == CF4_F && h->wide == 0)
+        rc_launch = launch_big_lds(corr4d_pick(h->N), CF4_T, CD_LDS_BYTES + lds_pad);
+    else if (h->F == CF4_F && h->wide == 1)
+        rc_launch = launch_big_lds(corr4e_pick(h->N), CE_T, CE_LDS_BYTES + lds_pad);
+    else
+#else
+    const int lds_pad = 0;
+#endif
+    if (h->F == CF_F)
+        hipLaunchKernelGGL(corr2d_pick(h->N), dim3(nseg, h->nchan), dim3(CF_T), C2_LDS_BYTES, st, p);
+    else
+        rc_launch = launch_big_lds(corr4f_pick(h->N), CE_T, cfz_lds_bytes(h->N) + lds_pad);
+    if (rc_launch != AISX_OK)
+        return rc_launch;
     AISX_HIPCHK(hipGetLastError());
     if (h->prof) {
         AISX_HIPCHK(hipEventRecord(h->ev1[evi], st));

@@ -107,7 +107,7 @@ static int msk_launch(const MskParams& p, int nwg, hipStream_t st)
     // LDS beyond what the kernel uses keeps other streams' workgroups off this CU: a knob for how
     // much of its SIMDs' issue the recurrence shares (AISX_MSK_LDS_PAD, KiB; experiments)
     static const int pad = [] {
-        const char* e = getenv("AISX_MSK_LDS_PAD");
+        const char* e = exp_env("AISX_MSK_LDS_PAD");
         return e ? atoi(e) * 1024 : 0;
     }();
     const int lds = std::min(msk_lds_bytes(p.lpw) + pad, 160 * 1024);
@@ -310,23 +310,23 @@ extern "C" int aisx_msk_create(aisx_msk** out, float sps, float gain, float limi
         // 7.2 / 6.3 / 5.5 ms per launch at 16 / 8 / 4 channels per wave; 8 gives the shortest
         // step (at 4 the kernel sits on all 256 CUs and slows the bandwidth-bound stages more)
         h->lpw = 8;
-        if (const char* e = getenv("AISX_MSK_INLINE_TAGS"))
+        if (const char* e = exp_env("AISX_MSK_INLINE_TAGS"))
             h->inline_tags = atoi(e) != 0;
-        if (const char* e = getenv("AISX_MSK_TIME_PARALLEL")) // (experiments; the API is aisx_msk_set_time_parallel)
+        if (const char* e = exp_env("AISX_MSK_TIME_PARALLEL")) // (experiments; the API is aisx_msk_set_time_parallel)
             h->tp_smax = atoi(e) != 0 ? MSKP_SMAX : 0;
-        if (const char* e = getenv("AISX_MSK_TP_SMAX")) // restart points per channel (0: the serial kernel)
+        if (const char* e = exp_env("AISX_MSK_TP_SMAX")) // restart points per channel (0: the serial kernel)
             h->tp_smax = std::max(0, std::min(atoi(e), (int)MSKP_SMAX));
-        if (const char* e = getenv("AISX_MSK_TP_GAP"))
+        if (const char* e = exp_env("AISX_MSK_TP_GAP"))
             h->tp_min_gap = std::max(0, atoi(e));
-        if (const char* e = getenv("AISX_MSK_TP_JOIN"))
+        if (const char* e = exp_env("AISX_MSK_TP_JOIN"))
             h->tp_join = atoi(e) != 0;
-        if (const char* e = getenv("AISX_MSK_TP_MAXSPAN"))
+        if (const char* e = exp_env("AISX_MSK_TP_MAXSPAN"))
             h->tp_max_span = std::max(64, atoi(e));
-        if (const char* e = getenv("AISX_MSK_JW"))
+        if (const char* e = exp_env("AISX_MSK_JW"))
             h->tp_jw = std::max(1, std::min(64, atoi(e)));
-        if (const char* e = getenv("AISX_MSK_MAX_NOUTPUT")) // (experiments; the API is aisx_msk_set_max_noutput_items)
+        if (const char* e = exp_env("AISX_MSK_MAX_NOUTPUT")) // (experiments; the API is aisx_msk_set_max_noutput_items)
             h->max_noutput = std::max(0, atoi(e));
-        if (const char* e = getenv("AISX_MSK_LPW")) { // (experiments)
+        if (const char* e = exp_env("AISX_MSK_LPW")) { // (experiments)
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64)
                 h->lpw = v;
@@ -773,7 +773,7 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         // the inputs are there (ready_event; without one: when `stream` gets here), when the join of
         // two calls ago has let go of this parity's records and the bit tail of its staging rows.
         // (experiment switches, read once: units on the call's stream; unsorted unit list)
-        static const bool one_stream = getenv("AISX_MSK_TP_ONE_STREAM") != nullptr;
+        static const bool one_stream = exp_env("AISX_MSK_TP_ONE_STREAM") != nullptr;
         if (!one_stream)
             su = h->s_units;
         if (su != st) {
@@ -812,7 +812,7 @@ static int msk_process_stream(aisx_msk* h, const aisx_cf32* d_in, long in_stride
         t.min_gap = h->tp_min_gap;
         t.max_span = h->tp_join ? h->tp_max_span : 0x3fffffff;
         // units sorted by length need every row within 4 GiB of the first (32-bit buffer offsets)
-        static const bool tp_unsorted_env = getenv("AISX_MSK_TP_UNSORTED") != nullptr;
+        static const bool tp_unsorted_env = exp_env("AISX_MSK_TP_UNSORTED") != nullptr;
         tp_sorted = (double)h->nchan * (double)in_stride * 8.0 < 4294000000.0 && !tp_unsorted_env;
         t.ucount = tp_sorted ? ucount : nullptr;
         t.ulist = ulist;

@@ -11,6 +11,8 @@
 #include "k_corr.h"
 #include "k_corr4k.h"
 #include "k_corr4d.h"
+#include "k_corr4e.h"
+#include "k_corr4f.h"
 #include "k_corr2d.h"
 
 namespace aisx {

@@ -149,6 +149,9 @@ struct aisx_freqsync {
     float* d_hst_fh = nullptr;
     size_t hst_in_cap = 0, hst_out_cap = 0, hst_fh_cap = 0;
     int nchan = 0, fftlen = 0, max_items = 0, offset = 0, max_vec = 0;
+    // made by aisx_freqest_create with a vector length the freq_sync kernels do not implement: the handle serves
+    // aisx_freqest_work / aisx_freqest_work_host only (the search over bins needs no transform of ours)
+    bool est_only = false;
     float binsize = 0, sensitivity = 0;
     cf* d_pend[2] = { nullptr, nullptr };
     int cur = 0, npend = 0;
@@ -190,6 +193,16 @@ struct aisx_freqsync {
     float* d_st_out = nullptr;
     int st_cap = 0;
 };
+
+static int fs_whole(const aisx_freqsync* h, const char* who)
+{
+    if (h && h->est_only) {
+        set_err("%s: this handle was made by aisx_freqest_create with fftlen %d and serves aisx_freqest_work / "
+                "aisx_freqest_work_host only (square_and_fft_sync_cc is implemented for fftlen = %d)", who, h->fftlen, FS_F);
+        return AISX_ERR_INVALID;
+    }
+    return AISX_OK;
+}
 
 extern "C" int aisx_freqsync_create(aisx_freqsync** out, double samplerate, double bits_per_sec, int fftlen, int nchan,
                                     int max_items)
@@ -284,23 +297,43 @@ extern "C" int aisx_freqsync_drop_ahead(aisx_freqsync* h, void* stream)
     return AISX_OK;
 }
 
-extern "C" int aisx_freqest_create(aisx_freqsync** out, float sample_rate, int data_rate, int fftlen, int max_vectors)
+extern "C" int aisx_freqest_create_n(aisx_freqsync** out, float sample_rate, int data_rate, int fftlen, int nchan, int max_vectors)
 {
     // freqest::make(float sample_rate, int data_rate, int fftlen) (include/ais/freqest.h:46): the block alone,
-    // with a sample rate that need not be a whole number (lib/freqest_impl.cc:46-47 keep the float)
-    if (max_vectors < 1 || data_rate < 1) {
-        if (out)
-            *out = nullptr;
-        set_err("aisx_freqest_create: bad argument");
+    // with a sample rate that need not be a whole number (lib/freqest_impl.cc:46-47 keep the float) and ANY vector
+    // length: work() is a search over fftlen - offset bins of spectra somebody else transformed (:57-88)
+    if (out)
+        *out = nullptr;
+    if (!out || max_vectors < 1 || data_rate < 1 || fftlen < 2 || nchan < 1 || !(sample_rate > 0)) {
+        set_err("aisx_freqest_create: bad argument (fftlen %d, data_rate %d, %d channels)", fftlen, data_rate, nchan);
         return AISX_ERR_INVALID;
     }
-    int rc = aisx_freqsync_create(out, (double)sample_rate, (double)data_rate, fftlen, 1, max_vectors * fftlen);
-    if (rc != AISX_OK)
-        return rc;
+    int rc;
+    if (fftlen == FS_F) {
+        if ((rc = aisx_freqsync_create(out, (double)sample_rate, (double)data_rate, fftlen, nchan, max_vectors * fftlen)) != AISX_OK)
+            return rc;
+    } else {
+        if ((rc = require_device()) != AISX_OK)
+            return rc;
+        aisx_freqsync* h = new aisx_freqsync();
+        h->est_only = true;
+        h->nchan = nchan;
+        h->fftlen = fftlen;
+        h->max_items = max_vectors * fftlen;
+        h->max_vec = max_vectors;
+        *out = h;
+    }
     (*out)->offset = (int)(fftlen * ((float)data_rate / sample_rate));
     (*out)->binsize = sample_rate / (float)fftlen;
     return AISX_OK;
 }
+
+extern "C" int aisx_freqest_create(aisx_freqsync** out, float sample_rate, int data_rate, int fftlen, int max_vectors)
+{
+    return aisx_freqest_create_n(out, sample_rate, data_rate, fftlen, 1, max_vectors);
+}
+
+extern "C" int aisx_freqsync_is_estimator_only(const aisx_freqsync* h) { return h && h->est_only ? 1 : 0; }
 
 extern "C" int aisx_freqsync_destroy(aisx_freqsync* h)
 {
@@ -338,6 +371,8 @@ extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
 {
     if (!h)
         return AISX_ERR_INVALID;
+    if (h->est_only)
+        return AISX_OK; // (freqest::work carries nothing from call to call)
     AISX_HIPCHK(hipDeviceSynchronize());
     AISX_HIPCHK(hipMemset(h->d_phase, 0, sizeof(float) * h->nchan));
     AISX_HIPCHK(hipDeviceSynchronize()); // (null-stream fill vs. the caller's non-blocking streams)
@@ -352,6 +387,8 @@ extern "C" int aisx_freqsync_reset(aisx_freqsync* h)
 extern "C" int aisx_freqsync_process(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, aisx_cf32* d_out,
                                      long out_stride, float* d_fhat, long fhat_stride, int* n_out, void* stream)
 {
+    if (fs_whole(h, "aisx_freqsync_process") != AISX_OK)
+        return AISX_ERR_INVALID;
     if (!h || !d_in || !d_out || !n_out || n < 1 || n > h->max_items || in_stride < n) {
         set_err("aisx_freqsync_process: bad argument");
         return AISX_ERR_INVALID;
@@ -445,6 +482,8 @@ extern "C" int aisx_freqest_work(aisx_freqsync* h, const aisx_cf32* d_vecs, long
 extern "C" int aisx_freqsync_work_host(aisx_freqsync* h, const aisx_cf32* in, int n, aisx_cf32* out, int out_cap,
                                        float* fhat, int fhat_cap)
 {
+    if (fs_whole(h, "aisx_freqsync_work_host") != AISX_OK)
+        return AISX_ERR_INVALID;
     if (!h || !in || !out || n < 1 || n > h->max_items)
         return AISX_ERR_INVALID;
     if (h->nchan != 1) {
@@ -558,7 +597,7 @@ extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, in
     h->W = nsamples;
     h->max_items = max_items;
     h->reference = reference;
-    if (const char* e = getenv("AISX_AGC_STREAMING")) // (experiments; the API is aisx_agc_set_streaming)
+    if (const char* e = exp_env("AISX_AGC_STREAMING")) // (experiments; the API is aisx_agc_set_streaming)
         h->tiles_only = atoi(e) == 0;
     if ((rc = dev_alloc(&h->d_hist[0], (size_t)nchan * nsamples)) != AISX_OK ||
         (rc = dev_alloc(&h->d_hist[1], (size_t)nchan * nsamples)) != AISX_OK) {
@@ -726,7 +765,7 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     e.maxpos_stride = h->max_vec;
     e.nvec = nvec;
     e.offset = h->offset;
-    static const int est_pad = getenv("AISX_EST_LDS_PAD") ? atoi(getenv("AISX_EST_LDS_PAD")) : 0; // (experiments: placement)
+    static const int est_pad = exp_env("AISX_EST_LDS_PAD") ? atoi(exp_env("AISX_EST_LDS_PAD")) : 0; // (experiments: placement)
     hipLaunchKernelGGL(k_fs_est, dim3((nvec + FS_VEC_PER_WG - 1) / FS_VEC_PER_WG, h->nchan), dim3(FS_T), FS_LDS_BYTES + est_pad, st, e);
     AISX_HIPCHK(hipGetLastError());
     if (st_walk != st) { // the walk on a stream of its own, behind the estimates
@@ -768,6 +807,8 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
 extern "C" int aisx_freqsync_estimate_ahead(aisx_freqsync* h, const aisx_cf32* d_in, long in_stride, int n, void* stream,
                                             void* walk_stream)
 {
+    if (fs_whole(h, "aisx_freqsync_estimate_ahead") != AISX_OK)
+        return AISX_ERR_INVALID;
     if (!h || !d_in || n < 1 || n > h->max_items || in_stride < n) {
         set_err("aisx_freqsync_estimate_ahead: bad argument");
         return AISX_ERR_INVALID;
@@ -803,6 +844,8 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
                                          aisx_cf32* d_out, long out_stride, float* d_fhat, long fhat_stride, int* n_out,
                                          void* stream)
 {
+    if (fs_whole(h, "aisx_freqsync_agc_process") != AISX_OK)
+        return AISX_ERR_INVALID;
     if (!h || !a || !d_in || !d_out || !n_out || n < 1 || n > h->max_items || in_stride < n || a->nchan != h->nchan) {
         set_err("aisx_freqsync_agc_process: bad argument");
         return AISX_ERR_INVALID;
@@ -866,7 +909,7 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     p.pend_out = h->d_pend[h->cur ^ 1];
     p.npend = h->npend;
     p.n_raw = n;
-    static const int agcw_pad = getenv("AISX_AGCW_LDS_PAD") ? atoi(getenv("AISX_AGCW_LDS_PAD")) : -1; // (experiments: overrides the handle's claim)
+    static const int agcw_pad = exp_env("AISX_AGCW_LDS_PAD") ? atoi(exp_env("AISX_AGCW_LDS_PAD")) : -1; // (experiments: overrides the handle's claim)
     if (agcw_applies(p.W, total) && !a->tiles_only) {
         const int lds = AGW_LDS_BYTES + (agcw_pad >= 0 ? agcw_pad : a->lds_claim);
         static int lds_limit = 64 * 1024; // (what a launch may ask for before the kernel's limit is raised)

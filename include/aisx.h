@@ -291,6 +291,12 @@ int aisx_freqsync_drop_ahead(aisx_freqsync* h, void* stream);
  * rate as lib/freqest_impl.cc:46-47 compute them (aisx_freqsync_create truncates it to an int first, as
  * python/gmsk_sync.py:25 does).  max_vectors bounds noutput_items of one work() call. */
 int aisx_freqest_create(aisx_freqsync** h, float sample_rate, int data_rate, int fftlen, int max_vectors);
+/* ... for nchan rows of vectors, and any fftlen >= 2: freqest::work (lib/freqest_impl.cc:57-88) searches fftlen - offset
+ * bins of spectra its caller transformed and needs no transform of its own.  A handle made with a vector length other
+ * than 1024 serves aisx_freqest_work / aisx_freqest_work_host only: the square_and_fft_sync_cc entry points
+ * (aisx_freqsync_process, _work_host, _agc_process, _estimate_ahead, aisx_chain_create) refuse it with AISX_ERR_INVALID. */
+int aisx_freqest_create_n(aisx_freqsync** h, float sample_rate, int data_rate, int fftlen, int nchan, int max_vectors);
+int aisx_freqsync_is_estimator_only(const aisx_freqsync* h); /* 1 for such a handle, 0 otherwise */
 int aisx_freqsync_reset(aisx_freqsync* h);
 /* n new items per channel; every complete fftlen-vector is processed (one
  * freqest work() call per channel); *n_out = items written per channel (a

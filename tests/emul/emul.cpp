@@ -87,6 +87,8 @@ struct EmuCtx {
     cf csub(cf a, cf b) const { return mk(a.re - b.re, a.im - b.im); }
     cf add_mj(cf a, cf b) const { return mk(a.re + b.im, a.im - b.re); }
     cf add_pj(cf a, cf b) const { return mk(a.re - b.im, a.im + b.re); }
+    cf cmul(cf a, cf b) const { return cmul_fma(a, b); }
+    cf cmul_conj(cf a, cf b) const { return cmul_conj_fma(a, b); }
     template <int KSEL, int CS, bool CNEG, int SS, bool SNEG>
     cf cmul_sel(cf a) const
     {
@@ -202,6 +204,13 @@ struct EmuCtx {
     template <int N>
     void wait_vm() const {}
     void lds_barrier() const { sync(); }
+    cf buf_load64(const Buf& b, unsigned voff, unsigned soff) const
+    {
+        cf v = mk(0.f, 0.f);
+        if (voff < b.nbytes && voff + 8u <= b.nbytes)
+            memcpy(&v, (const char*)b.base + voff + soff, 8);
+        return v;
+    }
     void buf_store64(const Buf& b, unsigned voff, unsigned soff, cf v) const
     {
         if (voff < b.nbytes && voff + 8u <= b.nbytes)
@@ -245,19 +254,23 @@ extern "C" {
 int emu_cf_sizes(int* F, int* T) { *F = CF_F; *T = CF_T; return CF_LDS_BYTES; }
 int emu_corr_max_template() { return CORR_MAX_TEMPLATE; }
 
+// which F = 4096 build runs: 0 = k_corr4k.h, 1 = k_corr4d.h (the length-specialised build where
+// there is one, as the product picks), 2 = k_corr4d.h's run-time-length build, 3 / 4 = the same two
+// of k_corr4e.h (512 threads x 8 points; the template spectrum is in ITS position order: the mode
+// is read when a handle is created), 5 / 6 = the same two of k_corr4f.h (the next window in registers)
+static int g_corr_dma = 1;
+void emu_corr_set_dma(int mode) { g_corr_dma = mode; }
+
 void emu_corr_inith(const cf* taps_scaled, const cf* wtab, cf* Hpos, int F)
 {
     CorrInitParams p{ taps_scaled, wtab, Hpos };
     if (F == CF_F)
         run_grid(1, 1, CF_T, CF_LDS_BYTES, [&](EmuCtx& cx) { corr_inith_body(cx, p); });
+    else if (g_corr_dma >= 3)
+        run_grid(1, 1, CE_T, CE_LDS_BYTES, [&](EmuCtx& cx) { corr4e_inith_body(cx, p); });
     else
         run_grid(1, 1, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_inith_body(cx, p); });
 }
-
-// which F = 4096 build runs: 0 = k_corr4k.h, 1 = k_corr4d.h (the length-specialised build where
-// there is one, as the product picks), 2 = k_corr4d.h's run-time-length build
-static int g_corr_dma = 1;
-void emu_corr_set_dma(int mode) { g_corr_dma = mode; }
 
 void emu_corr_main(const CorrParams* p, int nchan, int F)
 {
@@ -271,6 +284,18 @@ void emu_corr_main(const CorrParams* p, int nchan, int F)
         run_grid(p->nseg, nchan, CF_T, C2_LDS_BYTES, [&](EmuCtx& cx) { corr2d_main_body<EmuCtx, 0>(cx, *p); });
     else if (g_corr_dma == 0)
         run_grid(p->nseg, nchan, CF4_T, CF4_LDS_BYTES, [&](EmuCtx& cx) { corr4_main_body(cx, *p); });
+    else if (g_corr_dma == 3 && p->N == 896)
+        run_grid(p->nseg, nchan, CE_T, CE_LDS_BYTES, [&](EmuCtx& cx) { corr4e_main_body<EmuCtx, 896>(cx, *p); });
+    else if (g_corr_dma == 3 && p->N == 1120)
+        run_grid(p->nseg, nchan, CE_T, CE_LDS_BYTES, [&](EmuCtx& cx) { corr4e_main_body<EmuCtx, 1120>(cx, *p); });
+    else if (g_corr_dma == 3 || g_corr_dma == 4)
+        run_grid(p->nseg, nchan, CE_T, CE_LDS_BYTES, [&](EmuCtx& cx) { corr4e_main_body<EmuCtx, 0>(cx, *p); });
+    else if (g_corr_dma == 5 && p->N == 896)
+        run_grid(p->nseg, nchan, CE_T, cfz_lds_bytes(p->N), [&](EmuCtx& cx) { corr4f_main_body<EmuCtx, 896>(cx, *p); });
+    else if (g_corr_dma == 5 && p->N == 1120)
+        run_grid(p->nseg, nchan, CE_T, cfz_lds_bytes(p->N), [&](EmuCtx& cx) { corr4f_main_body<EmuCtx, 1120>(cx, *p); });
+    else if (g_corr_dma >= 5)
+        run_grid(p->nseg, nchan, CE_T, cfz_lds_bytes(p->N), [&](EmuCtx& cx) { corr4f_main_body<EmuCtx, 0>(cx, *p); });
     else if (g_corr_dma == 1 && p->N == 896)
         run_grid(p->nseg, nchan, CF4_T, CD_LDS_BYTES, [&](EmuCtx& cx) { corr4d_main_body<EmuCtx, 896>(cx, *p); });
     else if (g_corr_dma == 1 && p->N == 1120)
@@ -824,6 +849,16 @@ void emu_freqest_work(void* hv, const cf* vecs, long vec_stride, float* out, lon
     p.vecs = vecs; p.vec_stride = vec_stride; p.out = out; p.out_stride = out_stride; p.nvec = nvec; p.fftlen = FS_F;
     p.offset = h->offset; p.binsize = h->binsize;
     run_grid(h->nchan, 1, 64, 0, [&](EmuCtx& cx) { fs_freqest_body(cx, p); });
+}
+// the block alone for any vector length (aisx_freqest_create_n: offset and bin size from the float rate)
+void emu_freqest_any(const cf* vecs, long vec_stride, float* out, long out_stride, int nvec, int nchan, int fftlen,
+                     float sample_rate, int data_rate)
+{
+    FsFreqestParams p;
+    p.vecs = vecs; p.vec_stride = vec_stride; p.out = out; p.out_stride = out_stride; p.nvec = nvec; p.fftlen = fftlen;
+    p.offset = (int)(fftlen * ((float)data_rate / sample_rate));
+    p.binsize = sample_rate / (float)fftlen;
+    run_grid(nchan, 1, 64, 0, [&](EmuCtx& cx) { fs_freqest_body(cx, p); });
 }
 #endif
 }

@@ -61,6 +61,7 @@ def lib():
         L.emu_fs_process.restype = i32
         L.emu_fs_process.argtypes = [vp, vp, lng, i32, vp, lng, vp, lng]
         L.emu_freqest_work.argtypes = [vp, vp, lng, vp, lng, i32]
+        L.emu_freqest_any.argtypes = [vp, lng, vp, lng, i32, i32, i32, f32, i32]
         L.emu_pfb_create.restype = vp
         L.emu_pfb_create.argtypes = [i32, vp, i32, i32]
         L.emu_pfb_destroy.argtypes = [vp]
@@ -233,3 +234,12 @@ def fs_agc_process(fs, agc, x):
     fh = np.zeros((fs.nchan, nv), dtype=np.float32)
     m = lib().emu_fs_agc_process(fs.h, agc.h, _p(x), n, n, _p(out), cap, _p(fh), nv)
     return out[:, :m].copy(), fh[:, : m // fs.fftlen].copy()
+
+
+def freqest_any(vecs, nchan, fftlen, sample_rate, data_rate):
+    """fs_freqest_body for any vector length (the estimator block alone, aisx_freqest_create_n)"""
+    v = np.ascontiguousarray(vecs, dtype=np.complex64).reshape(nchan, -1)
+    nvec = v.shape[1] // fftlen
+    out = np.zeros((nchan, max(nvec, 1)), np.float32)
+    lib().emu_freqest_any(_p(v), v.shape[1], _p(out), out.shape[1], nvec, nchan, fftlen, float(sample_rate), int(data_rate))
+    return out[:, :nvec]

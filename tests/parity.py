@@ -162,3 +162,27 @@ def compare_bursts(got_bits, want_bits, infos, slack=4):
             elif any(np.array_equal(got_bits[max(pos + d, 0):max(pos + d, 0) + pat.size], pat) for d in range(-slack, slack + 1)):
                 near += 1
     return ncmp, same, near
+
+
+def freqest_cases(rng, fftlen, sample_rate, data_rate, nchan=3, nvec=6):
+    """Spectra for freqest::work at any vector length: noise vectors with a planted peak pair `offset` bins apart, all-zero
+    vectors (the reference keeps the previous vector's maxpos: lib/freqest_impl.cc:68 vs :74), a tie between two pairs (the
+    first strict maximum wins), a peak in the last searched bin."""
+    offset = int(fftlen * (np.float32(data_rate) / np.float32(sample_rate)))
+    span = fftlen - offset
+    v = (rng.normal(size=(nchan, nvec, fftlen)) + 1j * rng.normal(size=(nchan, nvec, fftlen))).astype(np.complex64) * 0.05
+    for c in range(nchan):
+        for k in range(nvec):
+            if span > 0 and k % 3 != 2:
+                j = int(rng.integers(0, span))
+                v[c, k, j] += 4 + c
+                v[c, k, j + offset] += 3j
+    v[0, 1] = 0  # stale maxpos behind vector 0
+    v[1, 0] = 0  # a call that opens with silence: maxpos 0
+    if span > 2:
+        v[2, 3] = 0
+        v[2, 3, 1] = v[2, 3, 1 + offset] = 1  # a tie: bins 1 and span - 1
+        v[2, 3, span - 1] = v[2, 3, span - 1 + offset] = 1
+        v[2, 4] = 0
+        v[2, 4, span - 1] = 2
+    return v

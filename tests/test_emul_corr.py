@@ -102,11 +102,13 @@ def test_emul_corr_sps_rounding_and_mark_delay_clamp():
         assert_tags_match(tags[0], ot)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("N", [896, 1120, 640, 513, 2047, 2048])
 def test_emul_corr_f4096_builds(mode, N):
-    # the three F = 4096 builds -- k_corr4k.h (0), k_corr4d.h with the template length folded in
-    # where such a build exists (1) and with it at run time (2): several tiles per segment (the
+    # the F = 4096 builds -- k_corr4k.h (0), k_corr4d.h with the template length folded in
+    # where such a build exists (1) and with it at run time (2), k_corr4e.h (512 threads x 8 points,
+    # four radix-8 passes) likewise (3, 4), k_corr4f.h (the same with
+    # the next window in registers and one image) likewise (5, 6): several tiles per segment (the
     # window images alternate, the overlap is copied across, the next window arrives by "DMA"),
     # several segments, a ragged last tile, calls with carried history, a peak on a call edge
     emu.lib().emu_corr_set_dma(mode)

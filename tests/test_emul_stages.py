@@ -77,6 +77,19 @@ def test_emul_freqest_work_kat():
     assert out[1][0] == -9600.0
 
 
+@pytest.mark.parametrize("fftlen,sample_rate,data_rate", [(256, 38400.0, 9600), (1000, 48000.0, 9600), (2048, 50000.5, 9600),
+                                                          (2, 48000.0, 9600), (64, 9600.0, 9600), (1024, 38400.0, 9600)])
+def test_emul_freqest_any_vector_length(fftlen, sample_rate, data_rate):
+    # freqest::work needs no transform of its own: every fftlen >= 2, incl. offset >= fftlen (nothing to search: 0 stays)
+    from parity import freqest_cases
+
+    v = freqest_cases(np.random.default_rng(fftlen), fftlen, sample_rate, data_rate)
+    out = emu.freqest_any(v, v.shape[0], fftlen, sample_rate, data_rate)
+    fe = orc.FreqEst.make(sample_rate, data_rate, fftlen)
+    for c in range(v.shape[0]):
+        assert np.array_equal(out[c].view(np.uint32), fe.work(v[c]).view(np.uint32)), (fftlen, c)
+
+
 def test_emul_fused_front_end_is_freq_sync_then_agc():
     # aisx_freqsync_agc_process under the lane model: frequency estimates, the NCO phase walk on its
     # own (fs_walk_body) and the mixing inside the AGC's load stage (agc8_body) against the oracle's

@@ -67,38 +67,6 @@ def test_corr_dense_matches_oracle(ais, N):
         assert ndet >= 6
 
 
-@pytest.mark.parametrize("N", [20, 112, 512, 896, 1500])
-def test_corr_round1_builds_still_agree(ais, N, monkeypatch):
-    # AISX_CORR_DMA=0 selects round 1's correlators (k_corr_main, k_corr4_main: plain window loads,
-    # H and twiddles from L2) -- the A/B partners of k_corr2d_main / k_corr4d_main.  Same contract:
-    # the same input through both builds gives the same pass-through bits, the same tags to the
-    # tolerance of two FFT orderings, and both match the oracle.
-    rng = np.random.default_rng(300 + N)
-    tmpl = unit_template(rng, N)
-    lens = [9000, N // 2 + 1, 7000]
-    pos = [[700, 2900, 9000 - N // 2], [5, 12000], []]
-    x = planted(rng, 3, sum(lens), tmpl, pos)
-    monkeypatch.setenv("AISX_CORR_DMA", "0")
-    old = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=3, max_items=max(lens), max_tags_per_chan=512)
-    monkeypatch.setenv("AISX_CORR_DMA", "1")
-    new = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=3, max_items=max(lens), max_tags_per_chan=512)
-    ora = [orc.CorrEst(tmpl, 4.0, 1, 0.9) for _ in range(3)]
-    k = ndet = 0
-    for L in lens:
-        xd = _dev(x[:, k:k + L])
-        oo, _ = old.work(xd)
-        on, _ = new.work(xd)
-        assert np.array_equal(oo.cpu().numpy().view(np.uint32), on.cpu().numpy().view(np.uint32))
-        to, tn = _per_chan(old.tags(), 3), _per_chan(new.tags(), 3)
-        for c in range(3):
-            want_out, _, want_tags = ora[c].work(x[c, k:k + L])
-            assert np.array_equal(on[c].cpu().numpy(), want_out)
-            assert_tags_match(to[c], want_tags)
-            ndet += assert_tags_match(tn[c], want_tags)
-        k += L
-    assert ndet >= 4
-
-
 @pytest.mark.parametrize("N", [112, 896])
 def test_corr_sparse_streaming(ais, N):
     # port 1 not connected (sparse scratch + direct-form neighbours), successive
@@ -321,59 +289,6 @@ def test_msk_many_tags_per_call(ais):
         out, _, _, _ = o.step(xs[c], ot, want_aux=True)
         assert prod[c] == len(out)
         assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
-
-
-@pytest.mark.parametrize("lpw", [4, 8, 16, 32, 64])
-def test_msk_channels_per_wave_builds(ais, lpw, monkeypatch):
-    # the three builds of the timing-recovery kernel (16 / 32 / 64 channels per wave) give the
-    # same bits and symbols as the oracle; the library picks 16, AISX_MSK_LPW overrides it
-    import synth
-
-    monkeypatch.setenv("AISX_MSK_LPW", str(lpw))
-    rng = np.random.default_rng(40 + lpw)
-    nchan, lens = 70, [5000, 3000]
-    total = sum(lens)
-    xs = np.stack([synth.make_channel(800 + c, total, "P", 4, amp=1.0, cfo_max=50.0)[0] for c in range(nchan)])
-    blk = ais.msk_timing_recovery_cc(4.0, 0.04, 0.01, 1, nchan=nchan, max_items=max(lens))
-    cap = 32
-    tg_all = []
-    for c in range(nchan):
-        t = np.zeros(12, dtype=ais.TAG_DTYPE)
-        t["offset"] = np.sort(rng.choice(np.arange(10, total - 10), size=12, replace=False))
-        t["value"] = rng.uniform(-0.9, 0.9, 12)
-        t["key"] = 2
-        t["chan"] = c
-        tg_all.append(t)
-    o = [orc.MskStream(4.0, 0.04, 0.01, 1) for _ in range(nchan)]
-    import torch
-    k = 0
-    for L in lens:
-        tg = np.zeros((nchan, cap), dtype=ais.TAG_DTYPE)
-        cnt = np.zeros(nchan, np.int32)
-        sels = []
-        for c in range(nchan):
-            sel = tg_all[c][(tg_all[c]["offset"] >= k) & (tg_all[c]["offset"] < k + L)]
-            tg[c, : len(sel)] = sel
-            cnt[c] = len(sel)
-            sels.append(sel)
-        d_tags = torch.as_tensor(tg.view(np.uint8).reshape(nchan, -1).copy()).cuda()
-        d_cnt = torch.as_tensor(cnt).cuda()
-        r = blk.work(_dev(xs[:, k:k + L]), tags_ptrs=(d_tags.data_ptr(), d_cnt.data_ptr(), cap))
-        assert blk.last_status() == 0
-        prod = r["produced"].cpu().numpy()
-        syms = r["syms"].cpu().numpy()
-        for c in range(0, nchan, 3):
-            ot = np.zeros(len(sels[c]), dtype=orc.TAG_DTYPE)
-            ot["offset"], ot["value"], ot["key"] = sels[c]["offset"], sels[c]["value"], sels[c]["key"]
-            out, _, _, _ = o[c].step(xs[c, k:k + L], ot, want_aux=True)
-            assert prod[c] == len(out)
-            assert np.array_equal(syms[c, :prod[c]].view(np.uint32), out.view(np.uint32))
-        for c in range(nchan):  # keep the oracles of the channels not compared in step
-            if c % 3:
-                ot = np.zeros(len(sels[c]), dtype=orc.TAG_DTYPE)
-                ot["offset"], ot["value"], ot["key"] = sels[c]["offset"], sels[c]["value"], sels[c]["key"]
-                o[c].step(xs[c, k:k + L], ot, want_aux=True)
-        k += L
 
 
 @pytest.mark.parametrize("sps", [4.0, 3.0])

@@ -105,6 +105,36 @@ def test_freqest_work_kat(ais):
     assert np.array_equal(out[1], orc.FreqEst.make(38400.0, 9600, 1024).work(v[1]))
 
 
+@pytest.mark.parametrize("fftlen,sample_rate,data_rate", [(256, 38400.0, 9600), (1000, 48000.0, 9600), (2048, 50000.5, 9600),
+                                                          (2, 48000.0, 9600), (64, 9600.0, 9600)])
+def test_freqest_any_vector_length(ais, fftlen, sample_rate, data_rate):
+    # the estimator block for every fftlen (include/ais/freqest.h:49): batched rows and the nchan = 1 host path, the
+    # stale-maxpos rule (lib/freqest_impl.cc:68 vs :74), ties, offset >= fftlen; such a handle is refused by the freq_sync calls
+    from parity import freqest_cases
+
+    v = freqest_cases(np.random.default_rng(fftlen), fftlen, sample_rate, data_rate)
+    nchan = v.shape[0]
+    fe = ais.freqest(sample_rate, data_rate, fftlen, nchan=nchan)
+    out = fe.work(_dev(v.reshape(nchan, -1))).cpu().numpy()
+    o = orc.FreqEst.make(sample_rate, data_rate, fftlen)
+    one = ais.freqest(sample_rate, data_rate, fftlen)
+    for c in range(nchan):
+        want = o.work(v[c])
+        assert np.array_equal(out[c].view(np.uint32), want.view(np.uint32)), (fftlen, c)
+        assert np.array_equal(one.work_host(v[c]).view(np.uint32), want.view(np.uint32))
+    import ctypes as C
+
+    from ais_amd import _lib
+
+    L = _lib.lib()
+    assert L.aisx_freqsync_is_estimator_only(fe._h) == 1
+    buf = np.zeros(64, np.complex64)
+    rc = L.aisx_freqsync_work_host(one._h, buf.ctypes.data_as(C.c_void_p), 4, buf.ctypes.data_as(C.c_void_p), 64, None, 0)
+    assert rc == _lib.AISX_ERR_INVALID and b"aisx_freqest_create" in L.aisx_last_error()
+    with pytest.raises(ais.AisxError):  # (square_and_fft_sync_cc itself keeps its one vector length)
+        ais.square_and_fft_sync_cc(sample_rate, float(data_rate), fftlen, nchan=1, max_items=4 * fftlen)
+
+
 @pytest.mark.parametrize("family,nchan,T,steps", [("P", 24, 16384, 3), ("S", 24, 16384, 3)])
 def test_stock_chain_bits_identical(ais, family, nchan, T, steps):
     # freq_sync -> agc -> corr_est -> msk -> NRZI bits, the connect order of

@@ -184,8 +184,26 @@ int main(int argc, char** argv)
             mn = std::min(mn, ms[k]);
         }
         const double avg = nms ? s / nms : 0;
+        if (getenv("CORRBENCH_SERIES")) {
+            printf("series:");
+            for (int k = 0; k < nms; k++)
+                printf(" %.3f", ms[k]);
+            printf("\n");
+        }
         printf("%s: main kernel avg %.4f ms min %.4f (%d launches)  call wall %.4f ms  frac_of_8TB/s %.3f  tags(read rc %d) %d\n",
                paths[v], avg, mn, nms, wall / iters, avg > 0 ? 16.0 * nchan * T / (avg * 1e-3) / 8e12 : 0, rc, ntags[v]);
+        if (auto prof = (int (*)(unsigned long long*, int))dlsym(L.h, "aisx_debug_ce_prof")) {
+            unsigned long long v[16];
+            prof(v, 1);
+            const char* nm[8] = { "wait window", "barrier top", "load/store/next", "pass 1", "barrier 1", "passes 2-4,H,4-2", "barrier 2", "last pass+thresh" };
+            double tot = 0;
+            for (int i = 0; i < 8; i++)
+                tot += (double)v[i];
+            printf("section timers (wave-ticks of 10 ns, %llu wave-tiles):", v[8]);
+            for (int i = 0; i < 8; i++)
+                printf("  %s %.1f%% (%.0f ns/tile)", nm[i], 100.0 * v[i] / tot, 10.0 * v[i] / (double)v[8]);
+            printf("\n");
+        }
         L.destroy(h);
     }
     if (refp) {
