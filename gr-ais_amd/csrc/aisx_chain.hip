@@ -13,6 +13,7 @@ using namespace aisx;
 struct aisx_chain {
     aisx_freqsync* fs = nullptr; // borrowed; null = core chain (corr_est -> msk only)
     aisx_agc* agc = nullptr;     // borrowed
+    int agc_claim_prev = -1;     // the handle's LDS claim before this chain set its own (-1: the chain set none)
     aisx_corr* corr = nullptr;   // borrowed
     aisx_msk* msk = nullptr;     // borrowed
     int nchan = 0, max_items = 0, fftlen = 0;
@@ -47,8 +48,8 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
-    if (h->agc) // (the placement claim is the chain's: the handle goes back as it came)
-        (void)aisx_agc_set_lds_claim(h->agc, 0);
+    if (h->agc && h->agc_claim_prev >= 0) // (the placement claim is the chain's: the handle goes back as it came)
+        (void)aisx_agc_set_lds_claim(h->agc, h->agc_claim_prev);
     for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamSynchronize(s);
@@ -65,6 +66,31 @@ static void chain_free(aisx_chain* h)
         if (s)
             (void)hipStreamDestroy(s);
     delete h;
+}
+
+// The LDS a front-end (k_agcw) workgroup claims beyond the `used` bytes it needs: how many of them the dispatcher can put
+// on a CU beside a timing-recovery workgroup (msk_lds bytes each, msk_wgs of them, one per CU at most), from the part's
+// own figures (ncu CUs of lds_cu bytes).  The rule and the sweep it follows: DESIGN_APPENDIX.md A.6, tools/claim_sweep.py.
+//   * the recovery leaves at least half of the CUs free: none beside it (used + claim > what it leaves), two per free CU;
+//   * a recovery workgroup on (nearly) every CU: exactly one beside each -- 48 KB of the 70 KB left on this part.
+// Unknown figures (a query failed) or a part where the arithmetic does not work out: no claim.
+static int chain_front_claim(int ncu, int lds_cu, int msk_wgs, int msk_lds, int used)
+{
+    if (ncu <= 0 || lds_cu <= 0 || msk_wgs <= 0 || msk_lds <= 0 || used <= 0 || msk_lds >= lds_cu)
+        return 0;
+    const int left = lds_cu - msk_lds; // beside a recovery workgroup
+    const int kb = 1024;
+    if (2 * msk_wgs <= ncu) {
+        int claim = (left - used) / kb * kb + kb; // the first whole KB with used + claim > left
+        if (claim < 0)
+            claim = 0;
+        return 2 * (used + claim) <= lds_cu ? claim : 0;
+    }
+    // one beside each: used + claim <= left < 2 (used + claim); of that range, two thirds of what is left
+    int claim = (2 * left / 3) / kb * kb;
+    if (used + claim > left)
+        claim = (left - used) / kb * kb;
+    return (claim > 0 && 2 * (used + claim) > left) ? claim : 0;
 }
 
 extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* agc, aisx_corr* corr, aisx_msk* msk,
@@ -202,14 +228,20 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         // for them to finish (8192 channels: 10.9 against 9.5 ms per step).  There 48 KB -- ONE front-end
         // workgroup beside each recovery workgroup instead of three -- is what measures best (9.40-9.42 against
         // 9.47-9.60 ms, the correlator 2.56 instead of 3.4-3.6 ms).
-        int dev = 0, ncu = 0;
+        int dev = 0, ncu = 0, lds_cu = 0, msk_wgs = 0, msk_lds = 0, prev = 0, used = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             ncu = prop.multiProcessorCount;
-        const int msk_wgs = (nchan + 31) / 32;
-        int claim = (ncu > 0 && 2 * msk_wgs <= ncu) ? 72 * 1024 : 48 * 1024;
-        if (const char* e = exp_env("AISX_CHAIN_AGC_CLAIM"))
-            claim = atoi(e);
+            lds_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+        }
+        (void)aisx_msk_placement(msk, &msk_wgs, &msk_lds);
+        (void)aisx_agc_get_lds_claim(agc, &prev, &used);
+        int claim = chain_front_claim(ncu, lds_cu, msk_wgs, msk_lds, used);
+        if (const char* e = exp_env("AISX_CHAIN_AGC_CLAIM")) {
+            const int v = atoi(e);
+            claim = v < 0 ? 0 : (v > 144 * 1024 ? 144 * 1024 : v);
+        }
+        h->agc_claim_prev = prev;
         if ((rc = aisx_agc_set_lds_claim(agc, claim)) != AISX_OK) {
             chain_free(h);
             return rc;

@@ -151,6 +151,7 @@ static void (*corr4f_pick(int N))(CorrParams)
 {
     switch (N) {
     case 896: return k_corr4f_main<896>;
+    case 112: return k_corr4f_main<112>;
     case 1120: return k_corr4f_main<1120>;
     case 1024: return k_corr4f_main<1024>;
     case 1139: return k_corr4f_main<1139>;
@@ -289,6 +290,15 @@ extern "C" int aisx_util_copy_GBs(size_t bytes, int iters, float* GBs)
 // ---------------------------------------------------------------------------
 // corr_est_cc
 // ---------------------------------------------------------------------------
+// (experiments: AISX_CORR_F4=1 serves every template length with the F = 4096 build)
+static int corr_pick_fft_x(int nsym)
+{
+    if (const char* e = exp_env("AISX_CORR_F4"))
+        if (atoi(e) != 0)
+            return CF4_F;
+    return corr_pick_fft(nsym);
+}
+
 struct aisx_corr {
     int nchan = 0, N = 0, max_items = 0, tag_cap = 0, L = 0, isps = 0, out_multiple = 0;
     int F = CF_F; // FFT build serving this template length
@@ -377,7 +387,7 @@ extern "C" int aisx_corr_create(aisx_corr** out, const aisx_cf32* symbols, int n
     h->max_items = max_items;
     h->tag_cap = max_tags_per_chan;
     h->sps = sps;
-    h->F = corr_pick_fft(nsym);
+    h->F = corr_pick_fft_x(nsym);
     h->L = h->F - nsym;
     if (const char* e = exp_env("AISX_CORR_DMA")) // (experiments, and the tests of the other build)
         h->dma = atoi(e) != 0;
@@ -485,7 +495,7 @@ extern "C" int aisx_corr_set_symbols(aisx_corr* h, const aisx_cf32* symbols, int
         // Transactional: every new buffer is allocated and filled first; the handle changes only
         // once nothing can fail any more.
         const int Nold = h->N, keep = std::min(Nold, nsym);
-        const int F = corr_pick_fft(nsym);
+        const int F = corr_pick_fft_x(nsym);
         cf *nh[2] = { nullptr, nullptr }, *ntaps = nullptr, *npad = nullptr, *nH = nullptr, *nw = nullptr;
         auto undo = [&](int r) {
             dev_free(nh[0]);

@@ -1152,6 +1152,17 @@ extern "C" int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items)
     return AISX_OK;
 }
 
+extern "C" int aisx_msk_placement(const aisx_msk* h, int* workgroups, int* lds_bytes_per_workgroup)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (workgroups)
+        *workgroups = (h->nchan + msk_wg_channels(h->lpw) - 1) / msk_wg_channels(h->lpw);
+    if (lds_bytes_per_workgroup)
+        *lds_bytes_per_workgroup = msk_lds_bytes(h->lpw);
+    return AISX_OK;
+}
+
 // what the time-parallel path made of the last call (diagnostics; waits for `stream`)
 extern "C" int aisx_msk_set_profiling(aisx_msk* h, int on)
 {

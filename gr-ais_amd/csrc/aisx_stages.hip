@@ -557,6 +557,8 @@ struct aisx_agc {
     int cur = 0;
     bool tiles_only = false; // aisx_agc_set_streaming(h, 0): the tile kernels for every call
     int lds_claim = 0; // aisx_agc_set_lds_claim: LDS a streaming workgroup claims beyond the 8 KB it uses
+    int lds_attr = 64 * 1024; // dynamic LDS a k_agcw<true> launch of THIS handle may ask for (raised per handle: handles
+                              // may live on different devices, and the attribute is a per-device one)
     cf *d_hst_in = nullptr, *d_hst_out = nullptr; // aisx_agc_work_host's staging (grown, never shrunk)
     size_t hst_in_cap = 0, hst_out_cap = 0;
 };
@@ -617,8 +619,8 @@ extern "C" int aisx_agc_create(aisx_agc** out, int nsamples, float reference, in
 
 extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
 {
-    if (!h || !(floor_env > 0.f)) {
-        set_err("aisx_agc_set_floor: the floor must be positive");
+    if (!h || !(floor_env > 0.f) || !(floor_env <= 3.4028234663852886e38f)) { // (NaN and +inf fail the second test)
+        set_err("aisx_agc_set_floor: the floor must be positive and finite");
         return AISX_ERR_INVALID;
     }
     h->floor_env = floor_env;
@@ -632,6 +634,17 @@ extern "C" int aisx_agc_set_lds_claim(aisx_agc* h, int bytes)
         return AISX_ERR_INVALID;
     }
     h->lds_claim = bytes;
+    return AISX_OK;
+}
+
+extern "C" int aisx_agc_get_lds_claim(const aisx_agc* h, int* bytes, int* used_bytes)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (bytes)
+        *bytes = h->lds_claim;
+    if (used_bytes)
+        *used_bytes = AGW_LDS_BYTES;
     return AISX_OK;
 }
 
@@ -912,10 +925,9 @@ extern "C" int aisx_freqsync_agc_process(aisx_freqsync* h, aisx_agc* a, const ai
     static const int agcw_pad = exp_env("AISX_AGCW_LDS_PAD") ? atoi(exp_env("AISX_AGCW_LDS_PAD")) : -1; // (experiments: overrides the handle's claim)
     if (agcw_applies(p.W, total) && !a->tiles_only) {
         const int lds = AGW_LDS_BYTES + (agcw_pad >= 0 ? agcw_pad : a->lds_claim);
-        static int lds_limit = 64 * 1024; // (what a launch may ask for before the kernel's limit is raised)
-        if (lds > lds_limit) {
+        if (lds > a->lds_attr) { // (what a launch may ask for before the kernel's limit is raised)
             AISX_HIPCHK(hipFuncSetAttribute((const void*)k_agcw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            lds_limit = lds;
+            a->lds_attr = lds;
         }
         hipLaunchKernelGGL(k_agcw<true>, dim3(agcw_grid(total), h->nchan), dim3(AGW_T), lds, st, p);
     }

@@ -173,7 +173,7 @@ AISX_DI void agcw_body(Ctx& cx, const AgcParams& p)
     const float* dv = MIXED ? p.dvec + (long)c * p.dvec_stride : nullptr;
     const int floor_i = f2i(p.floor_env);
     // (wave-uniform) the reciprocal form of the gain serves this call: reference and floor in its range
-    const bool fast_ref = agcw_fast_reference(p.reference) && p.floor_env >= AGW_RCP_LO;
+    const bool fast_ref = agcw_fast_reference(p.reference) && p.floor_env >= AGW_RCP_LO && p.floor_env <= AGW_RCP_HI;
     const int rcp_hi_i = f2i(AGW_RCP_HI);
 
     // what a block's lane loads: its 8 raw items (history: already mixed), the NCO checkpoint that

@@ -150,6 +150,9 @@ typedef struct aisx_msk aisx_msk;
 int aisx_msk_create(aisx_msk** h, float sps, float gain, float limit, int osps, int nchan, int max_items);
 int aisx_msk_destroy(aisx_msk* h);
 int aisx_msk_geometry(const aisx_msk* h, int* nchan, int* max_items); /* what aisx_msk_create was given */
+/* what the recovery kernel's launch occupies: its workgroups (one per CU at most: each takes more than half of a CU's LDS)
+ * and the LDS of one -- aisx_chain_create places the front-end kernel's workgroups by these.  Not part of the GNU Radio API. */
+int aisx_msk_placement(const aisx_msk* h, int* workgroups, int* lds_bytes_per_workgroup);
 int aisx_msk_set_gain(aisx_msk* h, float gain); /* :80-84, AISX_ERR_OUT_OF_RANGE if gain <= 0 */
 float aisx_msk_get_gain(const aisx_msk* h);     /* :86-88 */
 int aisx_msk_set_limit(aisx_msk* h, float limit); /* :90-92 */
@@ -353,6 +356,8 @@ int aisx_agc_set_streaming(aisx_agc* h, int on);
  * workgroup beside each recovery workgroup: 8192 channels 9.40-9.42 against 9.47-9.60 ms); default 0.
  * Results do not depend on it.  Environment AISX_AGCW_LDS_PAD overrides (experiments). */
 int aisx_agc_set_lds_claim(aisx_agc* h, int bytes);
+/* the claim in force, and the LDS a streaming workgroup uses itself (either pointer may be NULL) */
+int aisx_agc_get_lds_claim(const aisx_agc* h, int* bytes, int* used_bytes);
 int aisx_agc_process(aisx_agc* h, const aisx_cf32* d_in, long in_stride, aisx_cf32* d_out, long out_stride, int n,
                      void* stream);
 /* square_and_fft_sync_cc -> feedforward_agc_cc, the first two blocks of python/ais_demod.py:56, in

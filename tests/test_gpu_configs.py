@@ -10,11 +10,15 @@
 Oracle comparison on a subset of channels (the CPU oracle runs ~2.4 MS/s on the stock chain),
 size-independent properties on all of them.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle_py as orc
 from parity import assert_tags_match, compare_bursts, compare_detections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -188,7 +192,21 @@ def _stock_chain_against_oracle(ais, nchan, K, steps, seed0):
     # last place, ~3e-7, and the loop then free-runs on noise until the next tag) moves every later
     # burst of that channel by one position -- with the tags equal the symbols ARE bit-exact (above).
     # (round 2, 4096 x 2 steps: 453 of 453 in place; round 3, 8192 x 3 steps: 280 of 300, 300 of 300 within +-4)
-    assert ncmp > 8 * K * steps and near >= ncmp - tot["lone"] and same >= 0.8 * ncmp
+    # (round 5: 93-100 % in place at every shape run; round 6 gate 0.9)
+    assert ncmp > 8 * K * steps and near >= ncmp - tot["lone"] and same >= 0.9 * ncmp
+    # PDU level, as the application sees it (python/radio.py:64-73: hdlc_deframer_bp(11, 64) behind the demodulator): every
+    # frame the oracle's chain recovers with a good CRC the GPU's bit stream recovers too; what the GPU recovers beyond
+    # those is bounded by the detections only one side saw, and every frame it recovers was transmitted
+    npdu = nwant = 0
+    for c in range(K):
+        want = orc.Hdlc(11, 64).work(np.concatenate(obits[c]))
+        have = ais.hdlc_deframer_bp(11, 64).work(np.concatenate(gbits[c]))
+        sent = [np.packbits(np.array(i["payload"], np.uint8), bitorder="little").tobytes() for i in made[c][1]]
+        assert set(want) <= set(have), (c, len(want), len(have))
+        assert set(have) <= set(sent), c
+        npdu, nwant = npdu + len(have), nwant + len(want)
+    print("  PDUs with a good CRC: oracle %d, GPU %d on %d channels" % (nwant, npdu, K))
+    assert nwant > 4 * K * steps and npdu - nwant <= tot["lone"]
     return dem, x_dev, res
 
 
@@ -440,3 +458,23 @@ def test_freqest_work_host_gnuradio_path(ais):
     assert np.array_equal(fe.work_host(r), orc.FreqEst.make(38400.0, 9600, 1024).work(r))
     with pytest.raises(ValueError):
         ais.freqest(38400.0, 9600, 1024, nchan=2).work_host(v)
+
+
+@pytest.mark.parametrize("nchan", [2048, 4096, 8192])
+def test_chain_front_end_claim_is_near_the_best_of_a_sweep(ais, nchan):
+    # aisx_chain_create places the front-end kernel's workgroups by an LDS claim it derives from the part's CU count / LDS size
+    # and the recovery kernel's launch (aisx_chain.hip: chain_front_claim; DESIGN_APPENDIX.md A.6 holds the full sweep of
+    # tools/claim_sweep.py).  The gate: a step with the chain's own choice takes at most 2 % longer than the best of
+    # {no claim, 24, 48, 63 KB} set by hand on the same chain object, medians of three interleaved runs of 20 steps;
+    # a claim never changes a result (test_config3 / test_config4 run with it, their twins without).
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("claim_sweep", os.path.join(ROOT, "tools", "claim_sweep.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    r = cs.sweep(nchan, [0, 24, 48, 63], steps=20, reps=3)
+    print("claim sweep at %d channels: chosen %d B -> %.3f ms per step; by hand %s" % (
+        nchan, r["chosen_claim_bytes"], r["ms_per_step"]["chosen"], {k: v for k, v in r["ms_per_step"].items() if k != "chosen"}))
+    assert r["chosen_claim_bytes"] > 0
+    assert r["ms_per_step"]["chosen"] <= 1.02 * r["best_of_sweep_ms"], r["ms_per_step"]
+    assert r["ms_per_step"]["chosen"] <= 1.005 * r["ms_per_step"]["0"], r["ms_per_step"]  # never slower than no claim
