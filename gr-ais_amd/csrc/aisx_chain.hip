@@ -220,21 +220,24 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
             chain_free(h);
             return rc;
         }
-    if (!h->serial && agc) {
-        // The front-end kernel's workgroups stay off the CUs that hold a recovery workgroup (aisx_agc_set_lds_claim):
-        // 8 KB used + 72 KB claimed is more than the 71 680 B the recovery leaves, and two of them fit a free CU.
-        // Only while the recovery leaves half of the chip free (one workgroup of 32 channels per CU: up to 4096
-        // channels on 256 CUs): with a recovery workgroup on every CU that claim would make the front end wait
-        // for them to finish (8192 channels: 10.9 against 9.5 ms per step).  There 48 KB -- ONE front-end
-        // workgroup beside each recovery workgroup instead of three -- is what measures best (9.40-9.42 against
-        // 9.47-9.60 ms, the correlator 2.56 instead of 3.4-3.6 ms).
-        int dev = 0, ncu = 0, lds_cu = 0, msk_wgs = 0, msk_lds = 0, prev = 0, used = 0;
+    // What the part offers and what the recovery kernel's launch takes of it: the two placement decisions below follow.
+    int ncu = 0, lds_cu = 0, msk_wgs = 0, msk_lds = 0;
+    {
+        int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             ncu = prop.multiProcessorCount;
             lds_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
         }
         (void)aisx_msk_placement(msk, &msk_wgs, &msk_lds);
+    }
+    if (!h->serial && agc) {
+        // The front-end kernel's workgroups are placed by an LDS claim (aisx_agc_set_lds_claim, chain_front_claim above):
+        // while the recovery leaves half of the chip free (up to 4096 channels on 256 CUs) they stay off the CUs that
+        // hold a recovery workgroup and two of them fit a free CU; with a recovery workgroup on (nearly) every CU ONE
+        // sits beside each (the sweep: DESIGN_APPENDIX.md A.6 -- a claim too large there makes the front end wait for
+        // the recovery to finish: 10.6 against 9.2 ms per step at 8192 channels).
+        int prev = 0, used = 0;
         (void)aisx_agc_get_lds_claim(agc, &prev, &used);
         int claim = chain_front_claim(ncu, lds_cu, msk_wgs, msk_lds, used);
         if (const char* e = exp_env("AISX_CHAIN_AGC_CLAIM")) {

@@ -187,10 +187,11 @@ static void (*corr2d_pick(int N))(CorrParams)
     }
 }
 
-__global__ __launch_bounds__(64) void k_corr_resolve(ResolveParams p)
+__global__ __launch_bounds__(64 * RSV_WAVES) void k_corr_resolve(ResolveParams p)
 {
-    __shared__ __attribute__((aligned(16))) float atab[260]; // fast_atan2f's 257-entry table
-    DevCtx cx{ (char*)atab };
+    // fast_atan2f's 257-entry table, the regions' detection counts, the waves' detections (k_corr.h: rsv_lds_bytes)
+    extern __shared__ __attribute__((aligned(16))) char rsv[];
+    DevCtx cx{ rsv };
     corr_resolve_body(cx, p);
 }
 
@@ -709,7 +710,10 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
     r.tag_cap = h->tag_cap;
     r.tag_count = h->d_tag_count;
     r.atan_tab = h->d_atan;
-    hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64), 0, st, r);
+    {
+        const int nwv = rsv_waves_for(h->nchan);
+        hipLaunchKernelGGL(k_corr_resolve, dim3(h->nchan), dim3(64 * nwv), rsv_lds_bytes(nwv), st, r);
+    }
     AISX_HIPCHK(hipGetLastError());
     h->hist_cur ^= 1;
     h->corr_hist_zero = 0;

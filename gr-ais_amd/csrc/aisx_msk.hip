@@ -1169,9 +1169,24 @@ extern "C" int aisx_msk_set_profiling(aisx_msk* h, int on)
     if (!h)
         return AISX_ERR_INVALID;
     if (on && !h->pev0[0]) {
+        // all events or none: created into temporaries, committed to the handle once every one exists
+        hipEvent_t e0[aisx_msk::NEV] = {}, e1[aisx_msk::NEV] = {};
+        bool ok = true;
+        for (int k = 0; k < aisx_msk::NEV && ok; k++)
+            ok = hipEventCreate(&e0[k]) == hipSuccess && hipEventCreate(&e1[k]) == hipSuccess;
+        if (!ok) {
+            for (int k = 0; k < aisx_msk::NEV; k++) {
+                if (e0[k])
+                    (void)hipEventDestroy(e0[k]);
+                if (e1[k])
+                    (void)hipEventDestroy(e1[k]);
+            }
+            set_err("aisx_msk_set_profiling: hipEventCreate failed");
+            return AISX_ERR_HIP;
+        }
         for (int k = 0; k < aisx_msk::NEV; k++) {
-            AISX_HIPCHK(hipEventCreate(&h->pev0[k]));
-            AISX_HIPCHK(hipEventCreate(&h->pev1[k]));
+            h->pev0[k] = e0[k];
+            h->pev1[k] = e1[k];
         }
     }
     h->prof = on ? 1 : 0;
@@ -1293,12 +1308,14 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
     // the interpolator reads up to in[ninput_items] (one past): stage one spare item
     const int nin = ninput_items + 1;
     if (nin > h->st_in_cap) {
+        h->st_in_cap = 0; // (until the new buffer exists: a failed allocation leaves no stale capacity behind)
         dev_free(h->d_st_in);
         if ((rc = dev_alloc(&h->d_st_in, nin)) != AISX_OK)
             return rc;
         h->st_in_cap = nin;
     }
     if (noutput_items > h->st_out_cap) {
+        h->st_out_cap = 0;
         dev_free(h->d_st_blk);
         h->d_st_blk = nullptr;
         h->d_st_sym = nullptr;
@@ -1314,6 +1331,7 @@ extern "C" int aisx_msk_general_work_host(aisx_msk* h, int noutput_items, int ni
         h->st_host.resize((size_t)noutput_items + 2);
     }
     if (ntags + 1 > h->st_tag_cap) {
+        h->st_tag_cap = 0;
         dev_free(h->d_st_tags);
         dev_free(h->d_st_tagn);
         if ((rc = dev_alloc(&h->d_st_tags, ntags + 1)) != AISX_OK || (rc = dev_alloc(&h->d_st_tagn, 1)) != AISX_OK)

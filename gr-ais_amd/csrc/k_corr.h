@@ -313,7 +313,7 @@ AISX_DI void corr_main_body(Ctx& cx, const CorrParams& p)
 }
 
 // ---------------------------------------------------------------------------
-// A5: peak search and tag emission, one wave per channel.
+// A5: peak search and tag emission, one workgroup per channel.
 // ---------------------------------------------------------------------------
 struct ResolveParams {
     const unsigned long long* abits; long abits_stride;
@@ -338,7 +338,7 @@ AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk,
     // accumulation) for the below-threshold neighbours k = pk - 1 / pk + 1 of a peak; only
     // feeds the 3-point centre of mass.  Both neighbours in one pass over the taps (one
     // memory round trip, not two).
-    const int lane = cx.tid();
+    const int lane = cx.tid() & 63;
     const cf* xin = p.in + (long)c * p.in_stride;
     const cf* hist = p.hist_in + (long)c * p.N;
     double ar0 = 0.0, ai0 = 0.0, ar2 = 0.0, ai2 = 0.0;
@@ -390,24 +390,18 @@ AISX_DI void resolve_direct_mag2(Ctx& cx, const ResolveParams& p, int c, int pk,
     }
 }
 
-template <class Ctx>
-AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
+// The greedy scan of lib/corr_est_cc_impl.cc:197-270 over the hit bitmask words [base0, base1) of channel c (base0 a
+// multiple of 64), starting at item i0: first hit at or behind i, climb to the local maximum, centre of mass, phase,
+// emit(pk, mag^2, phase, centre) -- wave-uniform arguments --, on at pk + isps.  One wave; `lane` is the lane in it.
+template <class Ctx, class Emit>
+AISX_DI void resolve_scan(Ctx& cx, const ResolveParams& p, int c, const float* atab, int base0, int base1, int i0, Emit&& emit)
 {
-    const int lane = cx.tid();
-    const int c = cx.bx();
+    const int lane = cx.tid() & 63;
     const unsigned long long* A = p.abits + (long)c * p.abits_stride;
     const cf* corr = p.corr + (long)c * p.corr_stride;
-    tag_rec* tags = p.tags + (long)c * p.tag_cap;
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
-    // fast_atan2f's table next to the wave (a detection is a chain of dependent memory round
-    // trips; this one becomes an LDS read)
-    float* atab = (float*)cx.lds();
-    for (int k = lane; k < 257; k += 64)
-        atab[k] = p.atan_tab[k];
-    cx.sync();
-    int ntag = 0;
-    int i = 0;
+    int i = i0;
     // the window in hand: items wq0 .. wq0 + 63 (lane j: value, mag^2), the lanes whose value is in
     // hand, the lanes from which the climb steps on
     bool win = false;
@@ -415,7 +409,7 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
     cf wcv = mk(0.f, 0.f);
     float wmg = 0.f;
     unsigned long long wHV = 0ull, wC = 0ull;
-    for (int base = 0; base < nwords; base += 64) {
+    for (int base = base0; base < base1; base += 64) {
         if ((long)(base + 64) * 64 <= (long)i)
             continue;
         const int wi = base + lane;
@@ -516,29 +510,157 @@ AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
                 center = nom / den - 2.0;
             }
             const float phase = fast_atan2f_tab(cp.im, cp.re, atab); // :247
-            if (lane == 0) {
-                const unsigned long long o0 = p.written + (unsigned long long)pk;
-                const unsigned long long o1 = o0 + p.mark_delay;
-                if (ntag + 4 <= p.tag_cap) {
-                    tags[ntag + 0] = tag_rec{ o0, (double)mp, KEY_CORR_START, c };
-                    tags[ntag + 1] = tag_rec{ o1, (double)phase, KEY_PHASE_EST, c };
-                    tags[ntag + 2] = tag_rec{ o1, center, KEY_TIME_EST, c };
-                    tags[ntag + 3] = tag_rec{ o1, (double)mp, KEY_CORR_EST, c };
-                }
-                if (p.emit_port1 && ntag + 7 <= p.tag_cap) {
-                    tags[ntag + 4] = tag_rec{ o0, (double)phase, KEY_PHASE_EST | 0x100, c };
-                    tags[ntag + 5] = tag_rec{ o0, center, KEY_TIME_EST | 0x100, c };
-                    tags[ntag + 6] = tag_rec{ o0, (double)mp, KEY_CORR_EST | 0x100, c };
-                }
-            }
-            ntag += p.emit_port1 ? 7 : 4;
+            emit(pk, mp, phase, center);
             i = pk + p.isps; // :270
             if ((long)i >= (long)(base + 64) * 64)
                 break;
         }
     }
-    if (lane == 0)
-        p.tag_count[c] = ntag;
+}
+
+// tags of one detection, the d-th of its channel (:247-262): written while they fit, counted always
+AISX_DI void resolve_write_tags(const ResolveParams& p, tag_rec* tags, int c, int d, int pk, float mp, float phase, double center)
+{
+    const int per = p.emit_port1 ? 7 : 4;
+    const int ntag = d * per;
+    const unsigned long long o0 = p.written + (unsigned long long)pk;
+    const unsigned long long o1 = o0 + p.mark_delay;
+    if (ntag + 4 <= p.tag_cap) {
+        tags[ntag + 0] = tag_rec{ o0, (double)mp, KEY_CORR_START, c };
+        tags[ntag + 1] = tag_rec{ o1, (double)phase, KEY_PHASE_EST, c };
+        tags[ntag + 2] = tag_rec{ o1, center, KEY_TIME_EST, c };
+        tags[ntag + 3] = tag_rec{ o1, (double)mp, KEY_CORR_EST, c };
+    }
+    if (p.emit_port1 && ntag + 7 <= p.tag_cap) {
+        tags[ntag + 4] = tag_rec{ o0, (double)phase, KEY_PHASE_EST | 0x100, c };
+        tags[ntag + 5] = tag_rec{ o0, center, KEY_TIME_EST | 0x100, c };
+        tags[ntag + 6] = tag_rec{ o0, (double)mp, KEY_CORR_EST | 0x100, c };
+    }
+}
+
+// One workgroup of RSV_WAVES waves per channel (round 6; one wave per channel before: 0.36 / 0.58 ms per call at 4096 /
+// 8192 channels, a chain of dependent memory round trips per detection, ~55 detections one after the other).
+// The scan is sequential only through its cursor (i = pk + isps behind a detection), and the cursor cannot carry anything
+// across a gap: if the isps items in front of item s hold no hit, no climb reaches s (a climb walks over hits only) and
+// every detection in front of s leaves the cursor at or below s -- the scan from s on is the scan that starts at s.
+// So the bitmask is cut into blocks of 64 words (4096 items); a block whose start is such a gap ("clean": the last
+// isps bits of the word in front of it are zero; block 0 always) opens a REGION that runs to the next clean block,
+// and the regions of a channel are scanned by different waves at the same time.  Detections wait in LDS; behind a
+// barrier each wave knows how many detections precede its regions and writes its tags where the sequential scan
+// would have put them.  More detections in one wave than its share of the LDS holds, more than RSV_MAXB blocks, isps > 64: the
+// workgroup's first wave runs the sequential scan instead (same tags).
+#ifndef RSV_WAVES_MAX
+#define RSV_WAVES_MAX 16
+#endif
+constexpr int RSV_WAVES = RSV_WAVES_MAX;
+constexpr int RSV_DET_WAVE = 128; // detections a wave can hold in LDS (64 with sixteen waves: 24 KB per workgroup at most)
+AISX_HD int rsv_det_cap(int nwv) { return nwv >= 16 ? 64 : RSV_DET_WAVE; }
+constexpr int RSV_MAXB = 256;
+constexpr int RSV_ATAB_BYTES = 1056; // 257 floats, padded to 32 bytes
+struct rsv_det {
+    double center;
+    int pk;
+    float mp, phase;
+    int pad;
+};
+// LDS of a workgroup of nwv waves (one wave: the sequential scan, nothing but the table)
+AISX_HD int rsv_lds_bytes(int nwv) { return RSV_ATAB_BYTES + (nwv > 1 ? (RSV_MAXB + 8) * 4 + nwv * rsv_det_cap(nwv) * (int)sizeof(rsv_det) : 16); }
+// Waves per channel for a launch over nchan channels: what fills the chip's wave slots (8192 on 256 CUs), no more --
+// with a wave on every slot already (8192 channels) more waves per channel only add idle ones (measured: 0.99 against
+// 0.58 ms per call with sixteen), with few channels the scan's chain of round trips is cut sixteen-fold.
+AISX_HD int rsv_waves_for(int nchan)
+{
+    int w = RSV_WAVES;
+    while (w > 1 && (long)w * nchan > 8192)
+        w >>= 1;
+    return w;
+}
+
+template <class Ctx>
+AISX_DI void corr_resolve_body(Ctx& cx, const ResolveParams& p)
+{
+    const int tid = cx.tid(), lane = tid & 63, wv = tid >> 6, nwv = cx.nthreads() >> 6;
+    const int c = cx.bx();
+    const unsigned long long* A = p.abits + (long)c * p.abits_stride;
+    tag_rec* tags = p.tags + (long)c * p.tag_cap;
+    const int nwords = (p.n + 63) >> 6;
+    const int nblk = (nwords + 63) >> 6;
+    // fast_atan2f's table next to the waves (a detection is a chain of dependent memory round
+    // trips; this one becomes an LDS read)
+    float* atab = (float*)cx.lds();
+    int* cnt = (int*)(cx.lds() + RSV_ATAB_BYTES); // detections per region, by the block that opens it
+    int* ovf = cnt + RSV_MAXB;
+    const int det_cap = rsv_det_cap(nwv);
+    rsv_det* det = (rsv_det*)(cx.lds() + RSV_ATAB_BYTES + (RSV_MAXB + 8) * 4) + wv * det_cap;
+    const bool par = nwv > 1 && nblk > 1 && nblk <= RSV_MAXB && p.isps >= 1 && p.isps <= 64;
+    for (int k = tid; k < 257; k += cx.nthreads())
+        atab[k] = p.atan_tab[k];
+    if (nwv > 1)
+        for (int k = tid; k < RSV_MAXB + 8; k += cx.nthreads())
+            cnt[k] = 0;
+    cx.sync();
+    auto clean = [&](int b) { // (wave-uniform)
+        if (b == 0)
+            return true;
+        return (A[64 * b - 1] >> (64 - p.isps)) == 0ull;
+    };
+    int mine = 0; // detections this wave holds
+    if (par) {
+        for (int b = wv; b < nblk; b += nwv) {
+            if (!clean(b))
+                continue;
+            int e = b + 1;
+            while (e < nblk && !clean(e))
+                e++;
+            int here = 0;
+            resolve_scan(cx, p, c, atab, 64 * b, e < nblk ? 64 * e : nwords, 4096 * b, [&](int pk, float mp, float phase, double center) {
+                if (lane == 0 && mine < det_cap)
+                    det[mine] = rsv_det{ center, pk, mp, phase, 0 };
+                mine++;
+                here++;
+            });
+            if (lane == 0) {
+                cnt[b] = here;
+                if (mine > det_cap)
+                    *ovf = 1;
+            }
+        }
+    }
+    cx.sync();
+    if (!par || (nwv > 1 && *ovf != 0)) {
+        if (wv == 0) {
+            int nd = 0;
+            resolve_scan(cx, p, c, atab, 0, nwords, 0, [&](int pk, float mp, float phase, double center) {
+                if (lane == 0)
+                    resolve_write_tags(p, tags, c, nd, pk, mp, phase, center);
+                nd++;
+            });
+            if (lane == 0)
+                p.tag_count[c] = nd * (p.emit_port1 ? 7 : 4);
+        }
+        return;
+    }
+    // detections in front of each of this wave's regions: the counts of all earlier blocks
+    int beg = 0;
+    for (int b = wv; b < nblk; b += nwv) {
+        const int here = cnt[b];
+        if (here == 0)
+            continue;
+        int before = 0;
+        for (int k = 0; k < b; k++)
+            before += cnt[k];
+        for (int k = lane; k < here; k += 64) {
+            const rsv_det d = det[beg + k];
+            resolve_write_tags(p, tags, c, before + k, d.pk, d.mp, d.phase, d.center);
+        }
+        beg += here;
+    }
+    if (tid == 0) {
+        int total = 0;
+        for (int k = 0; k < nblk; k++)
+            total += cnt[k];
+        p.tag_count[c] = total * (p.emit_port1 ? 7 : 4);
+    }
 }
 
 } // namespace aisx

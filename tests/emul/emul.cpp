@@ -306,7 +306,10 @@ void emu_corr_main(const CorrParams* p, int nchan, int F)
 
 void emu_corr_resolve(const ResolveParams* p, int nchan)
 {
-    run_grid(nchan, 1, 64, 260 * 4, [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
+    // (the lane model takes sixteen waves whatever the channel count, or what EMU_RSV_WAVES says: the region logic is what it is there to test)
+    const char* e = getenv("EMU_RSV_WAVES");
+    const int nwv = e ? atoi(e) : RSV_WAVES;
+    run_grid(nchan, 1, 64 * nwv, rsv_lds_bytes(nwv), [&](EmuCtx& cx) { corr_resolve_body(cx, *p); });
 }
 
 #ifdef MSK_EMU_STATS

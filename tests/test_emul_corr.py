@@ -178,3 +178,46 @@ def test_emul_corr_f2048_builds(mode, N):
             assert ndet >= 6 or N == 1
     finally:
         emu.lib().emu_corr_set_dma(1)
+
+
+@pytest.mark.parametrize("sps", [4.0, 9.6, 1.0])
+def test_emul_corr_resolver_regions_at_block_boundaries(sps):
+    # The resolver cuts a channel's hit bitmask into blocks of 4096 items and scans "regions" on different waves
+    # (k_corr.h: corr_resolve_body).  Peaks planted so that the hit runs end just before, straddle, or start right
+    # at multiples of 4096 -- clean and dirty block starts, a region of several blocks -- against the oracle's
+    # sequential scan; a low threshold widens the runs around every peak.
+    rng = np.random.default_rng(int(sps * 10))
+    N = 20
+    tmpl = unit_template(rng, N)
+    n = 3 * 4096 + 700
+    offs = list(range(-9, 7))
+    pos = [[4096 - N + 1 + d, 8192 - N + 1 - d, 12288 - N + 1 + d // 2, 300 + 3 * d] for d in offs]
+    x = planted(rng, len(offs), n, tmpl, pos, noise=0.02)
+    e = emu.CorrEst(tmpl, sps, 1, 0.35, nchan=len(offs))
+    _, _, tags, cnt, _ = e.work(x, want_corr=False)
+    ndet = 0
+    for c in range(len(offs)):
+        o = orc.CorrEst(tmpl, sps, 1, 0.35)
+        _, _, ot = o.work(x[c], want_corr=False)
+        assert_tags_match(tags[c], ot)
+        ndet += len(ot) // 4
+    assert ndet >= 4 * len(offs)
+
+
+def test_emul_corr_resolver_flood_falls_back_to_one_wave():
+    # more detections in a wave's regions than it can hold in LDS (rsv_det_cap: 64 with sixteen waves): the workgroup's first wave runs the
+    # sequential scan; one quiet channel beside it takes the parallel path in the same launch
+    rng = np.random.default_rng(77)
+    N = 20
+    tmpl = unit_template(rng, N)
+    n = 2 * 4096 + 100
+    x = (rng.normal(size=(2, n)) + 1j * rng.normal(size=(2, n))).astype(np.complex64)
+    x[1] *= 1e-3
+    x[1, 5000:5000 + N] += tmpl
+    e = emu.CorrEst(tmpl, 4.0, 3, 1e-4, nchan=2)
+    _, _, tags, cnt, _ = e.work(x, want_corr=False, tag_cap=4 * n)
+    for c in range(2):
+        o = orc.CorrEst(tmpl, 4.0, 3, 1e-4)
+        _, _, ot = o.work(x[c], want_corr=False)
+        assert_tags_match(tags[c], ot)
+    assert len(tags[0]) > 4 * 1000 and 4 <= len(tags[1])

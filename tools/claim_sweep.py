@@ -51,8 +51,10 @@ def sweep(nchan, claims_kb, steps, reps, T=65536, sps=4):
     bench.spin_up(torch, device)
     res = {}
     order = [("chosen", chosen.value)] + [("%d" % k, k * 1024) for k in claims_kb]
-    for _ in range(reps):
-        for name, claim in order:
+    _lib.check(L.aisx_agc_set_lds_claim(dem.agc._h, chosen.value), "set_lds_claim")
+    run()  # (untimed: clocks, caches)
+    for r in range(reps):
+        for name, claim in order[r % len(order):] + order[:r % len(order)]:  # (a different first one every time round)
             _lib.check(L.aisx_agc_set_lds_claim(dem.agc._h, claim), "set_lds_claim")
             res.setdefault(name, []).append(run())
     _lib.check(L.aisx_agc_set_lds_claim(dem.agc._h, chosen.value), "set_lds_claim")
