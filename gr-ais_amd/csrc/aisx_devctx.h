@@ -266,6 +266,9 @@ struct DevCtx {
 #ifndef AISX_STORE_AUX
 #define AISX_STORE_AUX 2
 #endif
+#ifndef AISX_LOAD_AUX // buf_load64 (k_corr4f.h's window loads): the same bits
+#define AISX_LOAD_AUX AISX_STORE_AUX
+#endif
     __device__ __forceinline__ void dma16(const Buf& b, unsigned byte_off, unsigned lds_dst) const
     {
         v4i w;
@@ -297,7 +300,7 @@ struct DevCtx {
     __device__ __forceinline__ cf buf_load64(const Buf& b, unsigned voff, unsigned soff) const
     {
         const v2u d = __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)b.base, 0, (int)b.nbytes, 0x00020000),
-                                                           (int)voff, (int)soff, AISX_STORE_AUX);
+                                                           (int)voff, (int)soff, AISX_LOAD_AUX);
         return mk(__uint_as_float(d.x), __uint_as_float(d.y));
     }
     // one complex item to buffer byte offset voff + soff; range-checked on voff only (the scalar

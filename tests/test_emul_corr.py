@@ -204,20 +204,23 @@ def test_emul_corr_resolver_regions_at_block_boundaries(sps):
     assert ndet >= 4 * len(offs)
 
 
-def test_emul_corr_resolver_flood_falls_back_to_one_wave():
+def test_emul_corr_resolver_flood_falls_back_to_one_wave(monkeypatch):
     # more detections in a wave's regions than it can hold in LDS (rsv_det_cap: 64 with sixteen waves): the workgroup's first wave runs the
     # sequential scan; one quiet channel beside it takes the parallel path in the same launch
+    monkeypatch.setenv("EMU_RSV_WAVES", "4")  # (four waves: 128 detections each; sixteen lane-model waves take a minute)
     rng = np.random.default_rng(77)
     N = 20
     tmpl = unit_template(rng, N)
-    n = 2 * 4096 + 100
+    n = 4096 + 1200
     x = (rng.normal(size=(2, n)) + 1j * rng.normal(size=(2, n))).astype(np.complex64)
+    x[0, 700:] *= 1e-3  # (the flood fills the head of block 0: ~170 detections in one wave's region)
+    x[0, 4500:4500 + N] += tmpl
     x[1] *= 1e-3
-    x[1, 5000:5000 + N] += tmpl
+    x[1, 4500:4500 + N] += tmpl
     e = emu.CorrEst(tmpl, 4.0, 3, 1e-4, nchan=2)
     _, _, tags, cnt, _ = e.work(x, want_corr=False, tag_cap=4 * n)
     for c in range(2):
         o = orc.CorrEst(tmpl, 4.0, 3, 1e-4)
         _, _, ot = o.work(x[c], want_corr=False)
         assert_tags_match(tags[c], ot)
-    assert len(tags[0]) > 4 * 1000 and 4 <= len(tags[1])
+    assert len(tags[0]) > 4 * 100 and 4 <= len(tags[1])

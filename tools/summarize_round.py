@@ -71,7 +71,7 @@ print("\n".join(md[-12:]))
 
 
 # ---- the correlator builds alone
-def corr_summary(table_json, prefix, N, tiles_per_chan, waves_per_wg, lds_bytes, out_name, notes):
+def corr_summary(table_json, prefix, N, tiles_per_chan, waves_per_wg, lds_bytes, out_name, notes, vgprs=256):
     t = json.load(open(table_json))
     name = [k for k in t if k.startswith(prefix)][0]
     c = t[name]
@@ -93,7 +93,7 @@ def corr_summary(table_json, prefix, N, tiles_per_chan, waves_per_wg, lds_bytes,
         "hbm_bytes_per_launch": hbm,
         "algorithmic_bytes_per_launch": alg,
         "traffic_over_algorithmic": hbm / alg,
-        "occupancy": {"waves_per_launch": W, "tiles_per_wave": tiles_per_wave, "VGPRs_per_lane": 256,
+        "occupancy": {"waves_per_launch": W, "tiles_per_wave": tiles_per_wave, "VGPRs_per_lane": vgprs,
                       "LDS_bytes_per_workgroup": lds_bytes, "waves_per_workgroup": waves_per_wg},
         "per_wave_and_tile": {"VALU": per("SQ_INSTS_VALU"), "SALU": per("SQ_INSTS_SALU"), "LDS": per("SQ_INSTS_LDS"),
                               "VMEM_RD": per("SQ_INSTS_VMEM_RD"), "VMEM_WR": per("SQ_INSTS_VMEM_WR"), "BRANCH": per("SQ_INSTS_BRANCH")},
@@ -111,15 +111,18 @@ def corr_summary(table_json, prefix, N, tiles_per_chan, waves_per_wg, lds_bytes,
 
 L896 = 4096 - 896  # outputs per tile of the F = 4096 build
 L112 = 2048 - 112
-corr_summary(os.path.join(src, "corr896_pmc_table.json"), "k_corr4d_main", 896, -(-65536 // L896), 4, 71680,
+corr_summary(os.path.join(src, "corr896_pmc_table.json"), "k_corr4f_main", 896, -(-65536 // L896), 8, 55232,
              "%s_corr_main_pmc.json" % tag,
-             "round 4: the LDS-DMA window loads and the pass-through stores carry the nt (streaming) policy bit -- read once, "
-             "written once; corr_only 0.445 -> 0.460 of 8 TB/s at 4096 channels on one box (nt on the loads alone or sc1 / sc0 "
-             "variants: within noise or worse, DESIGN_APPENDIX.md).  SQ cycle counters are quad-cycles per wave.")
+             "round 6: k_corr4f_main (k_corr4f.h) -- 512 threads x 8 points (8 x 8 x 8 x 8), 120 VGPRs, 55 232 B of LDS: two workgroups "
+             "of eight waves per CU = four waves per SIMD (round 5's k_corr4d_main: 256 VGPRs, 71 680 B, two waves per SIMD); the next "
+             "window's new items fetched into registers (raw buffer loads, nt), one window image + a double-buffered overlap buffer, "
+             "two barriers per tile.  Alone on the chip the kernel runs the package into its 1400 W limit (%s_corr_energy.json): its "
+             "time follows the shader clock the firmware leaves it.  SQ cycle counters are quad-cycles per wave." % tag, vgprs=120)
 corr_summary(os.path.join(src, "corr112_pmc_table.json"), "k_corr2d_main", 112, -(-65536 // L112), 2, 35840,
              "%s_corr2d_main_pmc.json" % tag,
              "round 4: nt policy as in the F = 4096 build; the per-thread output mask is rebuilt where a hit needs it instead of "
-             "living across the tile loop -- the N = 112 build no longer spills (255 VGPRs, no scratch).")
+             "living across the tile loop -- the N = 112 build no longer spills (255 VGPRs, no scratch).  Round 6: built without the "
+             "SI load / store optimiser (no ds_read2 merging), otherwise unchanged.")
 
 # ---- chain traffic
 ker = {}
@@ -136,10 +139,10 @@ for k, v in ker.items():
         continue
     rows[k] = {"launches": len(v.get("fetch", [])), "fetch_GB": statistics.median(v.get("fetch", [0.0])) * 2 * 1024 / 1e9,
                "write_GB": statistics.median(v.get("write", [0.0])) * 1024 / 1e9}
-stream = [k for k in rows if k.startswith(("k_fs_est", "k_fs_walk", "k_agc8", "k_agcw", "k_corr4d_main", "k_corr_resolve"))]
+stream = [k for k in rows if k.startswith(("k_fs_est", "k_fs_walk", "k_agc8", "k_agcw", "k_corr4d_main", "k_corr4f_main", "k_corr_resolve"))]
 prev = None
 try:
-    prev = json.load(open("profiles/r04_chain_traffic.json"))
+    prev = json.load(open("profiles/r05_chain_traffic.json"))
 except OSError:
     pass
 chain = {
@@ -152,11 +155,10 @@ chain = {
     "kernels": rows,
     "streaming_side_GB_per_step": sum(rows[k]["fetch_GB"] + rows[k]["write_GB"] for k in stream),
     "whole_step_GB": sum(v["fetch_GB"] + v["write_GB"] for v in rows.values()),
-    "round_4": None if prev is None else {"streaming_side_GB_per_step": prev["streaming_side_GB_per_step"], "whole_step_GB": prev["whole_step_GB"]},
-    "notes": "round 5: the front-end pass is the streaming kernel k_agcw (k_agcw.h) -- the same bytes as the tile kernel it replaced "
-             "(input 8 B + checkpoints 0.5 B read, 8 B written per sample; a run of sixteen 512-item blocks re-reads one block: 6 %) in "
-             "1.2-1.3 ms instead of 2.3.  What is left to remove is unchanged: the AGC folded into the correlator's window load (-4.3 GB), "
-             "the delayed pass-through as a view (-2.15 GB, measured in round 4: no gain) -- DESIGN.md.",
+    "round_5": None if prev is None else {"streaming_side_GB_per_step": prev["streaming_side_GB_per_step"], "whole_step_GB": prev["whole_step_GB"]},
+    "notes": "round 6: the same passes and the same bytes as round 5 (the correlator build changed, not what it moves).  What could still "
+             "be removed is unchanged: the AGC folded into the correlator's window load (-4.3 GB), the delayed pass-through as a view "
+             "(-2.15 GB, measured in round 4: no gain) -- DESIGN.md says why neither was built.",
 }
 json.dump(chain, open("profiles/%s_chain_traffic.json" % tag, "w"), indent=1)
 print("streaming side %.2f GB, whole step %.2f GB" % (chain["streaming_side_GB_per_step"], chain["whole_step_GB"]))
@@ -216,6 +218,8 @@ if tp:
 try:
     fr = {}
     for name, path in (("k_agcw", "agcw_pmc_table.json"), ("k_fs_est", "est_pmc_table.json"), ("k_agc8", "agc8_pmc_table.json")):
+        if not os.path.exists(os.path.join(src, path)):
+            continue
         t = json.load(open(os.path.join(src, path)))
         for k, c in t.items():
             if not k.startswith(name):
@@ -249,3 +253,66 @@ try:
     json.dump(hc, open("profiles/%s_hbm_ceilings.json" % tag, "w"), indent=1)
 except (OSError, ValueError) as e:
     print("hbm ceilings skipped:", e)
+
+
+# ---- round 6: config 4's per-GPU shape under the kernel trace
+try:
+    c4 = bench_line(os.path.join(src, "c4_profiled.log"))
+    cands = glob.glob(os.path.join(src, "c4stats", "*", "*kernel_trace.csv"))
+    tr = max(cands, key=lambda f: open(f).read().count("k_msk<"))
+    st4 = {k: v for k, v in sp.timed_stats(tr, c4["steps"], c4["warmup"]).items() if not k.startswith(("k_mskp", "k_msk_ff"))}
+    md = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --parity-channels 0 --single-chain --config4 --steps 30", "",
+          "BASELINE config 4's per-GPU shape (8192 channels x 65536 samples per step) on one MI355X.  bench.py's line of this (profiled) "
+          "run: %.0f complex MS/s, %.2f ms/step, correlator %.3f ms in the chain." % (c4["value"], c4["ms_per_step"], c4["roofline"]["kernel_ms"]), "",
+          "| kernel | timed launches | avg ms | min ms | max ms |", "|---|---|---|---|---|"]
+    for k, v in sorted(st4.items(), key=lambda kv: -kv[1]["avg"]):
+        md.append("| %s | %d | %.3f | %.3f | %.3f |" % (k[:48], v["n"], v["avg"], v["mn"], v["mx"]))
+    md += ["", "The sample passes (k_fs_est -> k_agcw -> k_corr4f_main -> k_corr_resolve, one behind the other on one stream) add up to the "
+           "step; the recovery (k_msk) and the phase walk (k_fs_walk) run beside them on their own streams (DESIGN.md 5)."]
+    open("profiles/%s_config4_kernel_stats.md" % tag, "w").write("\n".join(md) + "\n")
+    print("\n".join(md[-14:]))
+except (OSError, KeyError, ValueError, TypeError) as e:
+    print("config 4 summary skipped:", e)
+
+# ---- round 6: the correlator's energy split
+try:
+    ce = json.load(open(os.path.join(src, "energy", "corr_energy.json")))
+    idle_w = (ce.get("idle") or {}).get("package_W_mean")
+    rows_e = []
+    for b in ce["builds"]:
+        pw = b.get("power") or {}
+        w, ms = pw.get("package_W_mean"), b.get("kernel_ms")
+        rows_e.append({"build": b["build"], "kernel_ms": ms, "package_W": w, "sclk_MHz": pw.get("sclk_MHz_mean"),
+                       "joule_per_launch": None if (w is None or ms is None) else w * ms * 1e-3})
+    what = {"f": "the product kernel", "fdbg8": "no threshold test / hit path", "fdbg9": "no hit path, no pass-through stores",
+            "fdbg10": "no hit path, no window loads (stores kept)", "fdbg11": "compute only (no loads, no stores, no hit path)",
+            "fdbg88": "memory only (loads, stores, overlap buffer; no transform passes)"}
+    for r in rows_e:
+        r["what"] = what.get(r["build"])
+    doc = {"what": "k_corr4f_main<896> alone (tools/native/corrbench, 4096 channels x 65536 samples, 3000 launches back to back): kernel "
+                   "time (the library's hipEvents), package power and shader clock (hwmon of the process's GPU, 20 ms samples) of the product "
+                   "build and of CE_DBG builds that leave parts of the tile loop out (timing / power only: their results are wrong)",
+           "command": "python tools/corr_energy.py <dir>  (variants: tools/mkvariant.sh fdbgN aisx_lib -DCE_DBG=N)",
+           "package_limit_W": 1400, "sclk_ceiling_MHz": 2400, "idle_package_W": idle_w, "builds": rows_e,
+           "reading": "with everything on the package sits at its limit and the firmware takes the shader clock down (2.0-2.15 GHz of 2.4); "
+                      "compute only and memory only each stay below the limit at the full clock.  Energy per launch of the full kernel ~= "
+                      "energy(memory only) + energy(compute only) - idle power x the time saved by overlapping: the kernel is bound by the "
+                      "package power, not by HBM bandwidth, LDS or issue -- a faster build has to spend fewer joules per sample (DESIGN.md 4.1)"}
+    json.dump(doc, open("profiles/%s_corr_energy.json" % tag, "w"), indent=1)
+    for r in rows_e:
+        print("energy:", r)
+except (OSError, KeyError, ValueError, TypeError) as e:
+    print("correlator energy summary skipped:", e)
+
+# ---- round 6: the front-end claim sweep
+try:
+    sw = [json.loads(ln) for ln in open(os.path.join(src, "claim_sweep.jsonl")) if ln.startswith("{")]
+    doc = {"what": "ms per pipelined step of the stock chain against the LDS claim of the front-end kernel (aisx_agc_set_lds_claim), by "
+                   "channel count: the chain's own choice (aisx_chain.hip: chain_front_claim) and every claim of the sweep set by hand on "
+                   "the same chain object, medians of three interleaved runs of 20 steps",
+           "command": "python tools/claim_sweep.py --claims 0,16,24,32,40,48,56,63,72 --steps 20 --reps 3", "rows": sw}
+    json.dump(doc, open("profiles/%s_claim_sweep.json" % tag, "w"), indent=1)
+    for r in sw:
+        print("claim sweep:", r["nchan"], r["chosen_claim_bytes"], r["chosen_over_best"])
+except (OSError, KeyError, ValueError, TypeError) as e:
+    print("claim sweep summary skipped:", e)
