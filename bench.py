@@ -133,6 +133,33 @@ def pmc_traffic(nchan, T, N):
     return None, None
 
 
+def energy_split():
+    """The committed energy split of the F = 4096 correlator alone (profiles/rNN_corr_energy.json, tools/corr_energy.py:
+    time x package power of the product build, a compute-only and a memory-only build), newest round first; None if absent."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_corr_energy.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            b = {r["build"]: r for r in d["builds"]}
+            f, c, m = b["f"], b["fdbg11"], b["fdbg88"]
+            lim = float(d.get("package_limit_W", 1400))
+            return {"source": "profiles/%s (static: measured by tools/corr_energy.py, not in this run)" % os.path.basename(path),
+                    "package_limit_W": lim,
+                    "joule_per_launch": {"product": f["joule_per_launch"], "compute_only": c["joule_per_launch"],
+                                         "memory_only": m["joule_per_launch"]},
+                    "ms": {"product": f["kernel_ms"], "compute_only": c["kernel_ms"], "memory_only": m["kernel_ms"]},
+                    "package_W": {"product": f["package_W"], "compute_only": c["package_W"], "memory_only": m["package_W"]},
+                    "sclk_MHz": {"product": f["sclk_MHz"], "compute_only": c["sclk_MHz"], "memory_only": m["sclk_MHz"]},
+                    "ms_at_the_limit": (c["joule_per_launch"] + m["joule_per_launch"]) / lim * 1e3,
+                    "reading": "joules(product) ~= joules(compute only) + joules(memory only): at the package limit a launch can not "
+                               "take less than that sum / limit (ms_at_the_limit) -- the kernel alone is bound by package power, not by "
+                               "HBM bandwidth; frac 0.60 of 8 TB/s (0.895 ms) needs about a third fewer joules in the transform (DESIGN.md 4.1)"}
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    return None
+
+
 MSK_BYTES_PER_SAMPLE = 10.25  # 8 read + 8 / sps symbol + 1 / sps bit written, sps = 4 (DESIGN.md 4.3)
 
 
@@ -862,6 +889,7 @@ def main():
                                   "the package limit is 1400 W, the clock's ceiling 2400 MHz: the correlator alone sits at the "
                                   "limit and its time follows the clock (DESIGN.md 4.1)"},
                 "frac_alone": CORR_BYTES_PER_SAMPLE * float(nchan) * T / (float(np.mean(iso)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "energy_split_alone": energy_split() if tmpl.size > 512 else None,
                 "note": "kernel_ms is measured over the timed region, where the timing-recovery kernel of the "
                         "previous step shares the chip; *_alone = same launch with nothing else running; copy_ceiling_GBs = "
                         "read + write rate of a plain float4 copy of 2 GiB on this box (hipEvents, no profiler)",
