@@ -129,6 +129,53 @@ struct DevCtx {
             hi = mk(__uint_as_float(ra[1]), __uint_as_float(rb[1]));
         }
     }
+    // Transpose of eight complex registers against lane bits 3 .. 5: x[j] of lane (h, e) <- x[h] of lane (j, e), h / j = bits
+    // 5:3 of the lane, e = bits 2:0.  Three stages of pairwise half exchanges: lane bit 5 against register bit 2 by
+    // v_permlane32_swap (lanes 32-63 of the first operand with lanes 0-31 of the second), lane bit 4 against register bit 1
+    // by v_permlane16_swap (odd rows of 16 with even rows), lane bit 3 against register bit 0 by two DPP moves per dword
+    // (row_ror:8 = the other half of the row, written under a bank mask): 32 VALU instructions for what an exchange through
+    // LDS does with 8 ds_write_b64 + 8 ds_read_b64 and a wait.
+    __device__ __forceinline__ void xpose8_lane_hi(cf (&x)[8]) const
+    {
+        unsigned u[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u[2 * k] = __float_as_uint(x[k].re);
+            u[2 * k + 1] = __float_as_uint(x[k].im);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const auto q = __builtin_amdgcn_permlane32_swap(u[2 * r + d], u[2 * (r + 4) + d], false, false);
+                u[2 * r + d] = q[0];
+                u[2 * (r + 4) + d] = q[1];
+            }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int r = (rr & 1) | ((rr & 2) << 1); // 0, 1, 4, 5
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const auto q = __builtin_amdgcn_permlane16_swap(u[2 * r + d], u[2 * (r + 2) + d], false, false);
+                u[2 * r + d] = q[0];
+                u[2 * (r + 2) + d] = q[1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 2)
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const int a = (int)u[2 * r + d], b = (int)u[2 * (r + 1) + d];
+                // lanes 0-7 of each row: b <- a of lane + 8; lanes 8-15: a <- b of lane - 8
+                const int nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);
+                const int na = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false);
+                u[2 * r + d] = (unsigned)na;
+                u[2 * (r + 1) + d] = (unsigned)nb;
+            }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            x[k] = mk(__uint_as_float(u[2 * k]), __uint_as_float(u[2 * k + 1]));
+    }
     // v of lane - 1 / lane + 1, 0 at the ends of the wave: one DPP move each (wave_shr:1 / wave_shl:1)
     __device__ __forceinline__ unsigned lane_prev_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
     __device__ __forceinline__ unsigned lane_next_u32(unsigned v) const { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }

@@ -49,6 +49,11 @@ constexpr int CE_IMG = 8 * CE_ROW;   // complex slots per window image
 #ifndef CE_W3_REGS
 #define CE_W3_REGS 0
 #endif
+// the exchange between the second and the third pass (register index against lane bits 3 .. 5 of ONE wave): 1 = in
+// registers (Ctx::xpose8_lane_hi: permlane swaps + DPP moves), 0 = through the window image in LDS
+#ifndef CE_XP2
+#define CE_XP2 0
+#endif
 // first / last pass twiddles W_4096^{k t}, k = 1 .. 7: 1 = all seven in registers (14 VGPRs),
 // 0 = the powers 1, 2, 4 (6 VGPRs) and four more products per pass
 #ifndef CE_W1_REGS
@@ -211,6 +216,9 @@ struct Ce {
 #pragma unroll
         for (int b = 1; b < 8; b++)
             x[b] = cx.cmul(x[b], tw2(b));
+#if CE_XP2
+        cx.xpose8_lane_hi(x); // (k2 in the registers, n3 in lane bits 3 .. 5) -> (n3 in the registers, k2 in the lane)
+#else
 #pragma unroll
         for (int b = 0; b < 8; b++)
             st8(A + c_p2[b & 3] + b * CE_BLK, x[b]);
@@ -219,6 +227,7 @@ struct Ce {
         for (int g = 0; g < 8; g++)
             x[g] = ld8(A + c_p3[g >> 1] + g * 8);
         cx.wave_sync();
+#endif
         dft8<false>(cx, x);
 #pragma unroll
         for (int g = 1; g < 8; g++)
@@ -248,6 +257,12 @@ struct Ce {
         }
         cx.wave_sync();
         dft8<true>(cx, x);
+#if CE_XP2
+        cx.xpose8_lane_hi(x);
+#pragma unroll
+        for (int b = 1; b < 8; b++)
+            x[b] = cx.cmul_conj(x[b], tw2(b));
+#else
 #pragma unroll
         for (int g = 0; g < 8; g++)
             st8(A + c_p3[g >> 1] + g * 8, x[g]);
@@ -258,6 +273,7 @@ struct Ce {
             x[b] = (b == 0) ? a : cx.cmul_conj(a, tw2(b));
         }
         cx.wave_sync();
+#endif
         dft8<true>(cx, x);
 #pragma unroll
         for (int b = 0; b < 8; b++)

@@ -167,6 +167,27 @@ struct EmuCtx {
     cf lds_cf(const float* tab, unsigned idx) const { return ld8(reinterpret_cast<const cf*>(tab) + idx); }
     unsigned lane_prev_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l > 0 ? l - 1 : l); return l > 0 ? r : 0u; }
     unsigned lane_next_u32(unsigned v) const { const int l = tid_ & 63; const unsigned r = xchg(v, l < 63 ? l + 1 : l); return l < 63 ? r : 0u; }
+    // (aisx_devctx.h: xpose8_lane_hi) x[j] of lane (h, e) <- x[h] of lane (j, e)
+    void xpose8_lane_hi(cf (&x)[8]) const
+    {
+        const int l = tid_ & 63, h = (l >> 3) & 7, e = l & 7;
+        cf y[8];
+        for (int j = 0; j < 8; j++) {
+            // every lane offers, for this round, the register the asking lanes (j' = h of the source) want: lane (j, e) is
+            // asked by lane (h, e) for its x[h]; in round j the source lane of lane (h, e) is (j, e), and that lane must
+            // publish x[h of the asker] -- askers of one source all differ in h, so publish one register per round r and
+            // let lane (h, e) pick in round r = h from source (j, e): run the 8 x 8 rounds
+            y[j] = mk(0.f, 0.f);
+        }
+        for (int r = 0; r < 8; r++)     // register published this round
+            for (int j = 0; j < 8; j++) { // source lane's high bits
+                const float re = xchg(x[r].re, (j << 3) | e), im = xchg(x[r].im, (j << 3) | e);
+                if (r == h)
+                    y[j] = mk(re, im);
+            }
+        for (int j = 0; j < 8; j++)
+            x[j] = y[j];
+    }
     unsigned long long shfl_u64(unsigned long long v, int src) const { return xchg(v, src); }
     float shfl_f32(float v, int src) const { return xchg(v, src); }
     int shfl_i32(int v, int src) const { return xchg(v, src); }
