@@ -102,8 +102,9 @@ def test_emul_corr_sps_rounding_and_mark_delay_clamp():
         assert_tags_match(tags[0], ot)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize("N", [896, 1120, 640, 513, 2047, 2048])
+# (the product's builds, 5 and 6, at every length; their predecessors -- the experiments build's twins -- at three)
+@pytest.mark.parametrize("mode,N", [(m, n) for m in (5, 6) for n in (896, 1120, 640, 513, 2047, 2048)] +
+                         [(m, n) for m in (0, 1, 2, 3, 4) for n in (896, 513, 2047)])
 def test_emul_corr_f4096_builds(mode, N):
     # the F = 4096 builds -- k_corr4k.h (0), k_corr4d.h with the template length folded in
     # where such a build exists (1) and with it at run time (2), k_corr4e.h (512 threads x 8 points,
