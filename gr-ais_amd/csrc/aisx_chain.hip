@@ -70,9 +70,14 @@ static void chain_free(aisx_chain* h)
 
 // The LDS a front-end (k_agcw) workgroup claims beyond the `used` bytes it needs: how many of them the dispatcher can put
 // on a CU beside a timing-recovery workgroup (msk_lds bytes each, msk_wgs of them, one per CU at most), from the part's
-// own figures (ncu CUs of lds_cu bytes).  The rule and the sweep it follows: DESIGN_APPENDIX.md A.6, tools/claim_sweep.py.
-//   * the recovery leaves at least half of the CUs free: none beside it (used + claim > what it leaves), two per free CU;
-//   * a recovery workgroup on (nearly) every CU: exactly one beside each -- 48 KB of the 70 KB left on this part.
+// own figures (ncu CUs of lds_cu bytes).  The rule and the sweeps it follows: DESIGN.md 4.8, DESIGN_APPENDIX.md A.6,
+// tools/claim_sweep.py, profiles/r06_claim_sweep.json.
+//   * the recovery leaves at least half of the CUs free: none beside it (used + claim > what it leaves), two per free CU
+//     (63 KB on this part: -4 ... -11 % per step against no claim at 2048 ... 4096 channels);
+//   * a recovery workgroup on more than half of the CUs, all of them resident at once: a third of what the recovery
+//     leaves (23 KB: two beside each; 6144 / 8192 channels -1 ... -2 %, where 63 KB costs +15 %);
+//   * more recovery workgroups than CUs (they come in rounds): two thirds of it (46 KB: one beside each; 12 288 / 16 384
+//     channels -3 ... -8 %).
 // Unknown figures (a query failed) or a part where the arithmetic does not work out: no claim.
 static int chain_front_claim(int ncu, int lds_cu, int msk_wgs, int msk_lds, int used)
 {
@@ -86,11 +91,10 @@ static int chain_front_claim(int ncu, int lds_cu, int msk_wgs, int msk_lds, int 
             claim = 0;
         return 2 * (used + claim) <= lds_cu ? claim : 0;
     }
-    // one beside each: used + claim <= left < 2 (used + claim); of that range, two thirds of what is left
-    int claim = (2 * left / 3) / kb * kb;
+    int claim = ((msk_wgs <= ncu ? 1 : 2) * left / 3) / kb * kb;
     if (used + claim > left)
         claim = (left - used) / kb * kb;
-    return (claim > 0 && 2 * (used + claim) > left) ? claim : 0;
+    return claim > 0 ? claim : 0;
 }
 
 extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* agc, aisx_corr* corr, aisx_msk* msk,
