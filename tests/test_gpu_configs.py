@@ -477,4 +477,4 @@ def test_chain_front_end_claim_is_near_the_best_of_a_sweep(ais, nchan):
         nchan, r["chosen_claim_bytes"], r["ms_per_step"]["chosen"], {k: v for k, v in r["ms_per_step"].items() if k != "chosen"}))
     assert r["chosen_claim_bytes"] > 0
     assert r["ms_per_step"]["chosen"] <= 1.02 * r["best_of_sweep_ms"], r["ms_per_step"]
-    assert r["ms_per_step"]["chosen"] <= 1.005 * r["ms_per_step"]["0"], r["ms_per_step"]  # never slower than no claim
+    assert r["ms_per_step"]["chosen"] <= 1.01 * r["ms_per_step"]["0"], r["ms_per_step"]  # never slower than no claim (1 % of scatter)
