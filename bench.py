@@ -654,7 +654,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(chain, want_parity, lookahead=True, msk_tp=False, msk_Q=0, nch=None):
+    def measure(chain, want_parity, lookahead=True, msk_tp=False, msk_Q=0, nch=None, corr_claim=0):
         """K timed steps of `chain` on this rank's channel shard; returns the wall time (max over
         ranks), the correlator kernel's per-launch times inside the timed region and (rank 0) the
         parity gates of the last step.  The step is the product's pipelined chain
@@ -675,6 +675,8 @@ def main():
                                 preamble_symbols=tmpl, fused_front_end=True)
         corr = dem.preamble_detect
         corr.set_profiling(True)
+        if corr_claim:
+            corr.set_lds_claim(corr_claim)
         if chain != "corr":
             if msk_Q:
                 dem.clockrec.set_max_noutput_items(msk_Q)
@@ -816,6 +818,9 @@ def main():
     # the caveats of the headline as numbers: the same steps without the one-buffer look-ahead (x_next = None: every
     # step estimates for itself), and with the time-parallel timing recovery (opt-in, include/aisx.h)
     nola = measure("stock", False, lookahead=False) if (args.chain == "stock" and side and world == 1) else None
+    # the placement choice the chain leaves to its caller: the correlator kept off the CUs that hold a recovery workgroup
+    # (aisx_corr_set_lds_claim: a shorter step for a slower graded kernel, include/aisx.h)
+    coff = measure("stock", False, corr_claim=17408) if (args.chain == "stock" and side and world == 1 and nchan <= 4096) else None
     tpm = measure(args.chain, True, msk_tp=True, msk_Q=256) if (args.chain != "corr" and side and world == 1) else None
     tpq = measure(args.chain, False, msk_tp=False, msk_Q=256) if (args.chain != "corr" and side and world == 1) else None
     corr_only = None
@@ -955,6 +960,15 @@ def main():
             line["no_lookahead_corr_kernel_ms"] = float(np.mean(nola["kern_ms"]))
             if nola.get("msk_ms"):
                 line["no_lookahead_msk_kernel_ms"] = float(np.mean(nola["msk_ms"]))
+        if coff is not None:
+            line["corr_off_recovery_cus"] = {
+                "what": "the same steps with aisx_corr_set_lds_claim(17408): no correlator workgroup fits beside a recovery workgroup "
+                        "(the recovery runs less disturbed, the correlator on half of the CUs); not the default",
+                "ms_per_step": coff["el"] / args.steps * 1e3, "value": nchan * world * float(T) * args.steps / coff["el"] / 1e6,
+                "corr_kernel_ms": float(np.mean(coff["kern_ms"])),
+                "msk_kernel_ms": float(np.mean(coff["msk_ms"])) if coff.get("msk_ms") else None,
+                "msk_status": int(coff["st"]),
+            }
         if tpm is not None:
             line["msk_time_parallel"] = {
                 "what": "the same steps with aisx_msk_set_time_parallel(64 restart points, serial kernel as join, units <= 16384 items) "
@@ -973,7 +987,8 @@ def main():
         # the side measurements once more under keys the driver's record keeps whole (it stores `config`, `roofline` and
         # `cpu_baseline` in full and only the NAMES of other top-level keys)
         sidek = {k: line[k] for k in ("config4_per_gpu", "corr_est_to_msk_only", "no_lookahead_ms_per_step", "no_lookahead_corr_kernel_ms",
-                                       "no_lookahead_msk_kernel_ms", "config5_wideband", "config1_host_path", "h2d") if k in line}
+                                       "no_lookahead_msk_kernel_ms", "config5_wideband", "config1_host_path", "h2d",
+                                       "corr_off_recovery_cus") if k in line}
         if "msk_time_parallel" in line:
             sidek["msk_time_parallel"] = {k: line["msk_time_parallel"][k] for k in ("ms_per_step", "ms_per_step_serial_kernel_same_max_noutput_items")}
         if sidek:

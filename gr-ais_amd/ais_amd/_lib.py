@@ -96,6 +96,7 @@ def lib(device=True):
     sig("aisx_corr_nitems_written", u64, [vp])
     sig("aisx_corr_reset", i32, [vp])
     sig("aisx_corr_process", i32, [vp, vp, lng, vp, lng, vp, lng, i32, vp])
+    sig("aisx_corr_set_lds_claim", i32, [vp, i32])
     sig("aisx_corr_set_profiling", i32, [vp, i32])
     sig("aisx_corr_last_kernel_ms", i32, [vp, C.POINTER(C.c_float)])
     sig("aisx_corr_kernel_ms_history", i32, [vp, C.POINTER(C.c_float), i32, pi32])

@@ -69,6 +69,10 @@ class corr_est_cc:
         check(_lib.lib().aisx_corr_set_symbols(self._h, s.ctypes.data_as(C.c_void_p), s.size), "set_symbols")
         self._N = s.size
 
+    def set_lds_claim(self, nbytes):
+        """placement knob of the F = 4096 build (include/aisx.h: aisx_corr_set_lds_claim); results do not depend on it"""
+        check(_lib.lib().aisx_corr_set_lds_claim(self._h, int(nbytes)), "set_lds_claim")
+
     def history(self):
         return _lib.lib().aisx_corr_history(self._h)
 

@@ -310,7 +310,9 @@ struct aisx_corr {
     // F = 4096 with dma: 0 = k_corr4d.h, 1 = the 512-thread build k_corr4e.h, 2 = k_corr4f.h (1 and 2: the template
     // spectrum in the order of the 8 x 8 x 8 x 8 plan)
     int wide = AISX_CORR_WIDE_DEFAULT;
-    const void* dma_attr_set = nullptr; // build whose dynamic-LDS limit has been raised
+    const void* dma_attr_set = nullptr; // build whose dynamic-LDS limit has been raised ...
+    int dma_attr_bytes = 0;             // ... and to how many bytes
+    int lds_claim = 0; // aisx_corr_set_lds_claim: LDS a workgroup of the F = 4096 build claims beyond what it uses
     float sps = 0, thresh = 0;
     unsigned mark_delay = 0;
     std::vector<cf> symbols; // d_symbols
@@ -651,16 +653,18 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         AISX_HIPCHK(hipEventRecord(h->ev0[evi], st));
     int rc_launch = AISX_OK;
     auto launch_big_lds = [&](void (*kern)(CorrParams), int threads, int lds_bytes) -> int {
-        if (h->dma_attr_set != (const void*)kern) { // (per handle: handles may live on different devices)
+        if (h->dma_attr_set != (const void*)kern || lds_bytes > h->dma_attr_bytes) { // (per handle: handles may live on different devices)
             AISX_HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
             h->dma_attr_set = (const void*)kern;
+            h->dma_attr_bytes = lds_bytes;
         }
         hipLaunchKernelGGL(kern, dim3(nseg, h->nchan), dim3(threads), lds_bytes, st, p);
         return AISX_OK;
     };
 #ifdef AISX_EXPERIMENTS
     // (LDS a workgroup claims beyond what it uses decides how many of them fit beside the timing recovery's 92 160 bytes on a CU)
-    static const int lds_pad = exp_env("AISX_CORR_LDS_PAD") ? atoi(exp_env("AISX_CORR_LDS_PAD")) : 0;
+    static const int lds_pad_env = exp_env("AISX_CORR_LDS_PAD") ? atoi(exp_env("AISX_CORR_LDS_PAD")) : 0;
+    const int lds_pad = lds_pad_env + h->lds_claim;
     if (h->F == CF_F && !dma)
         hipLaunchKernelGGL(k_corr_main, dim3(nseg, h->nchan), dim3(CF_T), CF_LDS_BYTES, st, p);
     else if (h->F == CF4_F && !dma)
@@ -671,7 +675,7 @@ extern "C" int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_st
         rc_launch = launch_big_lds(corr4e_pick(h->N), CE_T, CE_LDS_BYTES + lds_pad);
     else
 #else
-    const int lds_pad = 0;
+    const int lds_pad = h->lds_claim;
 #endif
     if (h->F == CF_F)
         hipLaunchKernelGGL(corr2d_pick(h->N), dim3(nseg, h->nchan), dim3(CF_T), C2_LDS_BYTES, st, p);
@@ -760,6 +764,16 @@ extern "C" int aisx_corr_kernel_ms_history(aisx_corr* h, float* ms, int cap, int
         w++;
     }
     *n = w;
+    return AISX_OK;
+}
+
+extern "C" int aisx_corr_set_lds_claim(aisx_corr* h, int bytes)
+{
+    if (!h || bytes < 0 || bytes > 96 * 1024) {
+        set_err("aisx_corr_set_lds_claim: 0 .. 98304 bytes");
+        return AISX_ERR_INVALID;
+    }
+    h->lds_claim = bytes;
     return AISX_OK;
 }
 

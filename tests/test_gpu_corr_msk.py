@@ -492,3 +492,27 @@ def test_full_size_properties(ais):
         _, infos = synth.make_channel(4000 + c, T, "P", sps, amp=1.0, cfo_max=15.0)
         ncmp += assert_decoded_bursts_identical(bits[c, : prod[c]], ob, infos)[0]
     assert ncmp > 50
+
+
+def test_corr_lds_claim_changes_placement_not_results(ais):
+    # aisx_corr_set_lds_claim is a placement knob of the F = 4096 build: outputs, correlation and tags of a claiming handle are
+    # those of its twin, byte for byte, before and after the claim is set and taken back; out-of-range values are refused
+    rng = np.random.default_rng(77)
+    N, n, nchan = 896, 3 * 3200 + 517, 6
+    tmpl = unit_template(rng, N)
+    x = planted(rng, nchan, 2 * n, tmpl, [[700, 5000, n + 100], [5], [], [n - N // 2], [2 * n - N - 3], [1234, 9000]])
+    a = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=nchan, max_items=n)
+    b = ais.corr_est_cc(tmpl, 4.0, 1, 0.9, nchan=nchan, max_items=n)
+    for i, claim in enumerate((17408, 0)):
+        b.set_lds_claim(claim)
+        xa = _dev(x[:, i * n:(i + 1) * n])
+        oa, ca = a.work(xa, want_corr=True)
+        ob, cb = b.work(xa, want_corr=True)
+        assert np.array_equal(oa.cpu().numpy().view(np.uint32), ob.cpu().numpy().view(np.uint32))
+        assert np.array_equal(ca.cpu().numpy().view(np.uint32), cb.cpu().numpy().view(np.uint32))
+        assert a.tags().tobytes() == b.tags().tobytes()
+    assert len(a.tags()) > 0
+    with pytest.raises(ValueError):
+        b.set_lds_claim(-1)
+    with pytest.raises(ValueError):
+        b.set_lds_claim(1 << 20)
