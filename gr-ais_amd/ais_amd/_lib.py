@@ -153,6 +153,8 @@ def lib(device=True):
     sig("aisx_agc_set_streaming", i32, [vp, i32])
     sig("aisx_agc_set_lds_claim", i32, [vp, i32])
     sig("aisx_agc_get_lds_claim", i32, [vp, pi32, pi32])
+    sig("aisx_freqsync_set_walk_lds_claim", i32, [vp, i32])
+    sig("aisx_freqsync_get_walk_lds_claim", i32, [vp, pi32, pi32])
     sig("aisx_msk_placement", i32, [vp, pi32, pi32])
     sig("aisx_agc_process", i32, [vp, vp, lng, vp, lng, i32, vp])
     sig("aisx_chain_create", i32, [pvp, vp, vp, vp, vp, i32, i32, i32])

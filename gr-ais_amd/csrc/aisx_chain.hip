@@ -14,6 +14,7 @@ struct aisx_chain {
     aisx_freqsync* fs = nullptr; // borrowed; null = core chain (corr_est -> msk only)
     aisx_agc* agc = nullptr;     // borrowed
     int agc_claim_prev = -1;     // the handle's LDS claim before this chain set its own (-1: the chain set none)
+    int walk_claim_prev = -1;    // ... and the phase walk's (aisx_freqsync_set_walk_lds_claim)
     aisx_corr* corr = nullptr;   // borrowed
     aisx_msk* msk = nullptr;     // borrowed
     int nchan = 0, max_items = 0, fftlen = 0;
@@ -48,8 +49,10 @@ static void chain_free(aisx_chain* h)
         return;
     if (h->msk)
         (void)aisx_msk_set_tail_stream(h->msk, nullptr, 0);
-    if (h->agc && h->agc_claim_prev >= 0) // (the placement claim is the chain's: the handle goes back as it came)
+    if (h->agc && h->agc_claim_prev >= 0) // (the placement claims are the chain's: the handles go back as they came)
         (void)aisx_agc_set_lds_claim(h->agc, h->agc_claim_prev);
+    if (h->fs && h->walk_claim_prev >= 0)
+        (void)aisx_freqsync_set_walk_lds_claim(h->fs, h->walk_claim_prev);
     for (hipStream_t s : { h->s_main, h->s_msk, h->s_tail, h->s_walk })
         if (s)
             (void)hipStreamSynchronize(s);
@@ -252,6 +255,20 @@ extern "C" int aisx_chain_create(aisx_chain** out, aisx_freqsync* fs, aisx_agc* 
         if ((rc = aisx_agc_set_lds_claim(agc, claim)) != AISX_OK) {
             chain_free(h);
             return rc;
+        }
+        // The phase walk's one-wave workgroups (3 KB) likewise, while the recovery leaves half of the CUs free: one of them
+        // beside a recovery workgroup delays its recurrence and takes the LDS the correlator's workgroup would have had
+        // there (4096 channels: the step 5.43-5.47 against 5.47-5.53 ms, the correlator 1.45-1.47 against 1.52-1.54).
+        // With a recovery workgroup on more than half of the CUs the walk has to run beside them: no claim.
+        if (fs && ncu > 0 && 2 * msk_wgs <= ncu) {
+            int wprev = 0, wused = 0;
+            (void)aisx_freqsync_get_walk_lds_claim(fs, &wprev, &wused);
+            const int wclaim = chain_front_claim(ncu, lds_cu, msk_wgs, msk_lds, wused);
+            h->walk_claim_prev = wprev;
+            if ((rc = aisx_freqsync_set_walk_lds_claim(fs, wclaim)) != AISX_OK) {
+                chain_free(h);
+                return rc;
+            }
         }
     }
     if (!h->serial) {

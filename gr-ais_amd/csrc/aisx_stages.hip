@@ -152,6 +152,9 @@ struct aisx_freqsync {
     // made by aisx_freqest_create with a vector length the freq_sync kernels do not implement: the handle serves
     // aisx_freqest_work / aisx_freqest_work_host only (the search over bins needs no transform of ours)
     bool est_only = false;
+    // aisx_freqsync_set_walk_lds_claim: LDS a workgroup of the phase walk claims beyond the 3 KB it uses, and what this
+    // handle has raised the kernel's dynamic-LDS limit to
+    int walk_claim = 0, walk_attr = 64 * 1024;
     float binsize = 0, sensitivity = 0;
     cf* d_pend[2] = { nullptr, nullptr };
     int cur = 0, npend = 0;
@@ -627,6 +630,27 @@ extern "C" int aisx_agc_set_floor(aisx_agc* h, float floor_env)
     return AISX_OK;
 }
 
+extern "C" int aisx_freqsync_set_walk_lds_claim(aisx_freqsync* h, int bytes)
+{
+    if (!h || bytes < 0 || bytes > 144 * 1024) {
+        set_err("aisx_freqsync_set_walk_lds_claim: 0 .. 147456 bytes");
+        return AISX_ERR_INVALID;
+    }
+    h->walk_claim = bytes;
+    return AISX_OK;
+}
+
+extern "C" int aisx_freqsync_get_walk_lds_claim(const aisx_freqsync* h, int* bytes, int* used_bytes)
+{
+    if (!h)
+        return AISX_ERR_INVALID;
+    if (bytes)
+        *bytes = h->walk_claim;
+    if (used_bytes)
+        *used_bytes = FSW_LDS_BYTES;
+    return AISX_OK;
+}
+
 extern "C" int aisx_agc_set_lds_claim(aisx_agc* h, int bytes)
 {
     if (!h || bytes < 0 || bytes > 144 * 1024) {
@@ -802,7 +826,15 @@ static int fs_estimate_into_slot(aisx_freqsync* h, const aisx_cf32* d_in, long i
     w.nvec = nvec;
     w.binsize = h->binsize;
     w.sensitivity = h->sensitivity;
-    hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES, st_walk, w);
+    // (LDS the walk's one-wave workgroups claim beyond what they use: aisx_freqsync_set_walk_lds_claim; experiments:
+    // AISX_WALK_LDS_PAD, bytes, overrides it)
+    static const int walk_pad_env = exp_env("AISX_WALK_LDS_PAD") ? atoi(exp_env("AISX_WALK_LDS_PAD")) : -1;
+    const int walk_pad = walk_pad_env >= 0 ? walk_pad_env : h->walk_claim;
+    if (FSW_LDS_BYTES + walk_pad > h->walk_attr) {
+        AISX_HIPCHK(hipFuncSetAttribute((const void*)k_fs_walk, hipFuncAttributeMaxDynamicSharedMemorySize, FSW_LDS_BYTES + walk_pad));
+        h->walk_attr = FSW_LDS_BYTES + walk_pad;
+    }
+    hipLaunchKernelGGL(k_fs_walk, dim3((h->nchan + FSW_T - 1) / FSW_T), dim3(FSW_T), FSW_LDS_BYTES + walk_pad, st_walk, w);
     AISX_HIPCHK(hipGetLastError());
     AISX_HIPCHK(hipEventRecord(h->ev_walk, st_walk));
     AISX_HIPCHK(hipEventRecord(s.ev_ready, st_walk));

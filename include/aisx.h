@@ -296,6 +296,13 @@ int aisx_freqsync_geometry(const aisx_freqsync* h, int* nchan, int* max_items, i
  * made for); `stream`: where the next pass will run -- it waits for what the dropped preparations still
  * have in flight */
 int aisx_freqsync_drop_ahead(aisx_freqsync* h, void* stream);
+/* Placement knob (as aisx_agc_set_lds_claim): LDS a one-wave workgroup of the NCO phase walk (aisx_freqsync_estimate_ahead /
+ * aisx_freqsync_agc_process) claims beyond the 3 KB it uses.  aisx_chain_create sets it while the recovery leaves half of the
+ * CUs free, so that no walk workgroup lands on a CU that holds a recovery workgroup -- where it also shuts the correlator's
+ * workgroup out (4096 channels: the step 0.8 % shorter, the correlator 1.46 instead of 1.53 ms) -- and gives the handle its
+ * previous claim back when it is destroyed.  Results do not depend on it; default 0.  Not part of the GNU Radio API. */
+int aisx_freqsync_set_walk_lds_claim(aisx_freqsync* h, int bytes);
+int aisx_freqsync_get_walk_lds_claim(const aisx_freqsync* h, int* bytes, int* used_bytes);
 /* freqest::make(sample_rate, data_rate, fftlen) (include/ais/freqest.h:46) for the block on its own
  * (nchan == 1, aisx_freqest_work / aisx_freqest_work_host): d_offset and d_binsize from the FLOAT sample
  * rate as lib/freqest_impl.cc:46-47 compute them (aisx_freqsync_create truncates it to an int first, as
