@@ -115,8 +115,9 @@ int aisx_corr_process(aisx_corr* h, const aisx_cf32* d_in, long in_stride, aisx_
                       aisx_cf32* d_corr, long corr_stride, int n, void* stream);
 /* Placement knob (as aisx_agc_set_lds_claim): LDS a workgroup of the F = 4096 build (templates of 513 .. 2048 items) claims
  * beyond the ~55 KB it uses.  17 408 bytes keep its workgroups off the CUs that hold a timing-recovery workgroup (55 + 17 KB
- * does not fit beside 90) while two still fit a free CU: in the 4096-channel chain the recovery then runs 0.25 ms shorter
- * and the step 3 % (5.31 against 5.49 ms), the correlator itself a third longer (1.98 against 1.50 ms) -- a caller's choice
+ * does not fit beside 90) while two still fit a free CU: in the 4096-channel chain the recovery then runs up to 0.25 ms shorter
+ * and the step up to 3 % (5.31 against 5.49 ms on one box, nothing on another), the correlator itself a third longer (1.98
+ * against 1.50 ms) -- a caller's choice
  * between the step and this kernel's own rate; aisx_chain_create leaves it alone (bench.py: config.side.corr_off_recovery_cus).
  * Results do not depend on it; default 0.  Not part of the GNU Radio API. */
 int aisx_corr_set_lds_claim(aisx_corr* h, int bytes);
