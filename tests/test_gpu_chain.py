@@ -210,3 +210,39 @@ def test_wait_prepass_is_an_event_wait_unless_a_head_start_is_asked_for(ais):
     L = _lib.lib()
     assert L.aisx_msk_set_head_start(blk._h, 20) == 0 and L.aisx_msk_set_head_start(blk._h, 0) == 0
     assert L.aisx_msk_set_head_start(blk._h, -1) == _lib.AISX_ERR_INVALID
+
+
+def test_chain_sets_its_placement_claims_and_gives_the_handles_theirs_back(ais):
+    """aisx_chain_create derives LDS claims for the front-end kernel and the phase walk from the part and the recovery's launch
+    (aisx_chain.hip: chain_front_claim) and sets them on the borrowed handles; what the caller had set before comes back when
+    the chain is destroyed.  Few channels = the recovery leaves more than half of the CUs free = both claims non-zero."""
+    import ctypes as C
+    from ais_amd import _lib
+
+    L = _lib.lib()
+    tmpl = np.ones(112, np.complex64)
+    fs, agc, corr, msk, ch = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.aisx_freqsync_create(C.byref(fs), 38400.0, 9600.0, 1024, 8, 4096) == 0
+    assert L.aisx_agc_create(C.byref(agc), 512, 2.0, 8, 4096 + 1024) == 0
+    assert L.aisx_corr_create(C.byref(corr), tmpl.ctypes.data_as(C.c_void_p), 112, 4.0, 1, 0.9, 8, 4096 + 1024, 512) == 0
+    assert L.aisx_msk_create(C.byref(msk), 4.0, 0.04, 0.01, 1, 8, 4096 + 1024) == 0
+    assert L.aisx_agc_set_lds_claim(agc, 5 * 1024) == 0 and L.aisx_freqsync_set_walk_lds_claim(fs, 7 * 1024) == 0
+
+    def claims():
+        a, w, ua, uw = C.c_int(-1), C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        assert L.aisx_agc_get_lds_claim(agc, C.byref(a), C.byref(ua)) == 0
+        assert L.aisx_freqsync_get_walk_lds_claim(fs, C.byref(w), C.byref(uw)) == 0
+        assert ua.value > 0 and uw.value > 0
+        return a.value, w.value
+
+    wgs, lds = C.c_int(0), C.c_int(0)
+    assert L.aisx_msk_placement(msk, C.byref(wgs), C.byref(lds)) == 0 and wgs.value == 1 and 0 < lds.value < 160 * 1024
+    assert claims() == (5 * 1024, 7 * 1024)
+    assert L.aisx_chain_create(C.byref(ch), fs, agc, corr, msk, 8, 4096, 1024) == 0
+    a, w = claims()
+    assert a > 160 * 1024 - lds.value - 16 * 1024 and w > a  # (none of either fits beside a recovery workgroup)
+    assert L.aisx_chain_destroy(ch) == 0
+    assert claims() == (5 * 1024, 7 * 1024)
+    assert L.aisx_freqsync_set_walk_lds_claim(fs, -1) == _lib.AISX_ERR_INVALID
+    for h, d in ((fs, L.aisx_freqsync_destroy), (agc, L.aisx_agc_destroy), (corr, L.aisx_corr_destroy), (msk, L.aisx_msk_destroy)):
+        d(h)
